@@ -1,0 +1,155 @@
+// ksw_device.h -- device-side pieces of the banded dual-affine anti-diagonal DP for gfx950.
+//
+// Replaces ksw_extd2_sse / ksw_extz2_sse (reference: src/kswlib/ksw2_extd2_sse.c:26-396,
+// ksw2_extz2_sse.c:23-305) and ksw_backtrack_D / ksw_apply_zdrop (src/kswlib/ksw2.h:119-151,245-261).
+//
+// Design (MI355X-first, not a port of the SSE code):
+//   * one 64-lane wavefront owns one alignment; lane L of chunk c owns target column t = 64c + L
+//     for the whole run, so the eight per-column DP state values (u,v,x,y,x2,y2,s,H) never leave
+//     VGPRs;  the (r-1,t-1) neighbours arrive by a DPP wave_shr:1 with the inter-chunk carry fed
+//     through v_readlane;
+//   * chunks of one anti-diagonal are visited from high t to low t so the carry is still "old";
+//   * the 7-bit direction bytes of the band are staged in LDS (one row per anti-diagonal, the
+//     reference's n_col_*16 row pitch) and the traceback walks them from LDS;
+//   * the per-diagonal exact max / arg-max (with the reference's 4-lane tie-break order) is a
+//     two-pass DPP row_shr/row_bcast wave reduction, no LDS traffic;
+//   * the reference's 16-lane block rounding of [st,en] is kept bit-for-bit: lanes outside the band
+//     but inside the rounded block are computed and later read back exactly as the SSE code does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/psvr_engine.h"
+
+namespace psvr {
+
+struct DpParams {
+	int32_t m;
+	int32_t q, e, q2, e2;       // after the q+e <= q2+e2 swap (ksw2_extd2_sse.c:70)
+	int32_t qe_pre;             // q+e BEFORE the swap: only feeds H[0] at r==0 (:60,351)
+	int32_t sc_mch, sc_mis, sc_N, m1;
+	int32_t w, zdrop, end_bonus, flag;
+	int32_t long_thres, long_diff;
+	int32_t skip;               // 1: parameter set makes the reference return right after reset (:68,93)
+	int8_t  mat[25];
+};
+
+struct DpBatch { // device pointers of one batch
+	const int32_t *idx;        // problem ids handled by this launch (one per workgroup)
+	const uint8_t *qseq; const int64_t *q_off; const int32_t *qlen;
+	const uint8_t *tseq; const int64_t *t_off; const int32_t *tlen;
+	psvr_extz_t *ez; uint32_t *cigar;
+	uint8_t *pslab; const int64_t *p_off;   // lds kernel only: direction-byte slab
+};
+
+template <int K> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
+template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
+
+__device__ __forceinline__ int s8(int v) { return (int)(int8_t)v; }
+
+// DPP controls (GFX9): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+__device__ __forceinline__ int dpp_wave_shr1(int v, int carry_in)
+{
+	return __builtin_amdgcn_update_dpp(carry_in, v, 0x138, 0xf, 0xf, false);
+}
+
+// wave-wide max of a signed 32-bit value; result valid in every lane (broadcast from lane 63)
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+	const int idn = (int)0x80000000;
+	int t;
+	t = __builtin_amdgcn_update_dpp(idn, v, 0x111, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(idn, v, 0x112, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(idn, v, 0x114, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(idn, v, 0x118, 0xf, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(idn, v, 0x142, 0xa, 0xf, false); v = max(v, t);
+	t = __builtin_amdgcn_update_dpp(idn, v, 0x143, 0xc, 0xf, false); v = max(v, t);
+	return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+	const int idn = (int)0xffffffff;
+	unsigned t;
+	t = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)v, 0x111, 0xf, 0xf, false); v = min(v, t);
+	t = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)v, 0x112, 0xf, 0xf, false); v = min(v, t);
+	t = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)v, 0x114, 0xf, 0xf, false); v = min(v, t);
+	t = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)v, 0x118, 0xf, 0xf, false); v = min(v, t);
+	t = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)v, 0x142, 0xa, 0xf, false); v = min(v, t);
+	t = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)v, 0x143, 0xc, 0xf, false); v = min(v, t);
+	return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// band limits of anti-diagonal r (ksw2_extd2_sse.c:125-140); returns false when st > en
+__device__ __forceinline__ bool band_limits(int r, int qlen, int tlen, int w, int &st0, int &en0, int &st, int &en)
+{
+	st0 = 0, en0 = tlen - 1;
+	if (st0 < r - qlen + 1) st0 = r - qlen + 1;
+	if (en0 > r) en0 = r;
+	if (st0 < ((r - w + 1) >> 1)) st0 = (r - w + 1) >> 1;
+	if (en0 > ((r + w) >> 1)) en0 = (r + w) >> 1;
+	st = st0 & ~15;
+	en = ((en0 + 16) & ~15) - 1;
+	return st0 <= en0;
+}
+
+struct EzAcc { // running ksw_extz_t (uniform per wave)
+	int max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end;
+	__device__ __forceinline__ void reset()
+	{
+		max_q = max_t = mqe_t = mte_q = -1;
+		max = 0, score = mqe = mte = PSVR_KSW_NEG_INF;
+		zdropped = 0, reach_end = 0;
+	}
+	// ksw_apply_zdrop with is_rot=1 (ksw2.h:245-261)
+	__device__ __forceinline__ bool apply_zdrop(int H, int r, int t, int zdrop, int e)
+	{
+		if (H > max) {
+			max = H, max_t = t, max_q = r - t;
+		} else if (t >= max_t && r - t >= max_q) {
+			int tl = t - max_t, ql = (r - t) - max_q;
+			int l = tl > ql ? tl - ql : ql - tl;
+			if (zdrop >= 0 && max - H > zdrop + l * e) {
+				zdropped = 1;
+				return true;
+			}
+		}
+		return false;
+	}
+};
+
+// Traceback over direction bytes (ksw_backtrack_D with is_rot=1, min_intron_len=0; ksw2.h:119-151).
+// `P` reads one byte of row r at column offset k; ops are staged through `emit(k, word)`.
+// Every lane runs the same (uniform) walk.  Returns the number of CIGAR ops.
+template <class ReadP, class Emit>
+__device__ __forceinline__ int traceback(int i0, int j0, int qlen, int tlen, int w, ReadP readp, Emit emit)
+{
+	int i = i0, j = j0, state = 0, n = 0;
+	int cur_op = -1, cur_len = 0;
+	auto push = [&](int op, int len) {
+		if (op == cur_op) cur_len += len;
+		else {
+			if (cur_op >= 0) emit(n++, (uint32_t)cur_len << 4 | (uint32_t)cur_op);
+			cur_op = op, cur_len = len;
+		}
+	};
+	while (i >= 0 && j >= 0) {
+		int r = i + j, st0, en0, off, off_end, force_state = -1;
+		band_limits(r, qlen, tlen, w, st0, en0, off, off_end);
+		if (i < off) force_state = 2;
+		if (i > off_end) force_state = 1;
+		int tmp = force_state < 0 ? readp(r, i - off) : 0;
+		if (state == 0) state = tmp & 7;
+		else if (!((tmp >> (state + 2)) & 1)) state = 0;
+		if (state == 0) state = tmp & 7;
+		if (force_state >= 0) state = force_state;
+		if (state == 0) push(0, 1), --i, --j;
+		else if (state == 1 || state == 3) push(2, 1), --i;
+		else push(1, 1), --j;
+	}
+	if (i >= 0) push(2, i + 1);
+	if (j >= 0) push(1, j + 1);
+	if (cur_op >= 0) emit(n++, (uint32_t)cur_len << 4 | (uint32_t)cur_op);
+	return n;
+}
+
+} // namespace psvr

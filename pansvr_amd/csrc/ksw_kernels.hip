@@ -1,0 +1,439 @@
+// ksw_kernels.hip -- K4 `extd2_dp`: the banded dual-affine anti-diagonal DP on gfx950.
+// See ksw_device.h for the design.  Two kernels:
+//   extd2_reg_kernel<K>  : fast path. tlen rounded to 16 fits 64*K columns (K<=5, i.e. tlen<=320),
+//                          DP state in VGPRs, direction bytes in LDS, traceback from LDS.
+//   extd2_lds_kernel     : general path (any shape the C ABI accepts, all KSW_EZ flags, and the
+//                          single-affine extz2 variant): DP state in LDS, direction bytes in a
+//                          global scratch slab.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ksw_device.h"
+
+namespace psvr {
+
+__device__ __forceinline__ void write_ez(psvr_extz_t *o, const EzAcc &a, int n_cigar)
+{
+	o->max = a.max, o->zdropped = a.zdropped;
+	o->max_q = a.max_q, o->max_t = a.max_t;
+	o->mqe = a.mqe, o->mqe_t = a.mqe_t;
+	o->mte = a.mte, o->mte_q = a.mte_q;
+	o->score = a.score, o->n_cigar = n_cigar, o->reach_end = a.reach_end, o->reserved = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// fast path
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	const int pid = B.idx[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
+	psvr_extz_t *out = B.ez + pid;
+	EzAcc ez;
+	ez.reset();
+	if (P.skip || qlen <= 0 || tlen <= 0) {
+		if (lane == 0) write_ez(out, ez, 0);
+		return;
+	}
+	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
+	const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
+	int n_col = qlen < tlen ? qlen : tlen;
+	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
+	const int rowb = n_col * 16;
+	const int n_rows = qlen + tlen - 1;
+	const int qimg = (qlen + 16 + 15) & ~15;
+	uint8_t *QR = lds;                 // reversed query + >=16 zero bytes (the calloc'ed tail of `qr`, :100,121)
+	uint8_t *Pm = lds + qimg;          // direction bytes, row pitch rowb (:115)
+	const int p_end = n_rows * rowb + 16;
+	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
+
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
+	int u[K], v[K], x[K], y[K], x2[K], y2[K], s[K], H[K], tb[K];
+#pragma unroll
+	for (int c = 0; c < K; ++c) {
+		int t = c * 64 + lane;
+		u[c] = v[c] = x[c] = y[c] = neg_qe;
+		x2[c] = y2[c] = neg_qe2;
+		s[c] = 0;
+		H[c] = PSVR_KSW_NEG_INF;
+		tb[c] = t < tlen ? target[t] : 0;
+	}
+	__syncthreads();
+
+	int last_st = -1;
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
+	for (int r = 0; r < n_rows; ++r) {
+		int st0, en0, st, en;
+		if (!band_limits(r, qlen, tlen, w, st0, en0, st, en)) { ez.zdropped = 1; break; }
+		const bool adv = st > 0 && st > last_st;   // (r-1,st-1) was computed last round (:143)
+		const int ur = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
+		const int fresh_end = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;  // score groups of 16 from st0 (:159)
+		const int qbase = qlen - 1 - r;
+		const int c_first = st >> 6, c_last = en >> 6;
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
+		int h_prev = 0;                                  // H[en0-1] of the previous diagonal (:322)
+		if (en0 > 0) {
+#pragma unroll
+			for (int c = 0; c < K; ++c)
+				if (((en0 - 1) >> 6) == c) h_prev = __builtin_amdgcn_readlane(H[c], (en0 - 1) & 63);
+		}
+		int bh = (int)0x80000000; unsigned bk = 0xffffffffu;
+		uint8_t *prow = Pm + r * rowb - st;
+#pragma unroll
+		for (int c = K - 1; c >= 0; --c) {
+			if (c < c_first || c > c_last) continue;
+			const int t = c * 64 + lane;
+			if (en >= r && t == r) { y[c] = neg_qe; y2[c] = neg_qe2; u[c] = ur; }   // (:153-156)
+			int cx = 0, cv = 0, cx2 = 0;
+			if (c > 0) {
+				cx = __builtin_amdgcn_readlane(x[c - 1], 63);
+				cv = __builtin_amdgcn_readlane(v[c - 1], 63);
+				cx2 = __builtin_amdgcn_readlane(x2[c - 1], 63);
+			}
+			int xt1 = dpp_wave_shr1(x[c], cx), vt1 = dpp_wave_shr1(v[c], cv), x2t1 = dpp_wave_shr1(x2[c], cx2);
+			if (t == st && !adv) { xt1 = neg_qe; x2t1 = neg_qe2; vt1 = st > 0 ? neg_qe : ur; }    // (:142-152)
+			if (t >= st0 && t <= fresh_end) {                 // fresh score (:158-173)
+				int qb = QR[qbase + t];
+				int sc = tb[c] == qb ? P.sc_mch : P.sc_mis;
+				s[c] = (tb[c] == P.m1 || qb == P.m1) ? P.sc_N : sc;
+			}
+			if (t >= st && t <= en) {
+				int z = s[c], ut = u[c];
+				int a = s8(xt1 + vt1), b = s8(y[c] + ut), a2 = s8(x2t1 + vt1), b2 = s8(y2[c] + ut);
+				int d = 0;
+				if (a > z)  d = 1, z = a;
+				if (b > z)  d = 2, z = b;
+				if (a2 > z) d = 3, z = a2;
+				if (b2 > z) d = 4, z = b2;
+				z = min(z, P.sc_mch);
+				int un = s8(z - vt1), vn = s8(z - ut);
+				int tmp = s8(z - P.q);
+				a = s8(a - tmp), b = s8(b - tmp);
+				tmp = s8(z - P.q2);
+				a2 = s8(a2 - tmp), b2 = s8(b2 - tmp);
+				u[c] = un, v[c] = vn;
+				x[c]  = s8(max(a, 0) - qe8);   d |= a  > 0 ? 0x08 : 0;
+				y[c]  = s8(max(b, 0) - qe8);   d |= b  > 0 ? 0x10 : 0;
+				x2[c] = s8(max(a2, 0) - qe28); d |= a2 > 0 ? 0x20 : 0;
+				y2[c] = s8(max(b2, 0) - qe28); d |= b2 > 0 ? 0x40 : 0;
+				if (with_cigar) prow[t] = (uint8_t)d;
+				// exact H tracking (:316-351)
+				if (r == 0) { if (t == 0) H[c] = vn - P.qe_pre; }
+				else if (t >= st0 && t < en0) H[c] += vn;
+				else if (t == en0) H[c] = en0 > 0 ? h_prev + un : H[c] + vn;
+				if (t >= st0 && t <= en0) {
+					unsigned rank = t == en0 ? 0u : t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
+					                                        : 1u + 4u * 4096u + (unsigned)(t - st0);
+					if (H[c] > bh || (H[c] == bh && rank < bk)) bh = H[c], bk = rank;
+				}
+			}
+		}
+		const int max_H = wave_max_i32(bh);
+		const unsigned rk = wave_min_u32(bh == max_H ? bk : 0xffffffffu);
+		const int max_t = rk == 0 ? en0 : st0 + (int)((rk - 1u) & 4095u);
+		int H_en0 = 0, H_st0 = 0;
+#pragma unroll
+		for (int c = 0; c < K; ++c) {
+			if ((en0 >> 6) == c) H_en0 = __builtin_amdgcn_readlane(H[c], en0 & 63);
+			if ((st0 >> 6) == c) H_st0 = __builtin_amdgcn_readlane(H[c], st0 & 63);
+		}
+		if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - en;
+		if (r - st0 == qlen - 1 && H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
+		if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) break;
+		if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H_en0;
+		last_st = st;
+	}
+	int n_cigar = 0;
+	if (with_cigar) {
+		__syncthreads();
+		int i0 = -1, j0 = -1;
+		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+		else if (!ez.zdropped && (P.flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
+		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+		if (i0 >= 0 && j0 >= 0) {
+			// ops are staged in the already-consumed tail of the direction-byte area (rows > r are dead)
+			uint32_t *stage_end = (uint32_t*)(Pm + p_end);
+			n_cigar = traceback(i0, j0, qlen, tlen, w,
+				[&](int r, int k) { return (int)Pm[r * rowb + k]; },
+				[&](int k, uint32_t word) { if (lane == 0) stage_end[-1 - k] = word; });
+			__syncthreads();
+			uint32_t *dst = B.cigar + out->cigar_off;
+			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
+			for (int m = lane; m < n_cigar; m += 64)
+				dst[m] = rev ? stage_end[-1 - m] : stage_end[-n_cigar + m];
+		}
+	}
+	if (lane == 0) write_ez(out, ez, n_cigar);
+}
+
+template __global__ void extd2_reg_kernel<1>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<2>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<3>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<4>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<5>(DpBatch, DpParams);
+
+
+// ------------------------------------------------------------------------------------------
+// general path: DP state in LDS laid out exactly like the reference's flat image
+//   extd2: u|v|x|y|x2|y2|s|sf|qr   (ksw2_extd2_sse.c:100-103)
+//   extz2: u|v|x|y|s|sf|qr         (ksw2_extz2_sse.c:85-87)
+// so that the unaligned 16-byte score loads/stores that run past an array behave identically.
+// Direction bytes go to a global slab (they can exceed LDS for long sequences).
+// VAR = 0: dual affine (extd2);  VAR = 1: single affine (extz2, SSE2 code path).
+// ------------------------------------------------------------------------------------------
+template <int VAR>
+__global__ __launch_bounds__(64) void extd2_lds_kernel(DpBatch B, DpParams P)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	const int pid = B.idx[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
+	psvr_extz_t *out = B.ez + pid;
+	EzAcc ez;
+	ez.reset();
+	if (P.skip || qlen <= 0 || tlen <= 0) {
+		if (lane == 0) write_ez(out, ez, 0);
+		return;
+	}
+	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
+	const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
+	int n_col = qlen < tlen ? qlen : tlen;
+	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
+	const int rowb = n_col * 16;
+	const int n_rows = qlen + tlen - 1;
+	const int T = ((tlen + 15) / 16) * 16, QL = ((qlen + 15) / 16) * 16;
+	constexpr int NARR = VAR == 0 ? 7 : 5;
+	int8_t *u8 = (int8_t*)lds, *v8 = u8 + T, *x8 = v8 + T, *y8 = x8 + T;
+	int8_t *x28 = VAR == 0 ? y8 + T : nullptr, *y28 = VAR == 0 ? x28 + T : nullptr;
+	int8_t *sa = VAR == 0 ? y28 + T : y8 + T;
+	uint8_t *sf = (uint8_t*)(sa + T), *qr = sf + T;
+	const int img = NARR * T + T + QL + 16;            // bytes of the byte image (+16 calloc tail)
+	int32_t *H = (int32_t*)(lds + ((img + 15) & ~15));
+	uint8_t *Pm = B.pslab + B.p_off[pid];
+	const int flag = P.flag;
+	const int with_cigar = !(flag & PSVR_EZ_SCORE_ONLY), approx_max = !!(flag & PSVR_EZ_APPROX_MAX);
+	const int right = with_cigar && (flag & PSVR_EZ_RIGHT);
+
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
+	const int qe = P.q + P.e;                       // extz2: no swap, qe used throughout
+	for (int i = lane; i < img; i += 64) {
+		int a = i / T;                               // which array
+		uint8_t val = 0;
+		if (VAR == 0) { if (a < 4) val = (uint8_t)neg_qe; else if (a < 6) val = (uint8_t)neg_qe2; }
+		if (a == NARR) { int t = i - NARR * T; val = t < tlen ? target[t] : 0; }
+		if (a > NARR)  { int k = i - (NARR + 1) * T; val = k < qlen ? query[qlen - 1 - k] : 0; }
+		lds[i] = val;
+	}
+	for (int i = lane; i < T; i += 64) H[i] = PSVR_KSW_NEG_INF;
+	__syncthreads();
+
+	int last_st = -1, last_en = -1, H0 = 0, last_H0_t = 0;
+	const uint8_t qe2b = (uint8_t)((P.q + P.e) * 2), max_scb = (uint8_t)(P.mat[0] + (P.q + P.e) * 2), qb8 = (uint8_t)P.q;
+	for (int r = 0; r < n_rows; ++r) {
+		int st0, en0, st, en;
+		if (!band_limits(r, qlen, tlen, w, st0, en0, st, en)) { ez.zdropped = 1; break; }
+		int x1, x21 = 0, v1;
+		if (VAR == 0) {
+			if (st > 0) {
+				if (st - 1 >= last_st && st - 1 <= last_en) x1 = x8[st - 1], x21 = x28[st - 1], v1 = v8[st - 1];
+				else x1 = neg_qe, x21 = neg_qe2, v1 = neg_qe;
+			} else {
+				x1 = neg_qe, x21 = neg_qe2;
+				v1 = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
+			}
+		} else {
+			if (st > 0) {
+				if (st - 1 >= last_st && st - 1 <= last_en) x1 = x8[st - 1], v1 = v8[st - 1];   // int8_t in the reference (:104,121)
+				else x1 = v1 = 0;
+			} else x1 = 0, v1 = r ? s8(P.q) : 0;
+		}
+		__syncthreads();
+		if (en >= r && lane == 0) {
+			if (VAR == 0) {
+				y8[r] = neg_qe, y28[r] = neg_qe2;
+				u8[r] = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
+			} else y8[r] = 0, u8[r] = r ? (int8_t)qb8 : 0;
+		}
+		// scores
+		const uint8_t *qrr = qr + (qlen - 1 - r);
+		if (!(flag & PSVR_EZ_GENERIC_SC)) {
+			const int fresh_end = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;
+			for (int t0 = st0; t0 <= fresh_end; t0 += 64) {
+				int t = t0 + lane;
+				if (t <= fresh_end) {
+					uint8_t sq = sf[t], sq2 = qrr[t];
+					int sc = sq == sq2 ? P.sc_mch : P.sc_mis;
+					if (sq == (uint8_t)P.m1 || sq2 == (uint8_t)P.m1) sc = P.sc_N;
+					sa[t] = (int8_t)sc;
+				}
+			}
+		} else {
+			for (int t = st0 + lane; t <= en0; t += 64) sa[t] = P.mat[sf[t] * P.m + qrr[t]];
+		}
+		__syncthreads();
+		// core: 64-lane groups from high t to low t
+		const int ngrp = (en - st) / 64 + 1;
+		for (int g = ngrp - 1; g >= 0; --g) {
+			const int t = st + g * 64 + lane;
+			if (t <= en) {
+				int d = 0;
+				if (VAR == 0) {
+					int xt1 = t == st ? x1 : (int)x8[t - 1], vt1 = t == st ? v1 : (int)v8[t - 1], x2t1 = t == st ? x21 : (int)x28[t - 1];
+					int z = sa[t], ut = u8[t];
+					int a = s8(xt1 + vt1), b = s8(y8[t] + ut), a2 = s8(x2t1 + vt1), b2 = s8(y28[t] + ut);
+					if (!right) {
+						if (a > z)  d = 1, z = a;
+						if (b > z)  d = 2, z = b;
+						if (a2 > z) d = 3, z = a2;
+						if (b2 > z) d = 4, z = b2;
+					} else {
+						d = z > a ? 0 : 1;  z = z > a ? z : a;
+						d = z > b ? d : 2;  z = z > b ? z : b;
+						d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+						d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+					}
+					z = min(z, P.sc_mch);
+					u8[t] = (int8_t)(z - vt1), v8[t] = (int8_t)(z - ut);
+					int tmp = s8(z - P.q);
+					a = s8(a - tmp), b = s8(b - tmp);
+					tmp = s8(z - P.q2);
+					a2 = s8(a2 - tmp), b2 = s8(b2 - tmp);
+					if (!right) {
+						x8[t]  = (int8_t)(max(a, 0) - qe8);   d |= a  > 0 ? 0x08 : 0;
+						y8[t]  = (int8_t)(max(b, 0) - qe8);   d |= b  > 0 ? 0x10 : 0;
+						x28[t] = (int8_t)(max(a2, 0) - qe28); d |= a2 > 0 ? 0x20 : 0;
+						y28[t] = (int8_t)(max(b2, 0) - qe28); d |= b2 > 0 ? 0x40 : 0;
+					} else {
+						x8[t]  = (int8_t)(max(a, 0) - qe8);   d |= a  >= 0 ? 0x08 : 0;
+						y8[t]  = (int8_t)(max(b, 0) - qe8);   d |= b  >= 0 ? 0x10 : 0;
+						x28[t] = (int8_t)(max(a2, 0) - qe28); d |= a2 >= 0 ? 0x20 : 0;
+						y28[t] = (int8_t)(max(b2, 0) - qe28); d |= b2 >= 0 ? 0x40 : 0;
+					}
+				} else {
+					const int k = t - st;
+					unsigned x1w = (unsigned)x1, v1w = (unsigned)v1;   // sign-extended into lanes 1..3 (:147-148)
+					uint8_t xt1 = k == 0 ? 0 : (uint8_t)x8[t - 1], vt1 = k == 0 ? 0 : (uint8_t)v8[t - 1];
+					if (k < 4) xt1 |= (uint8_t)(x1w >> (8 * k)), vt1 |= (uint8_t)(v1w >> (8 * k));
+					uint8_t z = (uint8_t)((uint8_t)sa[t] + qe2b), a = (uint8_t)(xt1 + vt1), ut = (uint8_t)u8[t], b = (uint8_t)((uint8_t)y8[t] + ut);
+					if (!with_cigar) {
+						z = (int8_t)z > 0 ? z : 0; z = z > a ? z : a;
+					} else if (!right) {
+						d = (int8_t)a > (int8_t)z ? 1 : 0;
+						z = (int8_t)z > 0 ? z : 0; z = z > a ? z : a;
+						if ((int8_t)b > (int8_t)z) d = 2;
+					} else {
+						d = (int8_t)z > (int8_t)a ? 0 : 1;
+						z = (int8_t)z > 0 ? z : 0; z = z > a ? z : a;
+						if (!((int8_t)z > (int8_t)b)) d = 2;
+					}
+					z = z > b ? z : b;
+					z = z < max_scb ? z : max_scb;
+					u8[t] = (int8_t)(uint8_t)(z - vt1), v8[t] = (int8_t)(uint8_t)(z - ut);
+					z = (uint8_t)(z - qb8);
+					a = (uint8_t)(a - z), b = (uint8_t)(b - z);
+					if (!right) {
+						x8[t] = (int8_t)a > 0 ? (int8_t)a : 0; d |= (int8_t)a > 0 ? 0x08 : 0;
+						y8[t] = (int8_t)b > 0 ? (int8_t)b : 0; d |= (int8_t)b > 0 ? 0x10 : 0;
+					} else {
+						x8[t] = (int8_t)a < 0 ? 0 : (int8_t)a; d |= (int8_t)a < 0 ? 0 : 0x08;
+						y8[t] = (int8_t)b < 0 ? 0 : (int8_t)b; d |= (int8_t)b < 0 ? 0 : 0x10;
+					}
+				}
+				if (with_cigar) Pm[(size_t)r * rowb + (t - st)] = (uint8_t)d;
+			}
+			__syncthreads();
+		}
+		const int e_drop = VAR == 0 ? P.e2 : P.e;
+		if (!approx_max) {
+			int max_H, max_t;
+			if (r > 0) {
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				const int uen = VAR == 0 ? (int)u8[en0] : (int)(uint8_t)u8[en0] - qe;
+				const int ven = VAR == 0 ? (int)v8[en0] : (int)(uint8_t)v8[en0] - qe;
+				const int h_en0 = en0 > 0 ? H[en0 - 1] + uen : H[en0] + ven;
+				__syncthreads();
+				int bh = (int)0x80000000; unsigned bk = 0xffffffffu;
+				for (int t0 = st0; t0 <= en0; t0 += 64) {
+					int t = t0 + lane;
+					if (t <= en0) {
+						int h;
+						if (t == en0) h = h_en0;
+						else h = H[t] + (VAR == 0 ? (int)v8[t] : (int)(uint8_t)v8[t] - qe);
+						H[t] = h;
+						unsigned rank = t == en0 ? 0u : t < en1 ? 1u + (unsigned)((t - st0) & 3) * 16384u + (unsigned)(t - st0)
+						                                        : 1u + 4u * 16384u + (unsigned)(t - st0);
+						if (h > bh || (h == bh && rank < bk)) bh = h, bk = rank;
+					}
+				}
+				max_H = wave_max_i32(bh);
+				unsigned rk = wave_min_u32(bh == max_H ? bk : 0xffffffffu);
+				max_t = rk == 0 ? en0 : st0 + (int)((rk - 1u) & 16383u);
+				__syncthreads();
+			} else {
+				int h0 = VAR == 0 ? (int)v8[0] - P.qe_pre : (int)(uint8_t)v8[0] - qe - qe;
+				__syncthreads();
+				if (lane == 0) H[0] = h0;
+				max_H = h0, max_t = 0;
+				__syncthreads();
+			}
+			const int H_en0 = H[en0], H_st0 = H[st0];
+			if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - en;
+			if (r - st0 == qlen - 1 && H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
+			if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, e_drop)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
+		} else {
+			const int bias = VAR == 0 ? 0 : qe;
+			if (r > 0) {
+				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+					int d0 = (VAR == 0 ? (int)v8[last_H0_t] : (int)(uint8_t)v8[last_H0_t]) - bias;
+					int d1 = (VAR == 0 ? (int)u8[last_H0_t + 1] : (int)(uint8_t)u8[last_H0_t + 1]) - bias;
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
+					H0 += (VAR == 0 ? (int)v8[last_H0_t] : (int)(uint8_t)v8[last_H0_t]) - bias;
+				} else {
+					++last_H0_t, H0 += (VAR == 0 ? (int)u8[last_H0_t] : (int)(uint8_t)u8[last_H0_t]) - bias;
+				}
+				if (VAR == 1 && (flag & PSVR_EZ_APPROX_DROP) && ez.apply_zdrop(H0, r, last_H0_t, P.zdrop, e_drop)) break;
+			} else H0 = VAR == 0 ? (int)v8[0] - P.qe_pre : (int)(uint8_t)v8[0] - qe - qe, last_H0_t = 0;
+			// extd2 tests the approximate drop on every diagonal including r==0 (ksw2_extd2_sse.c:373);
+			// extz2 only for r>0 (ksw2_extz2_sse.c:283)
+			if (VAR == 0 && (flag & PSVR_EZ_APPROX_DROP) && ez.apply_zdrop(H0, r, last_H0_t, P.zdrop, e_drop)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+		}
+		last_st = st, last_en = en;
+	}
+	int n_cigar = 0;
+	if (with_cigar) {
+		__threadfence_block();
+		__syncthreads();
+		int i0 = -1, j0 = -1;
+		if (!ez.zdropped && !(flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+		else if (!ez.zdropped && (flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
+		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+		if (i0 >= 0 && j0 >= 0) {
+			uint32_t *dst = B.cigar + out->cigar_off;
+			n_cigar = traceback(i0, j0, qlen, tlen, w,
+				[&](int r, int k) { return (int)__builtin_nontemporal_load(Pm + (size_t)r * rowb + k); },
+				[&](int k, uint32_t word) { if (lane == 0) dst[k] = word; });
+			if (!(flag & PSVR_EZ_REV_CIGAR)) {
+				__threadfence_block();
+				__syncthreads();
+				for (int m = lane; m < (n_cigar >> 1); m += 64) {
+					uint32_t a = __builtin_nontemporal_load(dst + m), b = __builtin_nontemporal_load(dst + n_cigar - 1 - m);
+					dst[m] = b, dst[n_cigar - 1 - m] = a;
+				}
+			}
+		}
+	}
+	if (lane == 0) write_ez(out, ez, n_cigar);
+}
+
+template __global__ void extd2_lds_kernel<0>(DpBatch, DpParams);
+template __global__ void extd2_lds_kernel<1>(DpBatch, DpParams);
+
+} // namespace psvr

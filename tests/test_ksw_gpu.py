@@ -1,0 +1,57 @@
+"""-m gpu: the HIP DP kernels (through the C ABI, seam B2) against
+(1) the committed reference known-answer vectors and (2) the oracle on fresh random inputs."""
+import pytest
+
+from ksw_cases import mat5, random_cases
+from ksw_ref import run_oracle
+from test_oracle_ksw import diff, load_kat
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(cases, variant):
+    from pansvr_amd import ksw
+    # group by parameter set: one batch (one plan) per distinct parameter tuple
+    groups = {}
+    for i, c in enumerate(cases):
+        key = (c["m"], c["match"], c["mismatch"], c["q"], c["e"], c["q2"], c["e2"], c["w"], c["zdrop"], c["end_bonus"], c["flag"])
+        groups.setdefault(key, []).append(i)
+    out = [None] * len(cases)
+    for key, ids in groups.items():
+        m, match, mismatch, q, e, q2, e2, w, zdrop, end_bonus, flag = key
+        p = ksw.make_params(m, mat5(match, mismatch), q, e, q2, e2, w, zdrop, end_bonus, flag)
+        res = ksw.ext_batch([cases[i]["query"] for i in ids], [cases[i]["target"] for i in ids], p, variant)
+        for i, r in zip(ids, res):
+            out[i] = r
+    return out
+
+
+@pytest.mark.parametrize("variant", ["extd2", "extz2"])
+def test_gpu_matches_reference_kat(variant):
+    recs = load_kat()
+    got = run_gpu(recs, variant)
+    bad = [(i, recs[i]["flag"], len(recs[i]["query"]), len(recs[i]["target"]), diff(recs[i][variant], g))
+           for i, g in enumerate(got) if g != recs[i][variant]]
+    assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(recs), bad[:3])
+
+
+@pytest.mark.parametrize("variant", ["extd2", "extz2"])
+def test_gpu_matches_oracle_random(variant):
+    cases = random_cases(777, 4000, 300)
+    got = run_gpu(cases, variant)
+    bad = []
+    for i, (c, g) in enumerate(zip(cases, got)):
+        want = run_oracle(c, variant)
+        if g != want:
+            bad.append((i, len(c["query"]), len(c["target"]), diff(want, g)))
+    assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:3])
+
+
+def test_gpu_empty_and_degenerate():
+    from pansvr_amd import ksw
+    p = ksw.make_params(5, mat5(2, 12), 16, 1, 32, 0, 200, 400, -1, 0)
+    assert ksw.ext_batch([], [], p) == []
+    res = ksw.ext_batch([[0], [], [1, 2]], [[0], [1, 2, 3], []], p)
+    assert res[0]["score"] == 2 and res[0]["cigar"] == [1 << 4]
+    for r in res[1:]:   # qlen<=0 or tlen<=0: the reference returns right after ksw_reset_extz
+        assert r["n_cigar"] == 0 and r["score"] == -0x40000000 and r["max"] == 0
