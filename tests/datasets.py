@@ -1,0 +1,36 @@
+"""Seeded data sets used by the golden fixtures and the parity tests (inputs are regenerated from
+the seeds; only the reference's outputs and the compact index are committed)."""
+import os
+
+import synth
+
+DATASETS = {
+    # cfg-1 style smoke set: 20 INS anchors (edge 500), 2000 pairs of 150 bp
+    "fx1": dict(anchors=dict(n_anchors=20, seed=7), reads={"reads150": dict(n_pairs=2000, seed=13)}),
+    # tie-breaks / STR / N bases / 250 bp: duplicated flanks and tandem-repeat alleles
+    "fx2": dict(anchors=dict(n_anchors=30, seed=21, edge=600, allele=(60, 400), str_frac=0.2, dup_frac=0.3),
+                reads={"reads150": dict(n_pairs=1500, seed=23, str_frac=0.05, n_frac=0.05),
+                       "reads250": dict(n_pairs=600, seed=29, L=250, frag=(500, 700), maxindel=40, str_frac=0.05, n_frac=0.03,
+                                        stat=(250, 300, 600, 900))}),
+}
+
+
+def anchors_of(name):
+    return synth.make_anchors(**DATASETS[name]["anchors"])
+
+
+def reads_of(name, rname):
+    a = anchors_of(name)
+    # anchor 0 is never sampled: the reference mis-assigns it (calloc'ed chr_file_n) and its
+    # left extensions clamp at reference position 0, where the reference reads stale scratch bytes
+    return synth.make_reads(a[1:], **DATASETS[name]["reads"][rname])
+
+
+def materialize(name, out_dir):
+    os.makedirs(out_dir, exist_ok=True)
+    synth.write_fasta(os.path.join(out_dir, "anchors.fa"), anchors_of(name))
+    with open(os.path.join(out_dir, "header.sam"), "w") as f:
+        f.write(synth.header_text())
+    for rname in DATASETS[name]["reads"]:
+        synth.write_fastq(os.path.join(out_dir, rname + ".fq"), reads_of(name, rname))
+    return out_dir

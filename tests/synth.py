@@ -1,0 +1,144 @@
+"""Seeded synthetic inputs for the `aln` path: SV anchor FASTA, header.sam and an
+interleaved FASTQ whose comment field follows fc_signal's wire format
+(reference src/PanSVgenerateVCF/getSignalRead.cpp:158-247).  No reference data ships with panSVR,
+so every fixture is generated here."""
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[a] = b
+
+
+def revcomp(s):
+    return _COMP[np.frombuffer(s, dtype=np.uint8)][::-1].tobytes()
+
+
+def rand_dna(rng, n):
+    return ACGT[rng.randint(0, 4, size=n)].tobytes()
+
+
+def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, dup_frac=0.0):
+    """INS anchors named ID_chr_st_len_TYPE_bp1_bp2_end_vcfid (get_anchor_ref.hpp:322-323).
+    str_frac: fraction of anchors whose allele is a short tandem repeat; dup_frac: fraction of anchors that
+    re-use the previous anchor's left flank (identical flanks => tied chains)."""
+    rng = np.random.RandomState(seed)
+    out = []
+    prev_left = None
+    for i in range(n_anchors):
+        st = 10000 * (i + 1)
+        alen = rng.randint(allele[0], allele[1] + 1)
+        left = rand_dna(rng, edge)
+        if prev_left is not None and rng.random_sample() < dup_frac:
+            left = prev_left
+        if rng.random_sample() < str_frac:
+            unit = rand_dna(rng, rng.randint(2, 7))
+            al = (unit * (alen // len(unit) + 1))[:alen]
+        else:
+            al = rand_dna(rng, alen)
+        right = rand_dna(rng, edge)
+        seq = left + al + right
+        prev_left = left
+        name = "%d_chr1_%d_%d_INS_%d_%d_%d_sv.INS.%d" % (i, st, len(seq), st + edge, st + edge, st + 2 * edge, i)
+        out.append((name, seq))
+    return out
+
+
+def header_text():
+    return "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n"
+
+
+def _mutate(rng, s, kind, maxindel=8):
+    b = bytearray(s)
+    if kind == 0:      # 1-4 substitutions
+        for _ in range(rng.randint(1, 5)):
+            p = rng.randint(len(b))
+            b[p] = b"ACGT"[(b"ACGT".index(b[p]) + 1 + rng.randint(3)) % 4] if b[p] in b"ACGT" else b[p]
+    elif kind == 1:    # deletion 1..maxindel
+        k = rng.randint(1, maxindel + 1)
+        p = rng.randint(10, len(b) - 10 - k)
+        del b[p:p + k]
+    elif kind == 2:    # insertion 1..maxindel
+        k = rng.randint(1, maxindel + 1)
+        p = rng.randint(10, len(b) - 10)
+        b[p:p] = rand_dna(rng, k)
+    return bytes(b)
+
+
+def make_reads(anchors, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, miss_frac=0.2, n_frac=0.01,
+               str_frac=0.02, stat=(150, 200, 400, 600), unmapped_frac=0.02, fullscore_frac=0.02):
+    """Returns a list of (name, comment, seq, qual) FASTQ records, two per pair (interleaved)."""
+    rng = np.random.RandomState(seed)
+    recs = []
+    for p in range(n_pairs):
+        miss = rng.random_sample() < miss_frac
+        if miss:
+            flen = rng.randint(frag[0], frag[1] + 1)
+            fragment = rand_dna(rng, flen + 2 * maxindel + 2)
+            st_pos, off = 10000 * (1 + rng.randint(len(anchors))), rng.randint(0, 500)
+        else:
+            a = rng.randint(len(anchors))
+            name, seq = anchors[a]
+            flen = min(rng.randint(frag[0], frag[1] + 1), len(seq) - 2 * maxindel - 2)
+            off = rng.randint(0, len(seq) - flen - 2 * maxindel - 1)
+            fragment = seq[off:off + flen + 2 * maxindel + 2]
+            st_pos = int(name.split("_")[2])
+        ends = []
+        for e in range(2):
+            kind = rng.choice(4, p=[0.3, 0.2, 0.2, 0.3])
+            if e == 0:
+                src = fragment[:L + maxindel]
+            else:
+                src = revcomp(fragment[flen - L - maxindel:flen])
+            r = _mutate(rng, src, kind, maxindel)[:L]
+            if rng.random_sample() < str_frac:
+                unit = rand_dna(rng, rng.randint(2, 6))
+                k = rng.randint(30, 90)
+                s0 = rng.randint(0, L - k)
+                r = r[:s0] + (unit * (k // len(unit) + 1))[:k] + r[s0 + k:]
+            if rng.random_sample() < n_frac:
+                b = bytearray(r)
+                for _ in range(rng.randint(1, 3)):
+                    b[rng.randint(L)] = ord("N")
+                r = bytes(b)
+            ends.append(r)
+        swap = rng.random_sample() < 0.5         # which mate is "first in pair"
+        isize = flen
+        pos1 = st_pos + off                      # 0-based, as core.pos
+        pos2 = st_pos + off + flen - L
+        names = "r%07d" % p
+        for k in range(2):
+            e = k ^ int(swap)                     # fragment end this record holds
+            fwd = e == 0
+            unm = rng.random_sample() < unmapped_frac
+            full = (not unm) and rng.random_sample() < fullscore_frac
+            tid = 30 if unm else 0                # tid > 24 => treated as unmapped (read_realignment.cpp:413)
+            softl = 0 if full else 40
+            score = 2 * L if full else 140
+            pos = pos1 if fwd else pos2
+            mpos = pos2 if fwd else pos1
+            flag = (0x40 if k == 0 else 0x80) | 0x1 | (0 if fwd else 0x10) | (0x20 if fwd else 0)
+            cigar = "%dM" % L if full else "40S%dM" % (L - 40)
+            c = "%d_%d_%d_%d_20_20_0_0_%d_%sN%sY_%sNNY_" % (tid, pos, softl, score, isize, "F" if fwd else "R",
+                                                           "N", "R" if fwd else "F")
+            if p == 0 and k == 0 and stat is not None:
+                c += "STAT_%d_%d_%d_%d_" % stat
+            c += "FLAG_%d_20_CIGAR_%s_MATE_0_%d_%d_TAG_NM:i:3_" % (flag, cigar, mpos, isize if fwd else -isize)
+            qual = bytes(33 + rng.randint(20, 41, size=L).astype(np.uint8))
+            recs.append((names, c, ends[e].decode(), qual.decode()))
+    return recs
+
+
+def write_fasta(path, anchors):
+    with open(path, "w") as f:
+        for name, seq in anchors:
+            f.write(">%s\n" % name)
+            s = seq.decode()
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+
+
+def write_fastq(path, recs):
+    with open(path, "w") as f:
+        for name, c, s, q in recs:
+            f.write("@%s %s\n%s\n+\n%s\n" % (name, c, s, q))
