@@ -111,6 +111,111 @@ int psvr_dp_plan_launch(psvr_dp_plan_t *plan,
 int psvr_dp_plan_describe(const psvr_dp_plan_t *plan, char *buf, size_t buflen);
 void psvr_dp_plan_destroy(psvr_dp_plan_t *plan);
 
+
+/* ------------------------------------------------------------------------------------------
+ * The deBGA unipath k-mer index, resident in HBM.
+ * Replaces deBGA_INDEX::load_index_file + building_chr_index + building_bam_header
+ * (src/deBGA_index.cpp:40-86,363-439 / src/PanSVgenerateVCF/deBGA_index.cpp:33-80,354-431).
+ * The nine files are uploaded once; the 2 GiB first-level table `unipath_g.hash` stays a dense
+ * uint64[4^14+1] prefix-sum array so that one 16-byte gather returns hash[h], hash[h+1].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psvr_index psvr_index_t;
+
+typedef struct psvr_index_view {           /* host pointers, element counts (not bytes) */
+	const uint64_t *ref_seq;  uint64_t n_ref_seq;   /* ref.seq          2-bit MSB-first, 32 bases/word */
+	const uint64_t *seq;      uint64_t n_seq;       /* unipath.seqb     same packing */
+	const uint64_t *seqf;     uint64_t n_seqf;      /* unipath.seqfb    unipath start offsets (U+1) */
+	const uint64_t *pos;      uint64_t n_pos;       /* unipath.pos      1-based reference positions */
+	const uint64_t *posp;     uint64_t n_posp;      /* unipath.posp     (U+1) */
+	const uint64_t *hash;     uint64_t n_hash;      /* unipath_g.hash   4^14+1 prefix sums */
+	const uint32_t *kmer;     uint64_t n_kmer;      /* unipath_g.kmer   low 16 bits of each 22-mer */
+	const uint64_t *off;      uint64_t n_off;       /* unipath_g.offset */
+	const char *chr_text;                           /* contents of unipath.chr (name, cumulative end+1 alternating) */
+	const char *const *header_names; int32_t n_header; /* @SQ names of the ORIGINAL genome header (bam_name2id lookups) */
+} psvr_index_view_t;
+
+int psvr_index_create(const psvr_index_view_t *view, int device, psvr_index_t **out);
+/* reads the nine files from `index_dir` and the @SQ lines of `header_sam` */
+int psvr_index_load(const char *index_dir, const char *header_sam, int device, psvr_index_t **out);
+void psvr_index_destroy(psvr_index_t *idx);
+int64_t psvr_index_device_bytes(const psvr_index_t *idx);
+int32_t psvr_index_n_anchor(const psvr_index_t *idx);
+/* SV_chr_info::vcf_print_string / vcf_id of anchor `sv_id` (deBGA_index.hpp:116-119); NULL if out of range */
+const char *psvr_index_sv_print_string(const psvr_index_t *idx, int32_t sv_id);
+const char *psvr_index_sv_vcf_id(const psvr_index_t *idx, int32_t sv_id);
+
+/* ------------------------------------------------------------------------------------------
+ * Seam B1: one batch of read pairs through seeding -> chaining -> extension DP -> pairing.
+ * Replaces kt_for(worker_for -> align_read_pair) minus the SAM text formatting
+ * (src/PanSVgenerateVCF/read_realignment.cpp:114,154-161,745-775; legacy src/jlra_aln.cpp:115,140-147).
+ * Results are those of the reference at `-t 1`: the engine consumes the same rand()/random_r
+ * draw sequence in input order (see DESIGN.md "rand() order").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psvr_engine psvr_engine_t;
+
+typedef struct psvr_aln_params {           /* MAP_PARA, read_realignment.hpp:46-129 */
+	int32_t match, mismatch, gap_open, gap_ex, gap_open2, gap_ex2, zdrop;
+	int32_t normal_read_length, isize_min, isize_max;   /* STAT_ of the first read or 150/100/900 */
+	int32_t min_filter_score;
+} psvr_aln_params_t;
+void psvr_aln_params_default(psvr_aln_params_t *p);
+
+/* the original alignment parsed from the FASTQ comment (single_end_handler::parse_ori_mapping_rst,
+ * read_realignment.hpp:392-429): tokens 0-4 and the signal-flag token */
+typedef struct psvr_ori {
+	int32_t  chr_id;
+	uint32_t ref_bg, read_bg, align_score;
+	uint8_t  mapq, direction /* 1 = FORWARD */, unmapped, reserved;
+} psvr_ori_t;
+
+#define PSVR_MAX_RESULT 12                  /* MAX_OUTPUT_NUMBER * 2, read_realignment.hpp:323,328 */
+typedef struct psvr_cand {                  /* MAX_IDX_OUTPUT, read_realignment.hpp:243-319 */
+	uint32_t align_score, chain_score, ref_bg, read_bg;
+	int32_t  chr_id, sv_id;
+	uint32_t max_index;
+	uint32_t n_cigar;
+	int64_t  cigar_off;                     /* into the engine's cigar arena (uint32 len<<4|op) */
+	uint8_t  direction, mapq, reserved[6];
+} psvr_cand_t;
+
+typedef struct psvr_read_result {
+	int32_t n_result;
+	uint8_t unmapped, early_out, is_str, reserved;
+	int32_t primary, secondary;             /* -1 none, -2 the original alignment, k>=0 = cand[k] */
+	int32_t has_mate, mate_chr_id;
+	uint32_t mate_ref_bg;
+	int32_t prim_sv_id, mate_sv_id;         /* SV:Z / MV:Z anchors of the primary record */
+	uint32_t n_seed[2];                     /* trace: UNI_SEEDs per strand */
+	uint64_t seed_hash[2], chain_hash[2];   /* trace: FNV-1a of the sorted seeds / chaining DP per strand */
+	psvr_cand_t cand[PSVR_MAX_RESULT];
+} psvr_read_result_t;
+
+typedef struct psvr_pair_result {           /* PE_score, read_realignment.hpp:434-628 */
+	int32_t max_score, cur_isize;
+	int32_t proper, gain;
+	int32_t max1, max2;                     /* -1 none, -2 original, k */
+} psvr_pair_result_t;
+
+int psvr_engine_create(const psvr_index_t *idx, const psvr_aln_params_t *par, psvr_engine_t **out);
+void psvr_engine_destroy(psvr_engine_t *eng);
+/*
+ * n_pairs read pairs; read r = 2*pair + mate has bases[base_off[r] .. base_off[r+1]) (ASCII) and ori[r].
+ * reads[2*n_pairs] / pairs[n_pairs] receive the results; CIGARs of all candidates are appended to
+ * cigar[] (capacity cigar_cap uint32; PSVR_ERR_OVERFLOW if too small).  `trace` != 0 also fills the
+ * per-strand trace hashes.  Host-buffer form: copies in, runs, copies out.
+ */
+int psvr_engine_align_batch(psvr_engine_t *eng, int64_t n_pairs, const char *bases, const int64_t *base_off,
+                            const psvr_ori_t *ori, psvr_read_result_t *reads, psvr_pair_result_t *pairs,
+                            uint32_t *cigar, int64_t cigar_cap, int trace);
+/* Device-resident form used by bench.py: upload once, run the hot path any number of times with the
+ * rand() state rewound, download once.  No host<->device traffic inside psvr_engine_run. */
+int psvr_engine_upload(psvr_engine_t *eng, int64_t n_pairs, const char *bases, const int64_t *base_off, const psvr_ori_t *ori);
+int psvr_engine_run(psvr_engine_t *eng, int trace, void *stream);
+int psvr_engine_download(psvr_engine_t *eng, psvr_read_result_t *reads, psvr_pair_result_t *pairs,
+                         uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used);
+/* work counters of the last run (probes, hits, dp problems, cells, speculative re-runs ...) as JSON */
+int psvr_engine_stats(const psvr_engine_t *eng, char *buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

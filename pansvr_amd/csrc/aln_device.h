@@ -1,0 +1,1093 @@
+// aln_device.h -- the per-item stages of the `aln` hot path (seam B1) as __host__ __device__ functions.
+//
+// Every stage is "one GPU thread owns one item" (read, read-strand, candidate or pair); the only
+// wave-cooperative stage is the banded DP (ksw_kernels.hip).  Data lives in flat HBM arrays and
+// bump arenas so a batch of millions of reads runs as a handful of launches:
+//
+//   prep      read       ASCII -> 2-bit fwd/rev-comp bytes + packed words, N -> rand() draw
+//   seed      strand     STR mask, stride-5 20-mer probes of the HBM hash, MEM extension in unipaths
+//   chain     strand     merge MEMs, expand to reference positions, sort, sparse chaining DP
+//   select    read       iterative best-chain extraction (rand() tie-breaks), candidate cut
+//   walk      candidate  chain -> extension / between-seed sub-problems; simple ones scored inline,
+//                        the rest queued for the DP kernel
+//   (fetch + DP kernels: ksw_kernels.hip)
+//   assemble  candidate  scores + CIGAR pieces -> merged CIGAR, align score
+//   finalize  read       sort, thresholds, anchor -> genome coordinates, mapq
+//   pair      pair       PE_score (rand() tie-breaks), primary / secondary / mate
+//
+// The functions are also compiled for the host by tests/emu (test-only) to check this logic against
+// the oracle without a GPU; the product library never calls them on the host.
+//
+// Reference: src/PanSVgenerateVCF/read_realignment.{cpp,hpp} (== src/jlra_aln.{cpp,hpp}),
+// src/deBGA_index.{cpp,hpp}, src/cpp_lib/graph.cpp, src/clib/binarys_qsort.c.  `rr` below =
+// src/PanSVgenerateVCF/read_realignment.
+#pragma once
+#include <stdint.h>
+#include "../../include/psvr_engine.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PSVR_HD __host__ __device__ __forceinline__
+#define PSVR_HDN __host__ __device__
+#else
+#define PSVR_HD inline
+#define PSVR_HDN
+#endif
+
+namespace psvr {
+
+static const int kLenKmer = 20, kSeedStep = 5, kUniPosNMax = 32;   // rr.hpp:26-29, deBGA_index.hpp:17
+static const int kMaxOut = 6;                                       // MAX_OUTPUT_NUMBER
+static const int kMaxReadLen = 1600;                                // MAX_READ_LEN, rr.hpp:322
+static const int kFwd = 1, kRev = 0;                                // clib/utils.h:72-73
+static const int kSegMax = 96;                                      // CIGAR pieces per candidate
+static const int kCigMax = 256;                                     // merged CIGAR ops per candidate
+static const int kMemSlot = 32;                                     // MEMs per read-strand before spilling to the bump region
+
+struct SvDev { uint32_t chr_id; uint32_t st_pos; int32_t end_offset; int32_t pad; };
+
+struct DevIndex {
+	const uint64_t *ref_seq, *seq, *seqf, *pos, *posp, *hash, *off;
+	const uint32_t *kmer;
+	uint64_t n_seqf;
+	const uint32_t *chr_end_n, *chr_search_index;
+	const SvDev *sv;
+	int32_t chr_file_n;
+	// tests/emu only (PSVR_EMU_SPARSE_HASH): non-empty first-level buckets instead of the dense 2 GiB table
+	const uint32_t *sp_id; const uint64_t *sp_start; uint64_t sp_n, n_kmer;
+};
+
+// hash[h], hash[h+1] of the first-level table (one 16-byte gather on the device)
+PSVR_HD void hash_pair(const DevIndex &ix, uint64_t h, uint64_t &lo, uint64_t &hi);
+
+struct VMem { uint64_t uid; uint32_t seed_id, read_pos, uni_pos_off, length, pos_n, pad; };   // vertex_MEM
+struct VU { uint64_t uid; uint32_t read_pos, uni_pos_off, length1, length2, pos_n, cov; };      // vertex_U
+struct USeed { uint32_t read_begin, read_end, seed_id, ref_begin, ref_end, cov; };              // UNI_SEED
+struct PathN { int32_t dist, pre_node; uint32_t brk; uint32_t used; };                          // PATH_t (+ scan break)
+
+template <class T> struct Arena {
+	T *base;
+	unsigned long long *top;
+	unsigned long long cap;
+	int *overflow;
+};
+
+PSVR_HD unsigned long long atomic_bump(unsigned long long *p, unsigned long long n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return atomicAdd(p, n);
+#else
+	unsigned long long o = *p;
+	*p += n;
+	return o;
+#endif
+}
+
+template <class T> PSVR_HD long long arena_alloc(const Arena<T> &a, unsigned long long n)
+{
+	unsigned long long o = atomic_bump(a.top, n);
+	if (o + n > a.cap) { *a.overflow = 1; return -1; }
+	return (long long)o;
+}
+
+struct Strand {                  // per read-strand bookkeeping
+	long long mem_off; uint32_t mem_n;
+	long long us_off;  uint32_t us_n;      // USeed + PathN arenas share offsets
+	uint64_t seed_hash, chain_hash;
+};
+
+struct ChainCand {               // one sort_output() pick (rr.cpp:212-293)
+	uint32_t chain_score, max_index, read_bg, ref_bg;
+	int32_t chr_id;              // anchor id from get_chromosome_ID
+	int32_t direction;
+};
+
+struct Seg {                     // one piece of KSW_ALN_handler::cigar_tmp, in push order
+	int32_t kind;                // 0 literal op, 1 DP result
+	int32_t a, b;                // literal: type,size ; DP: problem id, emit order (0 forward i=0.., 1 reverse)
+};
+
+struct DpDesc {                  // one queued ksw_extd2_sse call (rr.cpp:872-891,910-986)
+	int32_t read, strand;        // query source
+	int32_t q_st, qlen;          // read_str + q_st, qlen bases (reversed for left extension)
+	uint32_t ref_st; int32_t tlen;
+	int32_t type;                // 0 left, 1 right, 2 end-to-end
+	int32_t pad;
+};
+
+struct CandWork {                // a candidate between walk and assemble
+	int32_t read, k;             // read id, slot in the read's candidate list
+	int32_t n_seg;
+	int32_t read_score;          // partial: simple pieces + gap penalties + tail terms
+	int32_t rba;                 // read_begin_alignment
+	int32_t bad;
+	long long seg_off;
+};
+
+struct Ctx {
+	DevIndex idx;
+	psvr_aln_params_t par;
+	int8_t mat[25];
+	// batch inputs
+	long long n_pairs;
+	const char *bases; const long long *base_off; const psvr_ori_t *ori;
+	int32_t lmax;                // padded per-strand byte stride
+	int32_t wmax;                // packed words per strand
+	// rand streams: rand() and the two per-handler random_r streams (rr.hpp:340)
+	const int32_t *grand; long long grand_n; long long grand_base;
+	const int32_t *hrand[2]; long long hrand_n; long long hrand_base[2];
+	// per pair-item (3 per pair: read1, read2, pairing) draw offsets and counts
+	long long *roff; int32_t *rcnt;
+	long long *hoff; int32_t *hcnt;          // per read: random_r offsets / counts
+	// per read
+	uint8_t *active; uint8_t *unmapped; uint8_t *is_str;
+	int32_t *read_l;
+	uint8_t *bin;                // [read][2][lmax]
+	uint64_t *rb;                // [read][2][wmax]
+	uint8_t *seed_list;          // [read][lmax]
+	Strand *strand;              // [read][2]
+	ChainCand *ccand; int32_t *n_ccand;      // [read][12]
+	psvr_read_result_t *res; psvr_pair_result_t *pres;
+	// arenas
+	Arena<VMem> mem; Arena<USeed> us; PathN *path;   // path shares the us arena's offsets
+	Arena<Seg> seg; Arena<DpDesc> dp; Arena<CandWork> cw; Arena<uint32_t> cig;
+	// DP results
+	const psvr_extz_t *dp_ez; const uint32_t *dp_cig;
+	int32_t trace;
+	int32_t *err;                // sticky error word (reference would xassert/abort)
+	unsigned long long *stats;   // [16] work counters
+};
+
+enum { ST_PROBES = 0, ST_HITS, ST_SEEDS, ST_DP, ST_SIMPLE, ST_CELLS, ST_READS, ST_CAND, ST_N };
+
+PSVR_HD void stat_add(const Ctx &c, int k, unsigned long long v)
+{
+	if (!c.stats) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+	atomicAdd(c.stats + k, v);
+#else
+	c.stats[k] += v;
+#endif
+}
+
+PSVR_HD uint64_t fnv1a(uint64_t h, uint64_t v)
+{
+	for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ULL; }
+	return h;
+}
+
+PSVR_HD void hash_pair(const DevIndex &ix, uint64_t h, uint64_t &lo, uint64_t &hi)
+{
+#ifdef PSVR_EMU_SPARSE_HASH
+	auto at = [&](uint64_t x) {
+		uint64_t l = 0, r = ix.sp_n;
+		while (l < r) { uint64_t m = (l + r) >> 1; if (ix.sp_id[m] < x) l = m + 1; else r = m; }
+		return l < ix.sp_n ? ix.sp_start[l] : ix.n_kmer;
+	};
+	lo = at(h), hi = at(h + 1);
+#else
+	lo = ix.hash[h], hi = ix.hash[h + 1];
+#endif
+}
+
+PSVR_HD int base_at(const uint64_t *w, uint64_t i) { return (int)((w[i >> 5] >> ((31 - (i & 0x1f)) << 1)) & 3); }
+
+// ---------------------------------------------------------------------------------------------
+// prep: parse-independent part of single_end_handler::align up to binary_read_2_bit (rr.cpp:406-416,646-654)
+// ---------------------------------------------------------------------------------------------
+PSVR_HDN inline void prep_read(const Ctx &c, long long read)
+{
+	const psvr_ori_t &o = c.ori[read];
+	const int L = (int)(c.base_off[read + 1] - c.base_off[read]);
+	c.read_l[read] = L;
+	bool unm = o.unmapped != 0;
+	if ((uint32_t)o.chr_id > 24u) unm = true;                          // rr.cpp:413
+	c.unmapped[read] = unm;
+	c.is_str[read] = 0;
+	long long item = (read >> 1) * 3 + (read & 1);
+	c.rcnt[item] = 0;
+	c.hcnt[read] = 0;
+	c.n_ccand[read] = 0;
+	for (int s = 0; s < 2; ++s) { Strand &st = c.strand[read * 2 + s]; st.mem_n = st.us_n = 0; st.mem_off = st.us_off = 0; st.seed_hash = st.chain_hash = 1469598103934665603ULL; }
+	if (L > kMaxReadLen || L < kLenKmer) { c.active[read] = 0; if (L > kMaxReadLen) *c.err = 1; return; }
+	if (!unm && o.align_score == (uint32_t)(L * c.par.match)) { c.active[read] = 0; return; }   // rr.cpp:414
+	c.active[read] = 1;
+	const char *s = c.bases + c.base_off[read];
+	uint8_t *b0 = c.bin + (read * 2) * (long long)c.lmax, *b1 = b0 + c.lmax;
+	uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
+	for (int i = 0; i < c.wmax; ++i) w0[i] = 0, w1[i] = 0;
+	long long ro = c.roff[item];
+	int draws = 0;
+	for (int i = 0; i < L; ++i) {
+		char ch = s[i];
+		if (ch == 'N') {
+			long long k = ro + draws - c.grand_base;
+			int32_t r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
+			ch = "ACGT"[r % 4];
+			++draws;
+		}
+		uint8_t code = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0; // charToDna5n
+		b0[i] = code;
+		b1[L - 1 - i] = code ^ 3;
+	}
+	for (int i = 0; i < L; ++i) {                                       // binary_read_64_bit, rr.cpp:295-300
+		w0[i >> 5] |= ((uint64_t)b0[i]) << ((31 - (i & 0x1f)) << 1);
+		w1[i >> 5] |= ((uint64_t)b1[i]) << ((31 - (i & 0x1f)) << 1);
+	}
+	c.rcnt[item] = draws;
+	stat_add(c, ST_READS, 1);
+}
+
+PSVR_HD uint64_t get_kmer(uint32_t off, const uint64_t *rb)           // getKmer, rr.cpp:204-210
+{
+	uint32_t w = off >> 5, iw = off & 0x1f;
+	uint64_t full = (rb[w] << (iw << 1)) | (iw == 0 ? 0 : (rb[w + 1] >> ((32 - iw) << 1)));
+	return full >> ((32 - kLenKmer) << 1);
+}
+
+// STR detection on the forward strand (rr.cpp:549-598).  O(n^2) distinct/count over <= L-19 k-mers.
+PSVR_HDN inline void str_detect(const Ctx &c, long long read)
+{
+	if (!c.active[read]) return;
+	const int L = c.read_l[read];
+	const uint64_t *rb = c.rb + (read * 2) * (long long)c.wmax;
+	uint8_t *sl = c.seed_list + read * (long long)c.lmax;
+	const uint32_t kn = L - kLenKmer + 1;
+	uint32_t distinct = 0;
+	for (uint32_t i = 0; i < kn; ++i) {
+		uint64_t ki = get_kmer(i, rb);
+		bool first = true;
+		for (uint32_t j = 0; j < i; ++j) if (get_kmer(j, rb) == ki) { first = false; break; }
+		distinct += first;
+	}
+	if (!(distinct < kn - 15)) { c.is_str[read] = 0; return; }
+	c.is_str[read] = 1;
+	for (uint32_t i = 0; i < kn; ++i) {
+		uint64_t ki = get_kmer(i, rb);
+		int cnt = 0;
+		for (uint32_t j = 0; j < kn; ++j) cnt += get_kmer(j, rb) == ki;
+		sl[i] = cnt >= 4 ? 0 : 1;
+	}
+	int bg = 0, ed = 0;
+	for (uint32_t o = 0; o < (uint32_t)kSeedStep; ++o) {
+		bg += sl[o] == 0, ed += sl[L - kLenKmer - o] == 0;
+		sl[o] += 2, sl[L - kLenKmer - o] += 4;
+	}
+	if (bg < kSeedStep && ed < kSeedStep) {
+		int tot = 0;
+		for (uint32_t o = 0; tot < kSeedStep && o < kn; ++o) {
+			if (sl[o] > 0) continue;
+			sl[o] += 8, tot++;
+		}
+	}
+}
+
+// seed_list as the reverse strand sees it: getReverseStr_qual (clib/bam_file.c:341-349) swaps i <-> len-1-i for
+// i = 0..len/2 INCLUSIVE, so for even len the two middle entries are swapped twice
+PSVR_HD uint8_t seed_list_at(const uint8_t *sl, int len, int rev, int i)
+{
+	if (!rev) return sl[i];
+	if (!(len & 1) && (i == len / 2 || i == len / 2 - 1)) return sl[i];
+	return sl[len - 1 - i];
+}
+
+// seed loop of chainning_one_read (rr.cpp:614-635) for one strand: search_kmer + binsearch_range
+// (deBGA_index.cpp:84-101, binarys_qsort.c:25-100) and UNITIG_MEM_search (deBGA_index.cpp:105-146)
+PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
+{
+	const long long read = rs >> 1;
+	const int rev = (int)(rs & 1);
+	if (!c.active[read]) return;
+	const int L = c.read_l[read];
+	const uint64_t *rb = c.rb + rs * (long long)c.wmax;
+	const uint8_t *sl = c.seed_list + read * (long long)c.lmax;
+	const bool is_str = c.is_str[read] != 0;
+	const uint32_t kn = L - kLenKmer + 1;
+	const DevIndex &ix = c.idx;
+	// MEMs go to this strand's fixed slot of kMemSlot entries; a strand with more re-runs as count + fill
+	// passes into the bump region behind the slots (rare: > 32 MEMs needs repeats)
+	long long base = rs * (long long)kMemSlot;
+	uint32_t total = 0, probes = 0;
+	for (int pass = 0; pass < 3; ++pass) {            // 0: write into slot (counting), 1: count only (skipped), 2: fill arena slice
+		if (pass == 1) continue;
+		uint32_t n = 0, msr = 0;
+		for (uint32_t off = 0; off < kn; off += kSeedStep) {
+			if (off + kLenKmer - 1 <= msr) continue;
+			if (is_str && seed_list_at(sl, (int)kn, rev, off) == 0) continue;
+			uint64_t kmer = get_kmer(off, rb);
+			uint64_t key = kmer & 0xfff, h = kmer >> 12;
+			uint64_t lo, hi;
+			hash_pair(ix, h, lo, hi);
+			if (pass == 0) ++probes;
+			long long l = 0, r = (long long)(hi - lo) - 1, first = -1, last = -1;
+			const uint32_t *v = ix.kmer + lo;
+			while (l <= r) {                                            // binsearch_range with k_off = 4
+				long long m = (l + r) / 2;
+				uint32_t t = v[m] >> 4;
+				if (t == key) {
+					first = last = m;
+					long long sl2 = l, sr = m - 1;
+					while (sl2 <= sr) { long long sm = (sl2 + sr) / 2; uint32_t t2 = v[sm] >> 4; if (t2 == key) first = sm, sr = sm - 1; else if (t2 > key) sr = sm - 1; else sl2 = sm + 1; }
+					sl2 = m + 1, sr = r;
+					while (sl2 <= sr) { long long sm = (sl2 + sr) / 2; uint32_t t2 = v[sm] >> 4; if (t2 == key) last = sm, sl2 = sm + 1; else if (t2 > key) sr = sm - 1; else sl2 = sm + 1; }
+					break;
+				} else if (t > key) r = m - 1;
+				else l = m + 1;
+			}
+			if (first < 0) continue;
+			if ((uint64_t)(last - first + 1) > (uint64_t)kUniPosNMax) continue;
+			uint32_t mri = 1;
+			for (long long hit = (long long)lo + first; hit <= (long long)lo + last; ++hit) {
+				uint64_t kp = ix.off[hit];
+				long long lo2 = 0, hi2 = (long long)ix.n_seqf - 1, uid = -1;
+				while (lo2 <= hi2) {                                    // binsearch_interval_unipath64
+					long long mid = (lo2 + hi2) >> 1;
+					uint64_t sv = ix.seqf[mid];
+					if (kp < sv) hi2 = mid - 1;
+					else if (kp > sv) lo2 = mid + 1;
+					else { uid = mid; break; }
+				}
+				if (uid < 0) uid = hi2;
+				uint64_t f0 = ix.seqf[uid], f1 = ix.seqf[uid + 1];
+				uint32_t ul = (uint32_t)(kp - f0), ur = (uint32_t)(f1 - (kp + kLenKmer));
+				uint32_t li, ri;
+				for (li = 1; li <= ul && li <= off; li++)
+					if (base_at(ix.seq, kp - li) != base_at(rb, off - li)) break;
+				for (ri = 1; ri <= ur && ri <= (uint32_t)(L - off - kLenKmer); ri++)
+					if (base_at(ix.seq, kp + kLenKmer - 1 + ri) != base_at(rb, off + kLenKmer - 1 + ri)) break;
+				if (pass == 2 || n < (uint32_t)kMemSlot) {
+					VMem &m = c.mem.base[base + n];
+					m.uid = (uint64_t)uid, m.seed_id = n, m.read_pos = off + 1 - li, m.uni_pos_off = ul + 1 - li;
+					m.length = kLenKmer + li + ri - 2, m.pos_n = (uint32_t)(ix.posp[uid + 1] - ix.posp[uid]), m.pad = 0;
+				}
+				++n;
+				if (ri > mri) mri = ri;
+			}
+			msr = off + kLenKmer + mri - 1;
+		}
+		if (pass == 0) {
+			total = n;
+			if (n <= (uint32_t)kMemSlot) break;
+			base = arena_alloc(c.mem, n);
+			if (base < 0) return;
+		}
+	}
+	Strand &st = c.strand[rs];
+	st.mem_off = base, st.mem_n = total;
+	if (c.stats) { stat_add(c, ST_PROBES, probes); stat_add(c, ST_HITS, total); }
+}
+
+// stable bottom-up merge sort of idx[0..n) by less(a,b); tmp has n entries
+template <class T, class Less> PSVR_HD void stable_sort(T *a, T *tmp, uint32_t n, Less less)
+{
+	if (n < 2) return;
+	if (n <= 16) {                                                       // stable insertion sort
+		for (uint32_t i = 1; i < n; ++i) {
+			T x = a[i];
+			uint32_t j = i;
+			while (j > 0 && less(x, a[j - 1])) { a[j] = a[j - 1]; --j; }
+			a[j] = x;
+		}
+		return;
+	}
+	T *src = a, *dst = tmp;
+	for (uint32_t w = 1; w < n; w <<= 1) {
+		for (uint32_t lo = 0; lo < n; lo += 2 * w) {
+			uint32_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+			uint32_t i = lo, j = mid, k = lo;
+			while (i < mid && j < hi) { if (less(src[j], src[i])) dst[k++] = src[j++]; else dst[k++] = src[i++]; }
+			while (i < mid) dst[k++] = src[i++];
+			while (j < hi) dst[k++] = src[j++];
+		}
+		T *t = src; src = dst; dst = t;
+	}
+	if (src != a) for (uint32_t i = 0; i < n; ++i) a[i] = src[i];
+}
+
+// merge_seed_in_unipath + expand_seed + Graph_handler::process (deBGA_index.cpp:151-251, graph.cpp:53-150)
+PSVR_HDN inline void chain_strand(const Ctx &c, long long rs, int &hdraw_total)
+{
+	const long long read = rs >> 1;
+	const int rev = (int)(rs & 1);
+	if (!c.active[read]) return;
+	Strand &st = c.strand[rs];
+	const uint32_t mem_i = st.mem_n;
+	VMem *vm = c.mem.base + st.mem_off;
+	const DevIndex &ix = c.idx;
+	if (mem_i > 1) {
+		VMem *mtmp = nullptr;
+		if (mem_i > 16) {                                                   // merge-sort scratch from the bump region
+			long long t = arena_alloc(c.mem, mem_i);
+			if (t < 0) return;
+			mtmp = c.mem.base + t;
+		}
+		stable_sort(vm, mtmp, mem_i, [](const VMem &a, const VMem &b) { return a.uid != b.uid ? a.uid < b.uid : a.read_pos < b.read_pos; });
+	}
+	// pass 0 sizes the seed list, pass 1 fills it
+	long long ubase = 0;
+	uint32_t total = 0;
+	const long long hro = c.hoff[read] + hdraw_total;                     // the reverse strand continues the forward strand's draws
+	int hdraw = 0;
+	for (int pass = 0; pass < 2; ++pass) {
+		uint32_t n = 0, vu_i = 0;
+		hdraw = 0;
+		bool stop = false;
+		uint32_t j = 0;
+		while (j < mem_i && !stop) {
+			VU u;
+			if (mem_i == 1) {
+				const VMem &m = vm[0];
+				u.uid = m.uid, u.read_pos = m.read_pos, u.uni_pos_off = m.uni_pos_off, u.length1 = u.length2 = m.length, u.pos_n = m.pos_n, u.cov = m.length;
+				j = 1;
+			} else {
+				uint32_t s1 = j, cov = vm[s1].length;
+				// NB: uni_id_temp is re-read from vertexm_v[j] after every group, so the uid test below compares
+				// against the group's own first element
+				const uint64_t uid_t = vm[s1].uid;
+				j++;
+				while (j < mem_i && uid_t == vm[j].uid && vm[j].uni_pos_off > vm[j - 1].uni_pos_off) {
+					int diff = (int)(vm[j].read_pos - vm[j - 1].read_pos - vm[j - 1].length);
+					if (diff > 3) break;
+					int ce = (int)((vm[j].uni_pos_off - vm[j - 1].uni_pos_off) - (vm[j].read_pos - vm[j - 1].read_pos));
+					if ((ce < 0 ? -ce : ce) < 1) { cov += (diff > 0) ? vm[j].length : (uint32_t)(diff + (int)vm[j].length); ++j; }
+					else break;
+				}
+				uint32_t e1 = j - 1;
+				u.uid = vm[s1].uid, u.read_pos = vm[s1].read_pos, u.uni_pos_off = vm[s1].uni_pos_off, u.pos_n = vm[s1].pos_n, u.cov = cov;
+				if (s1 == e1) u.length1 = u.length2 = vm[s1].length;
+				else {
+					u.length1 = vm[e1].read_pos + vm[e1].length - vm[s1].read_pos;
+					u.length2 = vm[e1].uni_pos_off + vm[e1].length - vm[s1].uni_pos_off;
+				}
+			}
+			// expand_seed for this vertex_U (index vu_i)
+			uint32_t cnt = u.pos_n;
+			bool sample = false;
+			if (u.pos_n > 500) {
+				if (u.pos_n > 8000) { stop = true; break; }
+				cnt = 500, sample = true;
+			}
+			for (uint32_t k = 0; k < cnt; ++k) {
+				uint32_t m = k;
+				if (sample) {
+					long long q = hro + hdraw - c.hrand_base[read & 1];
+					int32_t rv = (q >= 0 && q < c.hrand_n) ? c.hrand[read & 1][q] : (*c.err = 3, 0);
+					m = (uint32_t)rv % u.pos_n;
+					++hdraw;
+				}
+				if (pass == 1) {
+					USeed &s = c.us.base[ubase + n];
+					s.seed_id = vu_i, s.read_begin = u.read_pos, s.read_end = u.read_pos + u.length1 - 1;
+					s.ref_begin = (uint32_t)(ix.pos[m + ix.posp[u.uid]] + u.uni_pos_off - 1);
+					s.ref_end = s.ref_begin + u.length2 - 1, s.cov = u.cov;
+				}
+				++n;
+			}
+			++vu_i;
+		}
+		if (pass == 0) {
+			total = n;
+			if (n == 0) break;
+			ubase = arena_alloc(c.us, 2ull * n);       // second half: merge-sort scratch
+			if (ubase < 0) return;
+		}
+	}
+	(void)rev;
+	st.us_off = ubase, st.us_n = total;
+	hdraw_total += hdraw;
+	if (total == 0) return;
+	USeed *v = c.us.base + ubase;
+	PathN *pa = c.path + ubase;
+	stable_sort(v, v + total, total, [](const USeed &a, const USeed &b) { return a.ref_end != b.ref_end ? a.ref_end < b.ref_end : a.ref_begin < b.ref_begin; });
+	const bool is_str = c.is_str[read] != 0;
+	const int max_ref_dis = is_str ? 400 : 50, max_read_dis = is_str ? 400 : 50;
+	const uint32_t max_search_step = is_str ? 80 : 40, max_gap = is_str ? 20 : 50;
+	const uint32_t n = total;
+	const uint32_t search_step = n < max_search_step ? n : max_search_step;
+	// forward scan per target: where would the reference's inner loop `break` (graph.cpp:86)?
+	for (uint32_t t = 0; t < n; ++t) {
+		pa[t].dist = (int32_t)v[t].cov, pa[t].pre_node = -1, pa[t].used = 0;
+		uint32_t se = t + search_step < n ? t + search_step : n, brk = se;
+		for (uint32_t y = t + 1; y < se; ++y) {
+			if (v[y].seed_id == v[t].seed_id) continue;
+			if (v[y].ref_end == v[t].ref_end) continue;
+			if ((int32_t)(v[y].ref_begin - v[t].ref_end) > max_ref_dis) { brk = y; break; }
+		}
+		pa[t].brk = brk;
+	}
+	// dynamic_programming_path over the implicit pre_edge lists (ascending source id)
+	for (uint32_t y = 1; y < n; ++y) {
+		int32_t cur = 0, pn = -1;
+		bool any = false;
+		uint32_t t0 = y >= search_step ? y - search_step + 1 : 0;
+		for (uint32_t t = t0; t < y; ++t) {
+			if (y >= pa[t].brk) continue;
+			if (v[y].seed_id == v[t].seed_id) continue;
+			if (v[y].ref_end == v[t].ref_end) continue;
+			int32_t dis_ref = (int32_t)(v[y].ref_begin - v[t].ref_end);
+			int32_t dis_read = (int32_t)(v[y].read_begin - v[t].read_end);
+			if (dis_read > max_read_dis) continue;
+			uint32_t abs_gap = dis_read > dis_ref ? (uint32_t)(dis_read - dis_ref) : (uint32_t)(dis_ref - dis_read);
+			if (abs_gap > max_gap) continue;
+			int32_t penalty = abs_gap == 0 ? 0 : (int32_t)((abs_gap >> 3) + 3);
+			uint32_t weight;
+			if (dis_read == dis_ref) weight = v[y].cov - (uint32_t)((1 - dis_read) > 0 ? (1 - dis_read) : 0);
+			else if (dis_read > 0 && dis_ref > 0) weight = v[y].cov;
+			else if (dis_read >= -5 && dis_read <= 0 && dis_ref >= -5) weight = v[y].cov + (uint32_t)(dis_read < dis_ref ? dis_read : dis_ref);
+			else continue;
+			any = true;
+			int32_t temp = pa[t].dist + (int32_t)weight - penalty;
+			if (cur <= temp) cur = temp, pn = (int32_t)t;
+		}
+		if (any) pa[y].dist = cur, pa[y].pre_node = pn;
+	}
+	if (c.trace) {
+		uint64_t hs = 1469598103934665603ULL, hd = hs;
+		for (uint32_t i = 0; i < n; ++i) {
+			hs = fnv1a(hs, v[i].read_begin); hs = fnv1a(hs, v[i].read_end); hs = fnv1a(hs, v[i].seed_id);
+			hs = fnv1a(hs, v[i].ref_begin); hs = fnv1a(hs, v[i].ref_end); hs = fnv1a(hs, v[i].cov);
+			hd = fnv1a(hd, (uint64_t)(int64_t)pa[i].dist); hd = fnv1a(hd, (uint64_t)(int64_t)pa[i].pre_node);
+		}
+		st.seed_hash = hs, st.chain_hash = hd;
+	}
+}
+
+// both strands of one read, forward first: the per-handler random_r stream is consumed in that order
+PSVR_HDN inline void chain_read(const Ctx &c, long long read)
+{
+	if (!c.active[read]) return;
+	int hdraw = 0;
+	chain_strand(c, read * 2, hdraw);
+	chain_strand(c, read * 2 + 1, hdraw);
+	c.hcnt[read] = hdraw;
+	if (c.stats) stat_add(c, ST_SEEDS, c.strand[read * 2].us_n + c.strand[read * 2 + 1].us_n);
+}
+
+PSVR_HD int get_chromosome_id(const DevIndex &ix, uint32_t position)   // deBGA_index.cpp:369-396
+{
+	int file_n = 0;
+	int pos_index = position / 0x4000;
+	int low = (int)ix.chr_search_index[pos_index];
+	int high = (int)ix.chr_search_index[pos_index + 1];
+	int pos = (int)position + 1;
+	while (low <= high) {
+		int mid = (low + high) >> 1;
+		int e = (int)(ix.chr_end_n[mid] - 1);
+		if (pos < e) high = mid - 1;
+		else if (pos > e) low = mid + 1;
+		else return mid;
+		file_n = low;
+	}
+	return file_n;
+}
+
+// sort_output (rr.cpp:212-293), recursion unrolled into a loop; returns 1 and fills `out` on success
+PSVR_HD int sort_output(const Ctx &c, const Strand &st, int direction, ChainCand &out, long long ro, int &draws)
+{
+	const uint32_t n = st.us_n;
+	if (n == 0) return 0;
+	const USeed *v = c.us.base + st.us_off;
+	PathN *pa = c.path + st.us_off;
+	for (;;) {
+		uint32_t max_index = 0xffffffffu;
+		int32_t max_distance = 0;
+		uint32_t same = 1;                   // same_top list starts with the sentinel entry
+		for (int i = (int)n - 1; i >= 0; i--) {
+			if (pa[i].used) continue;
+			int32_t d = pa[i].dist;
+			if (max_distance < d) max_distance = d, max_index = (uint32_t)i, same = 1;
+			else if (max_distance == d) same++;
+		}
+		if (max_index == 0xffffffffu) return 0;
+		if (same > 1) {                      // pick same_top[rand() % same]: entry 0 is the first maximum found (or the sentinel)
+			long long k = ro + draws - c.grand_base;
+			int32_t r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
+			++draws;
+			uint32_t pick = (uint32_t)r % same;
+			// rebuild the list order: [first maximum (descending scan), then every later index with dist == max]
+			uint32_t seen = 0;
+			for (int i = (int)n - 1; i >= 0; i--) {
+				if (pa[i].used) continue;
+				if (pa[i].dist == max_distance) { if (seen == pick) { max_index = (uint32_t)i; break; } ++seen; }
+			}
+		}
+		int used = 0, unused = 0;
+		int first_node = (int)max_index, orig_first = first_node;
+		for (; first_node != -1;) {
+			if (pa[first_node].used) used++;
+			else unused++;
+			pa[first_node].used = 1;
+			int nx = pa[first_node].pre_node;
+			if (nx == -1) break;
+			first_node = nx;
+		}
+		int orig_final = first_node;
+		if (orig_first - orig_final > ((unused + used + 5) << 1))
+			for (int k = orig_final; k < orig_first; k++) pa[k].used = 1;
+		if (used >= unused) continue;        // `return sort_output(...)`
+		uint32_t ref_begin = v[first_node].ref_begin;
+		int chr = get_chromosome_id(c.idx, ref_begin);
+		out.direction = direction;
+		out.max_index = max_index;
+		out.chain_score = (uint32_t)max_distance;
+		out.read_bg = v[first_node].read_begin;
+		out.chr_id = chr;
+		out.ref_bg = ref_begin - c.idx.chr_end_n[chr - 1];
+		return 1;
+	}
+}
+
+// the chain-selection part of single_end_handler::align (rr.cpp:417-442)
+PSVR_HDN inline void select_read(const Ctx &c, long long read)
+{
+	if (!c.active[read]) return;
+	const long long item = (read >> 1) * 3 + (read & 1);
+	const long long ro = c.roff[item] + c.rcnt[item];   // after the N draws of prep_read
+	int draws = 0;
+	ChainCand *cc = c.ccand + read * 12;
+	int n = 0;
+	uint32_t max_chain = 0;
+	for (int o = 0; o < 2; ++o) {
+		const int direction = o == 0 ? kFwd : kRev;
+		for (int i = 0; i < kMaxOut; ++i) {
+			ChainCand tmp;
+			if (!sort_output(c, c.strand[read * 2 + o], direction, tmp, ro, draws)) break;
+			uint32_t cs = tmp.chain_score;
+			if (cs > max_chain) max_chain = cs;
+			if (cs + 30 < max_chain || cs < 30) break;
+			cc[n++] = tmp;
+		}
+	}
+	// qsort by cmp_chain_score (rr.hpp:303-308): chain_score desc, max_index asc, stable
+	for (int i = 1; i < n; ++i) {
+		ChainCand x = cc[i];
+		int j = i;
+		while (j > 0 && (x.chain_score != cc[j - 1].chain_score ? x.chain_score > cc[j - 1].chain_score : x.max_index < cc[j - 1].max_index)) { cc[j] = cc[j - 1]; --j; }
+		cc[j] = x;
+	}
+	c.rcnt[item] += draws;
+	if (n == 0 || max_chain < 20) { c.n_ccand[read] = 0; return; }
+	int keep = n;
+	for (int k = 0; k < n; ++k) if (cc[k].chain_score + 30 < max_chain) { keep = k; break; }
+	c.n_ccand[read] = keep;
+}
+
+PSVR_HD void get_refseq(const DevIndex &ix, uint8_t *ref, uint32_t len, uint32_t start)
+{
+	for (uint32_t m = 0; m < len; ++m) ref[m] = (uint8_t)base_at(ix.ref_seq, (uint64_t)m + start);
+}
+
+struct WalkState {
+	const Ctx *c;
+	const uint8_t *read_str;
+	long long read; int strand;
+	int32_t read_score; uint32_t total_q_len;
+	bool is_simple;
+	Seg *seg; int n_seg; int bad;
+};
+
+PSVR_HD void seg_lit(WalkState &w, int type, int size)
+{
+	if (w.n_seg >= kSegMax) { w.bad = 1; return; }
+	Seg &s = w.seg[w.n_seg++];
+	s.kind = 0, s.a = type, s.b = (int32_t)(int16_t)(uint16_t)size;   // CIGAR_PATH(char, uint16_t) -> int16_t size
+}
+
+// KSW_ALN_handler::get_misMatch (rr.cpp:893-908)
+PSVR_HD int walk_mismatch(WalkState &w, int read_st, int read_ed, int ref_st, int ref_ed)
+{
+	uint32_t qlen = read_ed - read_st, tlen = ref_ed - ref_st;
+	if (ref_ed < ref_st) tlen = 0, qlen += (ref_st - ref_ed);
+	if (!(tlen < 1600)) { w.bad = 2; return 0; }
+	int nm = 0;
+	for (uint32_t i = 0; i < qlen && i < tlen; ++i) nm += w.read_str[read_st + i] != base_at(w.c->idx.ref_seq, (uint64_t)ref_st + i);
+	// (qlen == tlen on this call path; bases past tlen would be stale scratch in the reference)
+	return nm > 3 ? 3 : nm;
+}
+
+// KSW_ALN_handler::alignment (rr.cpp:910-986): simple pieces are scored here, DP pieces are queued
+PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, int ref_ed, int type)
+{
+	const Ctx &c = *w.c;
+	uint32_t qlen = read_ed - read_st, tlen = ref_ed - ref_st;
+	if (ref_ed < ref_st) tlen = 0, qlen += (ref_st - ref_ed);
+	if (!(tlen < 1600)) { w.bad = 2; return; }
+	w.total_q_len += qlen;
+	w.is_simple = false;
+	uint32_t nm = 0;
+	if (qlen == 0 || tlen == 0) {
+		w.is_simple = true;
+		nm = qlen + tlen;
+	} else if (qlen == tlen || type != 2) {
+		if (type == 0) {   // left extension compares the reversed sequences
+			for (uint32_t i = 0; i < qlen && nm < 6; ++i) {
+				int tb = i < tlen ? base_at(c.idx.ref_seq, (uint64_t)ref_st + (tlen - 1 - i)) : 0;
+				nm += w.read_str[read_st + (qlen - 1 - i)] != tb;
+			}
+		} else {
+			for (uint32_t i = 0; i < qlen && nm < 6; ++i) {
+				int tb = i < tlen ? base_at(c.idx.ref_seq, (uint64_t)ref_st + i) : 0;
+				nm += w.read_str[read_st + i] != tb;
+			}
+		}
+		if (nm == 1 || (nm < 6 && ((nm << 3) < qlen))) w.is_simple = true;
+	}
+	if (w.is_simple) {
+		stat_add(c, ST_SIMPLE, 1);
+		if (qlen == 0 || tlen == 0) {
+			if (nm != 0) {
+				int s1 = c.par.gap_open + (int)(nm - 1) * c.par.gap_ex, s2 = c.par.gap_open2 + (int)(nm - 1) * c.par.gap_ex2;
+				w.read_score -= s1 < s2 ? s1 : s2;
+			}
+		} else w.read_score += (int32_t)(qlen * c.par.match - nm * (c.par.match + c.par.mismatch));
+		if (qlen == 0) seg_lit(w, 2, (int)tlen);
+		else if (tlen == 0) seg_lit(w, 1, (int)qlen);
+		else seg_lit(w, 0, (int)qlen);
+		if (ref_ed < ref_st) seg_lit(w, 2, ref_ed - ref_st);
+		return;
+	}
+	if ((long long)tlen * qlen > 1000000) {                              // align_non_splice's fake result (rr.cpp:874-887)
+		seg_lit(w, 3, (int)tlen), seg_lit(w, 1, (int)qlen);              // emitted in the order the caller would push them
+		if (type == 0) { Seg t = w.seg[w.n_seg - 1]; w.seg[w.n_seg - 1] = w.seg[w.n_seg - 2]; w.seg[w.n_seg - 2] = t; }
+		if (type != 2) w.read_score += PSVR_KSW_NEG_INF;                  // ez.mqe after ksw_reset_extz
+		return;
+	}
+	long long id = arena_alloc(c.dp, 1);
+	if (id < 0 || w.n_seg >= kSegMax) { w.bad = 1; return; }
+	DpDesc &d = c.dp.base[id];
+	d.read = (int32_t)w.read, d.strand = w.strand, d.q_st = read_st, d.qlen = (int32_t)qlen, d.ref_st = (uint32_t)ref_st, d.tlen = (int32_t)tlen, d.type = type, d.pad = 0;
+	Seg &s = w.seg[w.n_seg++];
+	s.kind = 1, s.a = (int32_t)id, s.b = type;
+	stat_add(c, ST_DP, 1);
+	stat_add(c, ST_CELLS, (unsigned long long)qlen * tlen);
+}
+
+// get_ksw_score (rr.cpp:308-400) for candidate k of `read`
+PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
+{
+	const ChainCand &cc = c.ccand[read * 12 + k];
+	const int is_rev = cc.direction == kRev;
+	const Strand &st = c.strand[read * 2 + is_rev];
+	const USeed *va = c.us.base + st.us_off;
+	const PathN *dp = c.path + st.us_off;
+	const int read_l = c.read_l[read];
+	long long cwi = arena_alloc(c.cw, 1);
+	if (cwi < 0) return;
+	Seg lseg[kSegMax];
+	WalkState w;
+	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
+	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = lseg, w.n_seg = 0, w.bad = 0;
+	const int BIG = 0x7fffffff;
+	int aln_read_begin = read_l, aln_read_end = read_l, aln_ref_begin = BIG, aln_ref_end = BIG;
+	int last_aln_begin = read_l, last_ref_begin = BIG, unitig_mis = 0;
+	for (int node = (int)cc.max_index; node != -1;) {
+		int mrb = (int)va[node].read_begin, mre = (int)va[node].read_end, mfb = (int)va[node].ref_begin, mfe = (int)va[node].ref_end;
+		aln_read_begin = aln_read_begin < mre ? aln_read_begin : mre;
+		aln_ref_begin = aln_ref_begin < mfe ? aln_ref_begin : mfe;
+		if (aln_read_begin <= aln_read_end) {
+			if (aln_read_end < last_aln_begin) {
+				int ml = last_aln_begin - aln_read_end;
+				unitig_mis += walk_mismatch(w, aln_read_end, aln_read_end + ml, last_ref_begin, last_ref_begin + ml);
+				seg_lit(w, 0, ml);
+			}
+			last_aln_begin = aln_read_begin;
+			if (aln_ref_end == BIG) {
+				aln_ref_end = aln_ref_begin + (aln_read_end - aln_read_begin) + 30;
+				walk_alignment(w, aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 1);
+			} else walk_alignment(w, aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 2);
+		} else {
+			int dr = aln_read_end - aln_read_begin, df = aln_ref_end - aln_ref_begin;
+			if (dr != df) {
+				int dl = df - dr, a = dl > 0 ? dl : -dl;
+				int s1 = c.par.gap_open + (a - 1) * c.par.gap_ex, s2 = c.par.gap_open2 + (a - 1) * c.par.gap_ex2;
+				w.read_score -= s1 < s2 ? s1 : s2;
+			}
+		}
+		aln_read_end = mrb, last_ref_begin = mfb, aln_ref_end = mfb;
+		int nx = dp[node].pre_node;
+		if (nx == -1) break;
+		node = nx;
+	}
+	if (aln_read_end < last_aln_begin) {
+		int ml = last_aln_begin - aln_read_end;
+		unitig_mis += walk_mismatch(w, aln_read_end, aln_read_end + ml, last_ref_begin, last_ref_begin + ml);
+		seg_lit(w, 0, ml);
+	}
+	aln_read_begin = 0, aln_ref_begin = 0;
+	int rba = 0;
+	if (aln_read_begin < aln_read_end) {
+		aln_ref_begin = aln_ref_end - (aln_read_end - aln_read_begin) - 30;
+		aln_ref_begin = aln_ref_begin > 0 ? aln_ref_begin : 0;
+		walk_alignment(w, aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 0);
+		if (aln_ref_end > aln_ref_begin) rba = w.is_simple ? aln_ref_end - aln_ref_begin - 30 : aln_ref_end - aln_ref_begin;
+	}
+	w.read_score += (int32_t)((read_l - (int)w.total_q_len) * c.par.match);
+	w.read_score -= unitig_mis * (c.par.match + c.par.mismatch);
+	long long so = arena_alloc(c.seg, (unsigned long long)w.n_seg);
+	if (so < 0) return;
+	for (int i = 0; i < w.n_seg; ++i) c.seg.base[so + i] = lseg[i];
+	CandWork &cw = c.cw.base[cwi];
+	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = rba, cw.bad = w.bad, cw.seg_off = so;
+	if (w.bad) *c.err = 10 + w.bad;
+	stat_add(c, ST_CAND, 1);
+}
+
+struct CigOp { uint8_t type; int16_t size; };
+
+// CIGAR_PATH::try_merge (rr.hpp:159-178)
+PSVR_HD bool cig_try_merge(CigOp &a, const CigOp &cp, int &bad)
+{
+	if (cp.size < 0) {
+		if (cp.type != 2) { bad = 1; return true; }
+		if (a.type == 0) { a.size = (int16_t)(a.size + cp.size); if (!(a.size > 0)) bad = 1; return true; }
+		if (a.type == 2) { a.size = (int16_t)(a.size - cp.size); if (!(a.size > 0)) bad = 1; return true; }
+		bad = 1;
+		return true;
+	}
+	if (a.type == cp.type || cp.size == 0) { a.size = (int16_t)(a.size + cp.size); return true; }
+	return false;
+}
+
+// second half of the per-candidate loop in single_end_handler::align (rr.cpp:445-452): score sum,
+// cigar_tmp reconstruction in push order, reverseGIGAR (rr.hpp:277-301)
+PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
+{
+	const CandWork &cw = c.cw.base[cwi];
+	const Seg *seg = c.seg.base + cw.seg_off;
+	int32_t score = cw.read_score;
+	CigOp out[kCigMax];
+	int n = 0, bad = cw.bad;
+	bool have = false;
+	CigOp back;
+	back.type = 0, back.size = 0;
+	// cigar_tmp in push order is seg[0..n_seg) with DP pieces expanded; reverseGIGAR walks it from the back
+	for (int si = cw.n_seg - 1; si >= 0; --si) {
+		const Seg &s = seg[si];
+		int cnt = 1;
+		const psvr_extz_t *ez = nullptr;
+		const uint32_t *cg = nullptr;
+		if (s.kind == 1) {
+			ez = c.dp_ez + s.a;
+			cg = c.dp_cig + ez->cigar_off;
+			cnt = ez->n_cigar;
+			if (si == cw.n_seg - 1 || true) { /* score added once below */ }
+		}
+		for (int e = cnt - 1; e >= 0; --e) {
+			CigOp op;
+			if (s.kind == 0) op.type = (uint8_t)s.a, op.size = (int16_t)s.b;
+			else {
+				// pushed as i = n-1..0 for end-to-end / right extension, i = 0..n-1 for left extension (rr.cpp:971-984)
+				int pi = s.b == 0 ? e : cnt - 1 - e;
+				uint32_t b = cg[pi];
+				op.type = (uint8_t)(b & 0xf), op.size = (int16_t)(b >> 4);
+			}
+			if (!have) { back = op, have = true; continue; }
+			if (!cig_try_merge(back, op, bad)) {
+				if (n < kCigMax) out[n++] = back; else bad = 1;
+				back = op;
+			}
+		}
+		if (s.kind == 1) score += s.b == 2 ? ez->score : ez->mqe;
+	}
+	if (have) { if (n < kCigMax) out[n++] = back; else bad = 1; }
+	int first = 0;
+	if (n > 0 && out[0].size == 0) first = 1;                      // cigar.erase(cigar.begin())
+	psvr_read_result_t &rr = c.res[cw.read];
+	psvr_cand_t &pc = rr.cand[cw.k];
+	const ChainCand &cc = c.ccand[(long long)cw.read * 12 + cw.k];
+	pc.align_score = score > 0 ? (uint32_t)score : 0;
+	pc.chain_score = cc.chain_score;
+	pc.ref_bg = cc.ref_bg - (uint32_t)cw.rba;
+	pc.read_bg = cc.read_bg;
+	pc.chr_id = cc.chr_id, pc.sv_id = -1;
+	pc.max_index = cc.max_index;
+	pc.direction = (uint8_t)cc.direction, pc.mapq = 0;
+	for (int i = 0; i < 6; ++i) pc.reserved[i] = 0;
+	const int m = n - first;
+	long long co = arena_alloc(c.cig, (unsigned long long)(m > 0 ? m : 0));
+	pc.n_cigar = 0, pc.cigar_off = 0;
+	if (co >= 0) {
+		for (int i = 0; i < m; ++i) c.cig.base[co + i] = ((uint32_t)(uint16_t)out[first + i].size << 4) | out[first + i].type;
+		pc.n_cigar = (uint32_t)m, pc.cigar_off = co;
+	}
+	if (bad) *c.err = 20;   // the reference would xassert (abort) or print "ERROR cigar"
+}
+
+// rest of single_end_handler::align (rr.cpp:453-475)
+PSVR_HDN inline void finalize_read(const Ctx &c, long long read)
+{
+	psvr_read_result_t &rr = c.res[read];
+	rr.unmapped = c.unmapped[read], rr.early_out = !c.active[read], rr.is_str = c.is_str[read], rr.reserved = 0;
+	rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
+	for (int s = 0; s < 2; ++s) {
+		const Strand &st = c.strand[read * 2 + s];
+		rr.n_seed[s] = st.us_n, rr.seed_hash[s] = st.seed_hash, rr.chain_hash[s] = st.chain_hash;
+	}
+	int n = c.active[read] ? c.n_ccand[read] : 0;
+	psvr_cand_t *cd = rr.cand;
+	for (int i = 1; i < n; ++i) {                                        // cmp_align_score (rr.hpp:310-315), stable
+		psvr_cand_t x = cd[i];
+		int j = i;
+		while (j > 0 && (x.align_score != cd[j - 1].align_score ? x.align_score > cd[j - 1].align_score : x.max_index < cd[j - 1].max_index)) { cd[j] = cd[j - 1]; --j; }
+		cd[j] = x;
+	}
+	if (n > 0 && cd[0].align_score < 40) n = 0;
+	for (int i = 0; i < n; ++i) {
+		int sv = cd[i].chr_id;
+		const SvDev &s = c.idx.sv[sv];
+		cd[i].sv_id = sv;
+		cd[i].chr_id = (int32_t)s.chr_id;
+		cd[i].ref_bg += s.st_pos;
+		if (cd[i].ref_bg >= 0x7fffffffu) cd[i].ref_bg = 5;
+		cd[i].mapq = 0;
+	}
+	if (n > 0) {
+		int32_t d = (int32_t)(cd[0].align_score - (n > 1 ? cd[1].align_score : 0));
+		cd[0].mapq = (uint8_t)(d > 40 ? 40 : d);
+	}
+	rr.n_result = n;
+}
+
+// PE_score::read_get_best_pairing_results + set_primary_secondary_mate (rr.hpp:476-534)
+struct PeItem { uint32_t align_score, chr_id, ref_bg; int32_t direction, is_ori, sv_id, end_offset; };
+
+PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i)
+{
+	const psvr_read_result_t &rr = c.res[read];
+	PeItem p;
+	if (i < rr.n_result) {
+		const psvr_cand_t &d = rr.cand[i];
+		p.align_score = d.align_score, p.chr_id = (uint32_t)d.chr_id, p.ref_bg = d.ref_bg, p.direction = d.direction, p.is_ori = 0, p.sv_id = d.sv_id;
+		p.end_offset = c.idx.sv[d.sv_id].end_offset;
+	} else {
+		const psvr_ori_t &o = c.ori[read];
+		p.align_score = o.align_score, p.chr_id = (uint32_t)o.chr_id, p.ref_bg = o.ref_bg >= 0x7fffffffu ? 1u : o.ref_bg, p.direction = o.direction, p.is_ori = 1, p.sv_id = -1, p.end_offset = 0;
+	}
+	return p;
+}
+
+PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
+{
+	const long long r0 = pair * 2, r1 = r0 + 1;
+	const long long item = pair * 3 + 2;
+	for (int e = 0; e < 2; ++e) {       // re-runnable: the pairing stage alone is repeated when only its draw offset moved
+		psvr_read_result_t &rr = c.res[r0 + e];
+		rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
+	}
+	const long long ro = c.roff[item];
+	int draws = 0;
+	const int max_isize = c.par.isize_max + 200;
+	int min_isize = c.par.isize_min - 200;
+	if (min_isize < 0) min_isize = 0;
+	const int nrl = c.par.normal_read_length;
+	int max_same = 1, max_score = 0, cur_isize = 0, m1 = -1, m2 = -1;   // -1 NULL, else item index
+	bool proper = false;
+	int n0 = c.res[r0].n_result, n1 = c.res[r1].n_result;
+	const int nr0 = n0, nr1 = n1;
+	if (!c.unmapped[r0]) n0++;
+	if (!c.unmapped[r1]) n1++;
+	auto get_isize = [&](int p1, int p2, int d1, int d2) {
+		if (d1 == d2) return 0;
+		int is = nrl + ((d1 == kFwd) ? (p2 - p1) : (p1 - p2));
+		return (is < max_isize && is > min_isize) ? is : 0;
+	};
+	auto store = [&](int i, int j) {   // i / j = -1 for NULL
+		PeItem a, b;
+		if (i >= 0) a = pe_item(c, r0, i);
+		if (j >= 0) b = pe_item(c, r1, j);
+		int ISIZE = 0;
+		if (i >= 0 && j >= 0 && a.chr_id == b.chr_id) {
+			int s1p1 = (int)a.ref_bg, s1p2 = s1p1 + (a.is_ori ? 0 : a.end_offset);
+			int s2p1 = (int)b.ref_bg, s2p2 = s2p1 + (b.is_ori ? 0 : b.end_offset);
+			int is;
+			if ((is = get_isize(s1p1, s2p1, a.direction, b.direction)) > 0) ISIZE = is;
+			else if ((is = get_isize(s1p1, s2p2, a.direction, b.direction)) > 0) ISIZE = is;
+			else if ((is = get_isize(s1p2, s2p1, a.direction, b.direction)) > 0) ISIZE = is;
+			else if ((is = get_isize(s1p2, s2p2, a.direction, b.direction)) > 0) ISIZE = is;
+		}
+		int basic = (i >= 0 ? (int)a.align_score : 0) + (j >= 0 ? (int)b.align_score : 0);
+		bool one_new = (i >= 0 && !a.is_ori) || (j >= 0 && !b.is_ori);
+		int fin = basic + (ISIZE > 0 ? 0 : -60) + (one_new ? 0 : 1);
+		if (fin >= max_score) {
+			bool st = true;
+			if (fin > max_score) max_same = 1;
+			else {
+				max_same++;
+				long long k = ro + draws - c.grand_base;
+				int32_t r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
+				++draws;
+				if (r % max_same != 0) st = false;
+			}
+			if (st) m1 = i, m2 = j, max_score = fin, cur_isize = ISIZE, proper = cur_isize > 0;
+		}
+	};
+	for (int i = 0; i < n0; i++) store(i, -1);
+	for (int j = 0; j < n1; j++) store(-1, j);
+	for (int i = 0; i < n0; i++) for (int j = 0; j < n1; j++) store(i, j);
+	c.rcnt[item] = draws;
+	const bool a_new = m1 >= 0 && m1 < nr0, b_new = m2 >= 0 && m2 < nr1;
+	const bool gain = max_score > 0 && (a_new || b_new);
+	psvr_pair_result_t &pr = c.pres[pair];
+	pr.max_score = max_score, pr.cur_isize = cur_isize, pr.proper = proper, pr.gain = gain;
+	pr.max1 = m1 < 0 ? -1 : (m1 < nr0 ? m1 : -2);
+	pr.max2 = m2 < 0 ? -1 : (m2 < nr1 ? m2 : -2);
+	if (!gain) return;
+	for (int e = 0; e < 2; ++e) {                                        // set_primary_secondary_mate
+		const long long rd = e == 0 ? r0 : r1;
+		const int mine = e == 0 ? m1 : m2, other = e == 0 ? m2 : m1;
+		const int nmine = e == 0 ? nr0 : nr1, nother = e == 0 ? nr1 : nr0;
+		if (mine < 0) continue;
+		psvr_read_result_t &rr = c.res[rd];
+		const bool is_ori = mine >= nmine;
+		rr.primary = is_ori ? -2 : mine;
+		rr.secondary = -1;
+		if (is_ori && nmine > 0) rr.secondary = 0;
+		else if (nmine > 1) rr.secondary = mine == 0 ? 1 : 0;          // rst_idx == position after the final sort
+		PeItem me = pe_item(c, rd, mine);
+		rr.prim_sv_id = me.sv_id;
+		if (other >= 0) {
+			PeItem mt = pe_item(c, e == 0 ? r1 : r0, other);
+			(void)nother;
+			if (mt.chr_id != 0xffffffffu) {
+				rr.has_mate = 1, rr.mate_chr_id = (int32_t)mt.chr_id, rr.mate_ref_bg = mt.ref_bg, rr.mate_sv_id = mt.sv_id;
+				if (is_ori) rr.prim_sv_id = mt.sv_id;
+				continue;
+			}
+		}
+		rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_sv_id = -1;
+	}
+}
+
+// which pairs consumed draws from an offset that the scan of the actual draw counts has since moved?
+// Also adopts the new offsets.  (engine_core.h, "rand() order")
+PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, const long long *nhoff)
+{
+	int dirty = 0;                   // 0 clean, 1 only the pairing stage drew from a stale offset, 2 a read did
+	for (int k = 0; k < 3; ++k) {
+		long long i = pair * 3 + k;
+		if (c.rcnt[i] > 0 && c.roff[i] != noff[i]) dirty = k == 2 ? (dirty > 1 ? dirty : 1) : 2;
+		c.roff[i] = noff[i];
+	}
+	for (int k = 0; k < 2; ++k) {
+		long long r = pair * 2 + k;
+		if (c.hcnt[r] > 0 && c.hoff[r] != nhoff[r]) dirty = 2;
+		c.hoff[r] = nhoff[r];
+	}
+	return dirty;
+}
+
+// materialise the byte sequences of one queued DP problem (get_refseq + the reversal of left extensions,
+// rr.cpp:920-928)
+PSVR_HD void dp_fetch_base(const Ctx &c, const DpDesc &d, int i, uint8_t *q, uint8_t *t)
+{
+	const uint8_t *src = c.bin + ((long long)d.read * 2 + d.strand) * c.lmax + d.q_st;
+	if (i < d.qlen) q[i] = d.type == 0 ? src[d.qlen - 1 - i] : src[i];
+	if (i < d.tlen) t[i] = (uint8_t)base_at(c.idx.ref_seq, (uint64_t)d.ref_st + (d.type == 0 ? d.tlen - 1 - i : i));
+}
+PSVR_HD void dp_fetch_one(const Ctx &c, const DpDesc &d, uint8_t *q, uint8_t *t)
+{
+	int n = d.qlen > d.tlen ? d.qlen : d.tlen;
+	for (int i = 0; i < n; ++i) dp_fetch_base(c, d, i, q, t);
+}
+
+} // namespace psvr

@@ -44,6 +44,48 @@ struct DpBatch { // device pointers of one batch
 template <int K> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
 
+// ---- size classes shared by the host planner (ksw_host.hip) and the device-side planner (engine.hip)
+#define PSVR_DP_NUM_LDS_CLASSES 13
+#define PSVR_DP_MAX_LDS (160 * 1024)
+__host__ __device__ inline int dp_lds_class_bytes(int cls)
+{
+	const int t[PSVR_DP_NUM_LDS_CLASSES] = {2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072, PSVR_DP_MAX_LDS};
+	return t[cls];
+}
+__host__ __device__ inline int dp_n_col(int qlen, int tlen, int w_in)
+{
+	int w = w_in < 0 ? (qlen > tlen ? qlen : tlen) : w_in;
+	int n_col = qlen < tlen ? qlen : tlen;
+	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
+	return n_col;
+}
+__host__ __device__ inline long long dp_reg_lds_need(int qlen, int tlen, int w_in)
+{
+	return (long long)((qlen + 16 + 15) & ~15) + (long long)(qlen + tlen - 1) * dp_n_col(qlen, tlen, w_in) * 16 + 16;
+}
+__host__ __device__ inline long long dp_p_bytes(int qlen, int tlen, int w_in)
+{
+	return ((long long)(qlen + tlen - 1) * dp_n_col(qlen, tlen, w_in) + 1) * 16;
+}
+__host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int variant)
+{
+	int T = (tlen + 15) / 16 * 16, QL = (qlen + 15) / 16 * 16;
+	int narr = variant == 0 ? 7 : 5;
+	int img = narr * T + T + QL + 16;
+	return ((img + 15) & ~15) + 4 * T;
+}
+// kind: 1..5 = extd2_reg_kernel<kind>, 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
+__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need)
+{
+	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
+	int T = (tlen + 15) / 16 * 16;
+	long long n = dp_reg_lds_need(qlen, tlen, w);
+	if (fast_ok && T <= 320 && n <= PSVR_DP_MAX_LDS) { *need = (int)n; return (T + 63) / 64; }
+	int g = dp_lds_kernel_need(qlen, tlen, variant);
+	*need = g;
+	return g <= PSVR_DP_MAX_LDS ? 0 : -1;
+}
+
 __device__ __forceinline__ int s8(int v) { return (int)(int8_t)v; }
 
 // DPP controls (GFX9): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143

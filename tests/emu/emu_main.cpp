@@ -1,0 +1,121 @@
+// tests/emu/emu_main.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Host backend for pansvr_amd/csrc/engine_core.h: runs the very same stage functions
+// (aln_device.h) and batch orchestration the GPU engine uses, but as plain loops on the CPU, with the
+// oracle's DP (oracle/ksw_oracle.c) standing in for the HIP DP kernel.  It exists so the stage logic
+// and the speculative rand()-offset loop can be checked against the golden records in `-m "not gpu"`
+// tests.  It is never linked into libpsvr_engine.so.
+//
+// Usage: emu_aln <fixture_index_dir> <reads.fq> <header.sam> [--trace] [--batch N]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../pansvr_amd/csrc/engine_core.h"
+#include "../../pansvr_amd/csrc/host_io.h"
+#include "../../oracle/ksw_oracle.h"
+
+using namespace psvr;
+
+struct CpuBE {
+	void *dalloc(size_t n) { return calloc(n ? n : 1, 1); }
+	void dfree(void *p) { free(p); }
+	void dzero(void *p, size_t n) { memset(p, 0, n); }
+	void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
+	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
+	void fill_i64(long long *p, long long n, int stride, int off, long long v) { for (long long i = 0; i < n; ++i) p[off + i * stride] = v; }
+	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
+	void st_prep(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) prep_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
+	void st_str(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) str_detect(c, pr(w, i >> 1) * 2 + (i & 1)); }
+	void st_seed(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 4 * n; ++i) seed_strand(c, pr(w, i >> 2) * 4 + (i & 3)); }
+	void st_chain(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) chain_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
+	void st_select(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) select_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
+	void st_walk(const Ctx &c, const int32_t *w, long long n)
+	{
+		for (long long i = 0; i < 2 * n; ++i) {
+			long long r = pr(w, i >> 1) * 2 + (i & 1);
+			if (!c.active[r]) continue;
+			for (int k = 0; k < c.n_ccand[r]; ++k) walk_candidate(c, r, k);
+		}
+	}
+	void st_assemble(const Ctx &c, long long b, long long e) { for (long long i = b; i < e; ++i) assemble_candidate(c, i); }
+	void st_finalize(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) finalize_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
+	void st_pair(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < n; ++i) pair_reads(c, pr(w, i)); }
+	void st_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
+	{
+		long long acc = base;
+		for (long long i = 0; i < n; ++i) { out[off + i * stride] = acc; acc += cnt[off + i * stride]; }
+	}
+	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
+	{
+		for (long long p = 0; p < c.n_pairs; ++p) {
+			int d = mark_dirty(c, p, noff, nhoff);
+			if (d == 2) out[(*cnt)++] = (int32_t)p;
+			else if (d == 1) outp[(*cntp)++] = (int32_t)p;
+		}
+	}
+	template <class Core> int st_dp(Core &core)
+	{
+		const Ctx &c = core.c;
+		DpIO &d = core.dp;
+		long long n = d.end - d.begin, qb = 0, tb = 0;
+		for (long long i = 0; i < n; ++i) { const DpDesc &x = c.dp.base[d.begin + i]; qb += x.qlen, tb += x.tlen; }
+		if (!core.ensure_dp(n, qb, tb, qb + tb + 2 * n)) return PSVR_ERR_NOMEM;
+		long long qo = 0, to = 0;
+		for (long long i = 0; i < n; ++i) {
+			const DpDesc &x = c.dp.base[d.begin + i];
+			d.qlen[i] = x.qlen, d.tlen[i] = x.tlen, d.q_off[i] = qo, d.t_off[i] = to;
+			dp_fetch_one(c, x, d.qbuf + qo, d.tbuf + to);
+			orc_extz_t ez;
+			psvr_extz_t &o = d.ez[i];
+			o.cigar_off = qo + to + 2 * i;
+			orc_extd2(x.qlen, d.qbuf + qo, x.tlen, d.tbuf + to, 5, c.mat, (int8_t)c.par.gap_open, (int8_t)c.par.gap_ex, (int8_t)c.par.gap_open2, (int8_t)c.par.gap_ex2,
+			          200, c.par.zdrop, -1, 0, &ez, d.cig + o.cigar_off, x.qlen + x.tlen + 2);
+			o.max = ez.max, o.zdropped = ez.zdropped, o.max_q = ez.max_q, o.max_t = ez.max_t, o.mqe = ez.mqe, o.mqe_t = ez.mqe_t;
+			o.mte = ez.mte, o.mte_q = ez.mte_q, o.score = ez.score, o.n_cigar = ez.n_cigar, o.reach_end = ez.reach_end;
+			qo += x.qlen, to += x.tlen;
+		}
+		return PSVR_OK;
+	}
+};
+
+int main(int argc, char **argv)
+{
+	if (argc < 4) { fprintf(stderr, "usage: emu_aln <index_dir> <reads.fq> <header.sam> [--trace] [--batch N]\n"); return 1; }
+	bool trace = false;
+	long long batch = 1 << 20;
+	for (int i = 4; i < argc; ++i) {
+		if (!strcmp(argv[i], "--trace")) trace = true;
+		else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoll(argv[++i]);
+	}
+	HostIndex hi;
+	hi.keep_sparse = true;       // PSVR_EMU_SPARSE_HASH build: no 2 GiB table on the CPU
+	std::string err;
+	if (!hi.load_dir(argv[1], argv[3], &err)) { fprintf(stderr, "%s\n", err.c_str()); return 2; }
+	DevIndex ix = hi.view();       // host pointers: the CPU backend's "device" is host memory
+	psvr_aln_params_t par;
+	aln_params_default(&par);
+	CpuBE be;
+	EngineCore<CpuBE> core(be);
+	FastqBatch fb;
+	FILE *fq = fopen(argv[2], "r");
+	if (!fq) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+	bool first = true;
+	long long pair_base = 0;
+	while (fb.read(fq, batch)) {
+		if (first) { fb.stat_params(&par); core.init(ix, par); first = false; }
+		int rc = core.upload(fb.n_pairs(), fb.bases.data(), (const int64_t *)fb.base_off.data(), fb.ori.data());
+		if (!rc) rc = core.run(trace, true);
+		if (rc) { fprintf(stderr, "emu error %d: %s\n", rc, core.err.c_str()); return 3; }
+		for (long long p = 0; p < fb.n_pairs(); ++p) {
+			int lens[2] = {(int)fb.recs[2 * p].seq.size(), (int)fb.recs[2 * p + 1].seq.size()};
+			puts(record_json(pair_base + p, core.c.res + 2 * p, core.c.pres[p], &fb.ori[2 * p], lens, core.c.cig.base, trace).c_str());
+		}
+		core.commit();
+		pair_base += fb.n_pairs();
+		fprintf(stderr, "[emu] batch of %lld pairs: %lld rounds, %lld pair-runs (+%lld pairing-only), %lld DP problems, %lld candidates\n", fb.n_pairs(), core.stats.rounds,
+		        core.stats.pairs_run, core.stats.pair_only, core.stats.dp_problems, core.stats.cands);
+	}
+	return 0;
+}
