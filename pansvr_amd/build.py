@@ -11,14 +11,17 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+CLI = os.path.join(HERE, "bin", "panSVR")
+
+
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(CLI):
         return True
-    t = os.path.getmtime(OUT)
+    t = min(os.path.getmtime(OUT), os.path.getmtime(CLI))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "psvr_engine.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -41,6 +44,13 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    # the drop-in CLI: plain host C++ above the C ABI (no HIP in this translation unit)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", CLI, os.path.join(CSRC, "cli_main.cpp"),
+           "-L" + HERE, "-lpsvr_engine", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

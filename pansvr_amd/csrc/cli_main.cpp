@@ -1,0 +1,300 @@
+// cli_main.cpp -- `panSVR aln` / `panSVR fc_aln` on the MI355X engine: the host side of the reference's
+// three-stage pipeline (load_reads -> [engine] -> output_results; src/PanSVgenerateVCF/read_realignment.cpp:26-176)
+// above the C ABI of include/psvr_engine.h.  Same options, positional arguments, stderr progress
+// lines and SAM records as the reference; every other sub-command of panSVR is out of scope.
+//
+// It links libpsvr_engine.so only through psvr_engine.h; host_io.h is host-side parsing/formatting.
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include <time.h>
+#include <string>
+#include <vector>
+#include "../../include/psvr_engine.h"
+#include "host_io.h"
+
+using namespace psvr;
+
+struct Opt {
+	int thread_n = 4;
+	int gap_open = 16, gap_ex = 1, gap_open2 = 32, gap_ex2 = 0, match = 2, mismatch = 12, zdrop = 400, bw = 500;
+	std::string out = "./output.bam", out_ori = "./output_ori.bam";
+	bool not_ori = false, sam = false;
+	long long max_use_read = 0x7fffffff;
+	std::string index_dir, reads, header;
+	std::string records;      // --records FILE: one JSON line per pair (what the parity tests compare)
+	bool trace = false;
+	int device = 0;
+	long long batch_pairs = 2000000;   // N_NEEDED, rr.cpp:24
+};
+
+static int usage()
+{
+	fprintf(stderr,
+	        "\n  Usage:     panSVR  aln|fc_aln  [Options] <IndexDir> [ReadFiles.fa][ori_header_fn.sam]>\n"
+	        "  Basic:   \n"
+	        "    <IndexDir>      FOLDER   the directory contains index\n"
+	        "    [ReadFiles.fa]  FILES    reads files, FASTQ(A) format, read 1 and 2 of a pair stored together ('-' = stdin).\n"
+	        "                             Using [signal] command to generate this type of file\n"
+	        "    [ori_header.sam]  FILES  Header file of original BAM/CRAM file\n"
+	        "  Options:\n"
+	        "    -t, --thread            INT  accepted for compatibility (the engine runs on the GPU) [4]\n"
+	        "    -O, --gap-open1         INT  Gap open penalty 1 [16]\n"
+	        "    -P, --gap-open2         INT  Gap open penalty 2 [32]\n"
+	        "    -E, --gap-extension1    INT  Gap extension penalty 1 [1]\n"
+	        "    -F, --gap-extension2    INT  Gap extension penalty 2 [0]\n"
+	        "    -M, --match-score       INT  Match score [2]\n"
+	        "    -m, --mis-score         INT  Mismatch score [12]\n"
+	        "    -z, --zdrop             INT  Z-drop score [400]\n"
+	        "    -w, --band-width        INT  parsed and ignored like the reference (DP band is fixed at 200) [500]\n"
+	        "    -o, --output            STR  Output file [./output.bam]\n"
+	        "    -p, --output_signal_ori STR  Reads not fully aligned by aligner nor re-aligner [./output_ori.bam]\n"
+	        "    -Q, --not-ori                NOT output original result when score of ORI is bigger\n"
+	        "    -S, --SAM                    Output as SAM (the only format this build writes; without -S a .sam is still written and a note printed)\n"
+	        "    -R, --max_use_read      INT  Max number of read pairs to align\n"
+	        "        --device            INT  HIP device [0]\n"
+	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
+	        "        --trace                  add per-strand seed/chain hashes to --records\n\n");
+	return 1;
+}
+
+static double cputime()
+{
+	return (double)clock() / CLOCKS_PER_SEC;
+}
+
+static char rc_char(char c)   // getReverseChar, clib/bam_file.c:316-327
+{
+	switch (c) {
+	case 'A': case 'a': return 'T';
+	case 'C': case 'c': return 'G';
+	case 'G': case 'g': return 'C';
+	case 'T': case 't': return 'A';
+	}
+	return 'N';
+}
+static void rev_seq(std::string &s)   // getReverseStr_char, clib/bam_file.c:329-339
+{
+	int len = (int)s.size(), half = len >> 1;
+	for (int i = 0; i < half; i++) { char t = s[i]; s[i] = rc_char(s[len - 1 - i]); s[len - 1 - i] = rc_char(t); }
+	if (len & 1) s[half] = rc_char(s[half]);
+}
+static void rev_qual(std::string &q)  // getReverseStr_qual_char, clib/bam_file.c:351-359: loop bound len/2 + 1 (even len: middle pair swapped back)
+{
+	int len = (int)q.size(), half = len >> 1;
+	for (int i = 0; i < half + 1; i++) { int ri = len - 1 - i; if (ri < 0 || i >= len) break; char t = q[i]; q[i] = q[ri]; q[ri] = t; }
+}
+
+struct HeaderInfo {
+	std::string text;
+	std::vector<std::string> names;
+	const char *name(int id) const { return id >= 0 && id < (int)names.size() ? names[id].c_str() : "*"; }
+};
+
+static bool load_header(const std::string &fn, HeaderInfo *h)
+{
+	FILE *f = fopen(fn.c_str(), "r");
+	if (!f) return false;
+	char buf[65536];
+	while (fgets(buf, sizeof buf, f)) {
+		if (buf[0] != '@') continue;
+		h->text += buf;
+		if (strncmp(buf, "@SQ", 3)) continue;
+		char *p = strstr(buf, "SN:");
+		if (!p) continue;
+		p += 3;
+		char *e = p;
+		while (*e && *e != '\t' && *e != '\n') ++e;
+		h->names.emplace_back(p, e - p);
+	}
+	fclose(f);
+	return true;
+}
+
+// what survives sam_parse1 -> sam_write1 (htslib 1.9 sam.c:1197-1424, sam_format1) for the text built by
+// single_end_handler::output_BAM (rr.cpp:479-536): POS <= 0 drops the record, RNEXT collapses to '=' ...
+static bool emit_record(FILE *out, const HeaderInfo &H, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar,
+                        bool has_mate, int mate_chr, uint32_t mate_pos, int isize, const std::string &seq, const std::string &qual, const std::string &tags)
+{
+	int pos = (int)ref_bg;                               // printed with %d
+	if (chr_id < 0 || chr_id >= (int)H.names.size()) return false;   // target_name[] would be out of range in the reference
+	if (pos - 1 < 0) return false;                       // "mapped query cannot have zero coordinate; treated as unmapped" -> tid = -1 -> not written
+	std::string rnext = "*";
+	long pnext = 0;
+	if (has_mate) {
+		int mp = (int)mate_pos;
+		bool mate_ok = mate_chr >= 0 && mate_chr < (int)H.names.size() && !(mp - 1 < 0);
+		if (mate_ok) rnext = mate_chr == chr_id ? "=" : H.name(mate_chr);
+		pnext = mp;
+	}
+	fprintf(out, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%ld\t%d\t%s\t%s%s\n", name.c_str(), flag, H.name(chr_id), pos, mapq, cigar.empty() ? "*" : cigar.c_str(), rnext.c_str(), pnext, isize,
+	        seq.c_str(), qual.c_str(), tags.c_str());
+	return true;
+}
+
+static std::string cigar_string(const psvr_cand_t &c, const uint32_t *cig)
+{
+	std::string s;
+	char b[32];
+	for (uint32_t j = 0; j < c.n_cigar; ++j) { uint32_t w = cig[c.cigar_off + j]; snprintf(b, sizeof b, "%d%c", (int)(int16_t)(w >> 4), "MIDNSHP=XB"[w & 0xf]); s += b; }
+	return s;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2 || (strcmp(argv[1], "aln") && strcmp(argv[1], "fc_aln"))) {
+		fprintf(stderr, "panSVR (MI355X engine): only the read re-alignment step is implemented here.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n");
+		return 1;
+	}
+	Opt o;
+	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
+	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
+	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {0, 0, 0, 0}};
+	int c;
+	optind = 2;
+	while ((c = getopt_long(argc, argv, "t:O:P:E:F:M:m:z:w:o:p:QSR:", lo, NULL)) >= 0) {
+		switch (c) {
+		case 't': o.thread_n = atoi(optarg); break;
+		case 'O': o.gap_open = atoi(optarg); break;
+		case 'P': o.gap_open2 = atoi(optarg); break;
+		case 'E': o.gap_ex = atoi(optarg); break;
+		case 'F': o.gap_ex2 = atoi(optarg); break;
+		case 'M': o.match = atoi(optarg); break;
+		case 'm': o.mismatch = atoi(optarg); break;
+		case 'z': o.zdrop = atoi(optarg); break;
+		case 'w': o.bw = atoi(optarg); break;
+		case 'o': o.out = optarg; break;
+		case 'p': o.out_ori = optarg; break;
+		case 'Q': o.not_ori = true; break;
+		case 'S': o.sam = true; break;
+		case 'R': o.max_use_read = atoll(optarg); break;
+		case 1000: o.device = atoi(optarg); break;
+		case 1001: o.records = optarg; break;
+		case 1002: o.trace = true; break;
+		case 1003: o.batch_pairs = atoll(optarg); break;
+		default: return usage();
+		}
+	}
+	if (argc - optind < 3) return usage();
+	if (!(o.thread_n >= 1 && o.thread_n <= 48)) { fprintf(stderr, "Input error: thread_n cannot be less than 1 or more than 48\n"); abort(); }   // xassert, rr.hpp:121
+	o.index_dir = argv[optind], o.reads = argv[optind + 1], o.header = argv[optind + 2];
+	if (!o.sam) fprintf(stderr, "[panSVR-amd] BAM output is not built into this engine yet: writing SAM text to %s\n", o.out.c_str());
+
+	HeaderInfo H;
+	fprintf(stderr, "Open original header file [%s]\n", o.header.c_str());
+	if (!load_header(o.header, &H)) { fprintf(stderr, "fail to open file '%s'\n", o.header.c_str()); abort(); }
+	fprintf(stderr, "Begin loading index @%s\n", o.index_dir.c_str());
+	psvr_index_t *idx = nullptr;
+	if (psvr_index_load(o.index_dir.c_str(), o.header.c_str(), o.device, &idx)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
+	fprintf(stderr, "End loading index\n");
+
+	fprintf(stderr, "Start classify\n");
+	double cpu0 = cputime();
+	FILE *fq = o.reads == "-" ? stdin : fopen(o.reads.c_str(), "r");
+	if (!fq) { fprintf(stderr, "fail to open file '%s'\n", o.reads.c_str()); abort(); }
+	FILE *fo = fopen(o.out.c_str(), "w"), *fo_ori = fopen(o.out_ori.c_str(), "w");
+	if (!fo || !fo_ori) { fprintf(stderr, "fail to open output file\n"); abort(); }
+	fputs(H.text.c_str(), fo), fputs(H.text.c_str(), fo_ori);
+	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
+	fprintf(stderr, "Processing file: [%s].\n", o.reads.c_str());
+
+	psvr_aln_params_t par;
+	psvr_aln_params_default(&par);
+	par.match = o.match, par.mismatch = o.mismatch, par.gap_open = o.gap_open, par.gap_ex = o.gap_ex, par.gap_open2 = o.gap_open2, par.gap_ex2 = o.gap_ex2, par.zdrop = o.zdrop;
+	psvr_engine_t *eng = nullptr;
+	FastqBatch fb;
+	std::vector<psvr_read_result_t> res;
+	std::vector<psvr_pair_result_t> pres;
+	std::vector<uint32_t> cig;
+	long long loaded = 0, pair_base = 0;
+	int block = 0;
+	for (;;) {
+		long long want = o.batch_pairs;
+		if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
+		if (want <= 0 || !fb.read(fq, want)) break;
+		loaded += fb.n_pairs();
+		if (!eng) {
+			fb.stat_params(&par);
+			fprintf(stderr, "Current used read status: READ_LEN=%d; ISIZE_MIN=%d; ISIZE_MID=%d; ISIZE_MAX=%d; filter_score_full_match=%d\n", par.normal_read_length, par.isize_min, 0,
+			        par.isize_max, par.min_filter_score);
+			if (psvr_engine_create(idx, &par, &eng)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
+		}
+		const long long P = fb.n_pairs(), R = 2 * P;
+		res.resize(R), pres.resize(P);
+		int rc = psvr_engine_upload(eng, P, fb.bases.data(), (const int64_t *)fb.base_off.data(), fb.ori.data());
+		if (!rc) rc = psvr_engine_run(eng, o.trace ? 1 : 0, nullptr);
+		int64_t used = 0;
+		if (!rc) { rc = psvr_engine_download(eng, nullptr, nullptr, nullptr, 0, &used); if (rc == PSVR_ERR_OVERFLOW) rc = 0; }
+		cig.resize(used + 1);
+		if (!rc) rc = psvr_engine_download(eng, res.data(), pres.data(), cig.data(), (int64_t)cig.size(), &used);
+		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
+		fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
+		// ---- step 2: records (output_BAM, rr.cpp:479-536)
+		for (long long p = 0; p < P; ++p) {
+			const psvr_pair_result_t &pr = pres[p];
+			if (frec) {
+				int lens[2] = {(int)fb.recs[2 * p].seq.size(), (int)fb.recs[2 * p + 1].seq.size()};
+				fprintf(frec, "%s\n", record_json(pair_base + p, &res[2 * p], pr, &fb.ori[2 * p], lens, cig.data(), o.trace).c_str());
+			}
+			if (!pr.gain) continue;
+			for (int k = 0; k < 2; ++k) {
+				const psvr_read_result_t &rr = res[2 * p + k];
+				const FqRec &rec = fb.recs[2 * p + k];
+				const psvr_ori_t &ori = fb.ori[2 * p + k];
+				if (rr.primary == -1) continue;                          // primary_result == NULL
+				const bool is_ori = rr.primary == -2;
+				if (o.not_ori && is_ori) continue;
+				int chr_id, direction, mapq;
+				uint32_t ref_bg, align_score, chain_score = 0;
+				std::string cg;
+				char b[256];
+				if (is_ori) {
+					chr_id = ori.chr_id, direction = ori.direction, mapq = ori.mapq, ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg, align_score = ori.align_score;
+					if (ori.read_bg > 0) { snprintf(b, sizeof b, "%dS", (int)(int16_t)(uint16_t)ori.read_bg); cg += b; }
+					snprintf(b, sizeof b, "%dM", (int)(int16_t)(uint16_t)((int)rec.seq.size() - (int)ori.read_bg));
+					cg += b;
+				} else {
+					const psvr_cand_t &cd = rr.cand[rr.primary];
+					chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
+					cg = cigar_string(cd, cig.data());
+				}
+				if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
+				int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
+				int isize = direction == 1 ? pr.cur_isize : -pr.cur_isize;
+				std::string seq = rec.seq, qual = rec.qual;
+				if (direction == 0) rev_seq(seq), rev_qual(qual);
+				std::string tags;
+				snprintf(b, sizeof b, "\tAS:i:%d", (int)align_score); tags += b;
+				snprintf(b, sizeof b, "\tOS:i:%d\tOA:Z:%d,%d,%d,%d,%c;", (int)ori.align_score, ori.chr_id, (int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg), (int)ori.read_bg, (int)ori.mapq,
+				         rr.unmapped ? 'U' : 'M');
+				tags += b;
+				if (!is_ori) { snprintf(b, sizeof b, "\tCS:i:%d", (int)chain_score); tags += b; }
+				const char *svs = psvr_index_sv_print_string(idx, rr.prim_sv_id);
+				if (svs) tags += std::string("\tSV:Z:") + svs;
+				const char *mvs = rr.has_mate ? psvr_index_sv_print_string(idx, rr.mate_sv_id) : nullptr;
+				if (mvs) tags += std::string("\tMV:Z:") + mvs;
+				if (rr.secondary >= 0) {
+					const psvr_cand_t &sc = rr.cand[rr.secondary];
+					const char *vid = psvr_index_sv_vcf_id(idx, sc.sv_id);
+					snprintf(b, sizeof b, "\tXA:Z:%d,%d,%d,%d,%c,", sc.chr_id, (int)sc.ref_bg, (int)sc.read_bg, (int)sc.align_score, sc.direction == 1 ? 'F' : 'R');
+					tags += b;
+					tags += vid ? vid : "*";
+					tags += ";";
+				}
+				tags += "\tRC:Z:" + rec.comment;
+				emit_record(fo, H, rec.name, flag, chr_id, ref_bg, mapq, cg, rr.has_mate != 0, rr.mate_chr_id, rr.mate_ref_bg, isize, seq, qual, tags);
+			}
+		}
+		pair_base += P;
+	}
+	if (fq != stdin) fclose(fq);
+	fclose(fo), fclose(fo_ori);
+	if (frec) fclose(frec);
+	if (eng) psvr_engine_destroy(eng);
+	psvr_index_destroy(idx);
+	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
+	return 0;
+}

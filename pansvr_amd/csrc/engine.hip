@@ -1,0 +1,498 @@
+// engine.hip -- the MI355X backend of seam B1: one named HIP kernel per stage of aln_device.h,
+// device-side planning of the DP launches, the HBM-resident index and the psvr_index_* /
+// psvr_engine_* entry points of include/psvr_engine.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "common.h"
+#include "engine_core.h"
+#include "host_io.h"
+#include "ksw_device.h"
+
+namespace psvr {
+
+int make_dp_params(const psvr_ksw_params_t *par, int variant, DpParams *P);   // ksw_host.hip
+
+static const int kBlock = 256;
+static inline unsigned grid_for(long long n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
+
+__device__ __forceinline__ long long pair_of(const int32_t *work, long long i) { return work ? (long long)work[i] : i; }
+
+// ---- stage kernels: one thread per item -------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 2 * n) prep_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+}
+__global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 2 * n) str_detect(c, pair_of(work, i >> 1) * 2 + (i & 1));
+}
+// K1 seed_probe + K2 mem_extend: hash gather, bucket search, unipath lookup, MEM extension
+__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 4 * n) seed_strand(c, pair_of(work, i >> 2) * 4 + (i & 3));
+}
+// K3 chain: merge, expand, sort, sparse chaining DP
+__global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 2 * n) chain_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+}
+__global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 2 * n) select_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+}
+__global__ __launch_bounds__(64) void k_walk(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per (read, candidate slot)
+	if (i >= 24 * n) return;
+	long long r = pair_of(work, i / 24) * 2 + ((i / 12) & 1);
+	int k = (int)(i % 12);
+	if (c.active[r] && k < c.n_ccand[r]) walk_candidate(c, r, k);
+}
+__global__ __launch_bounds__(64) void k_assemble(Ctx c, long long begin, long long end)
+{
+	long long i = begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < end) assemble_candidate(c, i);
+}
+__global__ __launch_bounds__(kBlock) void k_finalize(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 2 * n) finalize_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+}
+__global__ __launch_bounds__(kBlock) void k_pair(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) pair_reads(c, pair_of(work, i));
+}
+__global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt,
+                                                  int32_t *outp, unsigned long long *cntp)
+{
+	long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (p >= c.n_pairs) return;
+	int d = mark_dirty(c, p, noff, nhoff);
+	if (d == 2) out[atomicAdd(cnt, 1ull)] = (int32_t)p;
+	else if (d == 1) outp[atomicAdd(cntp, 1ull)] = (int32_t)p;
+}
+__global__ void k_fill_i64(long long *p, long long n, int stride, int off, long long v)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) p[off + i * stride] = v;
+}
+
+// exclusive scan of int32 counts into int64 offsets; one 1024-thread workgroup walks the array in tiles
+// (the arrays are a few MB: this is launch-latency, not bandwidth)
+__global__ __launch_bounds__(1024) void k_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
+{
+	__shared__ long long part[1024];
+	__shared__ long long carry;
+	const int tid = threadIdx.x;
+	if (tid == 0) carry = base;
+	__syncthreads();
+	const int per = 8;
+	for (long long tile = 0; tile < n; tile += 1024 * per) {
+		long long v[per], s = 0;
+		for (int k = 0; k < per; ++k) {
+			long long i = tile + (long long)tid * per + k;
+			v[k] = i < n ? cnt[off + i * stride] : 0;
+			s += v[k];
+		}
+		part[tid] = s;
+		__syncthreads();
+		for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan of the per-thread sums
+			long long t = tid >= d ? part[tid - d] : 0;
+			__syncthreads();
+			part[tid] += t;
+			__syncthreads();
+		}
+		long long run = carry + part[tid] - s;
+		for (int k = 0; k < per; ++k) {
+			long long i = tile + (long long)tid * per + k;
+			if (i < n) out[off + i * stride] = run;
+			run += v[k];
+		}
+		__syncthreads();
+		if (tid == 1023) carry += part[1023];
+		__syncthreads();
+	}
+}
+
+// ---- DP planning on the device ---------------------------------------------------------------
+struct DpPlanDev {
+	const DpDesc *desc; long long n;
+	int32_t *qlen, *tlen; long long *q_off, *t_off, *p_off;
+	int32_t *plen;                 // padded direction-byte bytes for general-kernel problems (0 otherwise), as int32 units of 256 B
+	int32_t *bucket;               // bucket id per problem
+	unsigned long long *hist;      // [6*13] counts, then cursors
+	int32_t *idx;
+	psvr_extz_t *ez;
+};
+__global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= d.n) return;
+	const DpDesc &x = d.desc[i];
+	d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
+	int need;
+	int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need);
+	int cls = 0;
+	while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
+	d.plen[i] = kind == 0 ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
+	int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
+	d.bucket[i] = b;
+	atomicAdd(d.hist + b, 1ull);
+}
+__global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= d.n) return;
+	int b = d.bucket[i];
+	unsigned long long k = atomicAdd(d.hist + 128 + b, 1ull);
+	d.idx[bucket_start[b] + k] = (int32_t)i;
+	d.ez[i].cigar_off = d.q_off[i] + d.t_off[i] + 2 * i;
+}
+// K5 ref_fetch: unpack the 2-bit reference window / slice the read for every queued DP problem
+__global__ __launch_bounds__(64) void k_dp_fetch(Ctx c, long long begin, const long long *q_off, const long long *t_off, uint8_t *qbuf, uint8_t *tbuf)
+{
+	const DpDesc &x = c.dp.base[begin + blockIdx.x];
+	uint8_t *q = qbuf + q_off[blockIdx.x], *t = tbuf + t_off[blockIdx.x];
+	const int n = x.qlen > x.tlen ? x.qlen : x.tlen;
+	for (int i = threadIdx.x; i < n; i += 64) dp_fetch_base(c, x, i, q, t);
+}
+
+struct GpuBE {
+	hipStream_t stream = nullptr;
+	hipError_t last = hipSuccess;
+	std::vector<std::pair<std::string, long long>> launches;   // for psvr_engine_stats
+	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, pslab;
+	DpParams dpP;
+	bool dp_ready = false;
+
+	void note(hipError_t e) { if (e != hipSuccess && last == hipSuccess) last = e; }
+	void *dalloc(size_t n) { void *p = nullptr; hipError_t e = hipMalloc(&p, n ? n : 16); note(e); return e == hipSuccess ? p : nullptr; }
+	void dfree(void *p) { if (p) (void)hipFree(p); }
+	void dzero(void *p, size_t n) { note(hipMemsetAsync(p, 0, n, stream)); }
+	void h2d(void *d, const void *h, size_t n) { note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); }
+	void d2h(void *h, const void *d, size_t n) { note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); }
+	void fill_i64(long long *p, long long n, int stride, int off, long long v)
+	{
+		if (n) hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, stride, off, v);
+	}
+#define PSVR_STAGE(name, kern, mult, blk)                                                                          \
+	void name(const Ctx &c, const int32_t *w, long long n)                                                         \
+	{                                                                                                              \
+		if (n > 0) hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n, blk)), dim3(blk), 0, stream, c, w, n);       \
+		note(hipGetLastError());                                                                                   \
+	}
+	PSVR_STAGE(st_prep, k_prep, 2, kBlock)
+	PSVR_STAGE(st_str, k_str_detect, 2, kBlock)
+	PSVR_STAGE(st_seed, k_seed, 4, kBlock)
+	PSVR_STAGE(st_chain, k_chain, 2, kBlock)
+	PSVR_STAGE(st_select, k_select, 2, kBlock)
+	PSVR_STAGE(st_walk, k_walk, 24, 64)
+	PSVR_STAGE(st_finalize, k_finalize, 2, kBlock)
+	PSVR_STAGE(st_pair, k_pair, 1, kBlock)
+#undef PSVR_STAGE
+	void st_assemble(const Ctx &c, long long b, long long e)
+	{
+		if (e > b) hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b, 64)), dim3(64), 0, stream, c, b, e);
+		note(hipGetLastError());
+	}
+	void st_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
+	{
+		if (n > 0) hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, cnt, n, stride, off, base, out);
+		note(hipGetLastError());
+	}
+	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
+	{
+		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp);
+		note(hipGetLastError());
+	}
+
+	// queue -> lens -> offsets -> byte sequences -> size classes -> one DP launch per class
+	template <class Core> int st_dp(Core &core)
+	{
+		const Ctx &c = core.c;
+		DpIO &d = core.dp;
+		const long long n = d.end - d.begin;
+		if (!dp_ready) {
+			psvr_ksw_params_t kp;
+			memset(&kp, 0, sizeof kp);
+			kp.m = 5;
+			memcpy(kp.mat, c.mat, 25);
+			kp.q = (int8_t)c.par.gap_open, kp.e = (int8_t)c.par.gap_ex, kp.q2 = (int8_t)c.par.gap_open2, kp.e2 = (int8_t)c.par.gap_ex2;
+			kp.w = 200, kp.zdrop = c.par.zdrop, kp.end_bonus = -1, kp.flag = 0;   // KSW_ALN_handler::copy_option, rr.cpp:817-827 (bandwith = 200)
+			int rc = make_dp_params(&kp, 0, &dpP);
+			if (rc) return rc;
+#define PSVR_ATTR(k) note(hipFuncSetAttribute((const void *)(k), hipFuncAttributeMaxDynamicSharedMemorySize, PSVR_DP_MAX_LDS))
+			PSVR_ATTR(extd2_reg_kernel<1>); PSVR_ATTR(extd2_reg_kernel<2>); PSVR_ATTR(extd2_reg_kernel<3>);
+			PSVR_ATTR(extd2_reg_kernel<4>); PSVR_ATTR(extd2_reg_kernel<5>); PSVR_ATTR(extd2_lds_kernel<0>);
+#undef PSVR_ATTR
+			dp_ready = true;
+		}
+		// upper bounds for the sequence buffers: every problem has qlen, tlen < 1600; size from the actual lens
+		if (!core.ensure_dp(n, 0, 0, 0)) return set_error(PSVR_ERR_NOMEM, "DP buffers");
+		PSVR_HIP(plan_bucket.ensure(n * 4)); PSVR_HIP(plan_idx.ensure(n * 4)); PSVR_HIP(plan_plen.ensure((n + 1) * 4)); PSVR_HIP(plan_poff.ensure((n + 1) * 8));
+		PSVR_HIP(plan_hist.ensure(256 * 8)); PSVR_HIP(plan_bstart.ensure(128 * 8));
+		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 256 * 8, stream));
+		DpPlanDev pd;
+		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
+		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
+		pd.hist = plan_hist.as<unsigned long long>(), pd.idx = plan_idx.as<int32_t>(), pd.ez = d.ez;
+		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200);
+		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const int32_t *)d.qlen, n + 1, 1, 0, 0ll, d.q_off);
+		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
+		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
+		PSVR_HIP(hipGetLastError());
+		unsigned long long hist[128];
+		long long tot[3];
+		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 128 * 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(&tot[0], d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(&tot[1], d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(&tot[2], pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipStreamSynchronize(stream));
+		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
+		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
+		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
+		long long bstart[128], acc = 0;
+		std::vector<Launch3> ls;
+		const int kind_order[6] = {0, 5, 4, 3, 2, 1};
+		for (int ko = 0; ko < 6; ++ko)
+			for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
+				int b = kind_order[ko] * PSVR_DP_NUM_LDS_CLASSES + cls;
+				bstart[b] = acc;
+				if (hist[b]) ls.push_back(Launch3{kind_order[ko], dp_lds_class_bytes(cls), acc, (long long)hist[b]});
+				acc += (long long)hist[b];
+			}
+		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 128 * 8, hipMemcpyHostToDevice, stream));
+		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
+		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
+		hipLaunchKernelGGL(k_dp_fetch, dim3((unsigned)n), dim3(64), 0, stream, c, d.begin, (const long long *)d.q_off, (const long long *)d.t_off, d.qbuf, d.tbuf);
+		PSVR_HIP(hipGetLastError());
+		DpBatch B;
+		B.qseq = d.qbuf, B.q_off = (const int64_t *)d.q_off, B.qlen = d.qlen;
+		B.tseq = d.tbuf, B.t_off = (const int64_t *)d.t_off, B.tlen = d.tlen;
+		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = nullptr, B.p_unit_shift = 0;
+		// general-kernel problems address their direction bytes in 256-byte units: convert once
+		for (const Launch3 &L : ls) {
+			B.idx = plan_idx.as<int32_t>() + L.first;
+			dim3 grid((unsigned)L.count), block(64);
+			switch (L.kind) {
+			case 1: hipLaunchKernelGGL(extd2_reg_kernel<1>, grid, block, L.lds, stream, B, dpP); break;
+			case 2: hipLaunchKernelGGL(extd2_reg_kernel<2>, grid, block, L.lds, stream, B, dpP); break;
+			case 3: hipLaunchKernelGGL(extd2_reg_kernel<3>, grid, block, L.lds, stream, B, dpP); break;
+			case 4: hipLaunchKernelGGL(extd2_reg_kernel<4>, grid, block, L.lds, stream, B, dpP); break;
+			case 5: hipLaunchKernelGGL(extd2_reg_kernel<5>, grid, block, L.lds, stream, B, dpP); break;
+			default: {
+				DpBatch G = B;
+				G.p_off = (const int64_t *)plan_poff.p;
+				G.p_unit_shift = 8;
+				hipLaunchKernelGGL(extd2_lds_kernel<0>, grid, block, L.lds, stream, G, dpP);
+			}
+			}
+			PSVR_HIP(hipGetLastError());
+		}
+		return PSVR_OK;
+	}
+	struct Launch3 { int kind, lds; long long first, count; };
+};
+
+} // namespace psvr
+
+using namespace psvr;
+
+// ------------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------------
+struct psvr_index {
+	int device = 0;
+	HostIndex host;          // small tables + strings stay on the host too (SAM formatting)
+	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv;
+	DevIndex dev;
+	int64_t bytes = 0;
+};
+
+static int index_upload(psvr_index *ix, const psvr_index_view_t *v)
+{
+	PSVR_HIP(hipSetDevice(ix->device));
+	auto up = [&](DevBuf &b, const void *src, size_t n, size_t pad) -> hipError_t {
+		hipError_t e = b.alloc(n + pad);
+		if (e != hipSuccess) return e;
+		ix->bytes += (int64_t)(n + pad);
+		if (pad) { e = hipMemset((char *)b.p + n, 0, pad); if (e != hipSuccess) return e; }
+		return n ? hipMemcpy(b.p, src, n, hipMemcpyHostToDevice) : hipSuccess;
+	};
+	PSVR_HIP(up(ix->ref_seq, v->ref_seq, v->n_ref_seq * 8, 544));   // load_index_file pads ref.seq with 536 zero bytes
+	PSVR_HIP(up(ix->seq, v->seq, v->n_seq * 8, 16));
+	PSVR_HIP(up(ix->seqf, v->seqf, v->n_seqf * 8, 0));
+	PSVR_HIP(up(ix->pos, v->pos, v->n_pos * 8, 0));
+	PSVR_HIP(up(ix->posp, v->posp, v->n_posp * 8, 0));
+	PSVR_HIP(up(ix->hash, v->hash, v->n_hash * 8, 0));
+	PSVR_HIP(up(ix->off, v->off, v->n_off * 8, 0));
+	PSVR_HIP(up(ix->kmer, v->kmer, v->n_kmer * 4, 16));
+	const HostIndex &h = ix->host;
+	PSVR_HIP(up(ix->chr_end, h.chr_end_n.data(), h.chr_end_n.size() * 4, 0));
+	PSVR_HIP(up(ix->chr_idx, h.chr_search_index.data(), h.chr_search_index.size() * 4, 0));
+	PSVR_HIP(up(ix->sv, h.sv.data(), h.sv.size() * sizeof(SvDev), 0));
+	DevIndex &d = ix->dev;
+	memset(&d, 0, sizeof d);
+	d.ref_seq = ix->ref_seq.as<uint64_t>(), d.seq = ix->seq.as<uint64_t>(), d.seqf = ix->seqf.as<uint64_t>(), d.pos = ix->pos.as<uint64_t>();
+	d.posp = ix->posp.as<uint64_t>(), d.hash = ix->hash.as<uint64_t>(), d.off = ix->off.as<uint64_t>(), d.kmer = ix->kmer.as<uint32_t>();
+	d.n_seqf = v->n_seqf, d.chr_end_n = ix->chr_end.as<uint32_t>(), d.chr_search_index = ix->chr_idx.as<uint32_t>(), d.sv = ix->sv.as<SvDev>();
+	d.chr_file_n = h.chr_file_n;
+	return PSVR_OK;
+}
+
+extern "C" int psvr_index_create(const psvr_index_view_t *v, int device, psvr_index_t **out)
+{
+	if (!v || !out || !v->ref_seq || !v->seq || !v->seqf || !v->pos || !v->posp || !v->hash || !v->kmer || !v->off || !v->chr_text)
+		return set_error(PSVR_ERR_ARG, "psvr_index_create: null pointer in view");
+	if (v->n_hash != ((uint64_t)1 << 28) + 1) return set_error(PSVR_ERR_IO, "unipath_g.hash must hold 4^14+1 entries, got %llu", (unsigned long long)v->n_hash);
+	if (psvr_device_count() <= 0) return set_error(PSVR_ERR_DEVICE, "no HIP device visible: the engine has no CPU path");
+	psvr_index *ix = new psvr_index;
+	ix->device = device;
+	std::vector<std::string> names;
+	for (int i = 0; i < v->n_header; ++i) names.push_back(v->header_names[i]);
+	std::string err;
+	if (!ix->host.parse_chr(v->chr_text, names, &err)) { delete ix; return set_error(PSVR_ERR_IO, "%s", err.c_str()); }
+	int rc = index_upload(ix, v);
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return PSVR_OK;
+}
+
+extern "C" int psvr_index_load(const char *dir, const char *header_sam, int device, psvr_index_t **out)
+{
+	if (!dir || !header_sam || !out) return set_error(PSVR_ERR_ARG, "psvr_index_load: null argument");
+	if (psvr_device_count() <= 0) return set_error(PSVR_ERR_DEVICE, "no HIP device visible: the engine has no CPU path");
+	psvr_index *ix = new psvr_index;
+	ix->device = device;
+	std::string err;
+	if (!ix->host.load_dir(dir, header_sam, &err)) { delete ix; return set_error(PSVR_ERR_IO, "%s", err.c_str()); }
+	HostIndex &h = ix->host;
+	psvr_index_view_t v;
+	memset(&v, 0, sizeof v);
+	v.ref_seq = h.ref_seq.data(), v.n_ref_seq = h.ref_seq.size(), v.seq = h.seq.data(), v.n_seq = h.seq.size();
+	v.seqf = h.seqf.data(), v.n_seqf = h.seqf.size(), v.pos = h.pos.data(), v.n_pos = h.pos.size(), v.posp = h.posp.data(), v.n_posp = h.posp.size();
+	v.hash = h.hash.data(), v.n_hash = h.hash.size(), v.kmer = h.kmer.data(), v.n_kmer = h.kmer.size(), v.off = h.off.data(), v.n_off = h.off.size();
+	int rc = index_upload(ix, &v);
+	std::vector<uint64_t>().swap(h.hash);          // the 2 GiB table now lives in HBM only
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return PSVR_OK;
+}
+
+extern "C" void psvr_index_destroy(psvr_index_t *ix) { delete ix; }
+extern "C" int64_t psvr_index_device_bytes(const psvr_index_t *ix) { return ix ? ix->bytes : 0; }
+extern "C" int32_t psvr_index_n_anchor(const psvr_index_t *ix) { return ix ? ix->host.chr_file_n : 0; }
+extern "C" const char *psvr_index_sv_print_string(const psvr_index_t *ix, int32_t sv)
+{
+	return ix && sv >= 0 && sv < (int)ix->host.svh.size() ? ix->host.svh[sv].vcf_print_string.c_str() : nullptr;
+}
+extern "C" const char *psvr_index_sv_vcf_id(const psvr_index_t *ix, int32_t sv)
+{
+	return ix && sv >= 0 && sv < (int)ix->host.svh.size() ? ix->host.svh[sv].vcf_id.c_str() : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct psvr_engine {
+	const psvr_index *ix;
+	GpuBE be;
+	EngineCore<GpuBE> core;
+	bool committed = true;
+	explicit psvr_engine(const psvr_index *i) : ix(i), core(be) {}
+};
+
+extern "C" void psvr_aln_params_default(psvr_aln_params_t *p) { if (p) aln_params_default(p); }
+
+extern "C" int psvr_engine_create(const psvr_index_t *ix, const psvr_aln_params_t *par, psvr_engine_t **out)
+{
+	if (!ix || !par || !out) return set_error(PSVR_ERR_ARG, "psvr_engine_create: null argument");
+	PSVR_HIP(hipSetDevice(ix->device));
+	psvr_engine *e = new psvr_engine(ix);
+	e->core.init(ix->dev, *par);
+	*out = e;
+	return PSVR_OK;
+}
+
+extern "C" void psvr_engine_destroy(psvr_engine_t *e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->ix->device);
+	e->core.free_all();
+	delete e;
+}
+
+static int engine_status(psvr_engine *e, int rc)
+{
+	if (e->be.last != hipSuccess) { hipError_t x = e->be.last; e->be.last = hipSuccess; return set_error(PSVR_ERR_DEVICE, "HIP error: %s", hipGetErrorString(x)); }
+	if (rc) return set_error(rc, "%s", e->core.err.empty() ? psvr_last_error() : e->core.err.c_str());
+	return PSVR_OK;
+}
+
+extern "C" int psvr_engine_upload(psvr_engine_t *e, int64_t n_pairs, const char *bases, const int64_t *base_off, const psvr_ori_t *ori)
+{
+	if (!e || n_pairs < 0 || (n_pairs && (!bases || !base_off || !ori))) return set_error(PSVR_ERR_ARG, "psvr_engine_upload: bad argument");
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	if (!e->committed) { e->core.commit(); e->committed = true; }
+	int rc = e->core.upload(n_pairs, bases, base_off, ori);
+	return engine_status(e, rc);
+}
+
+extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
+{
+	if (!e) return set_error(PSVR_ERR_ARG, "psvr_engine_run: null engine");
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	e->be.stream = (hipStream_t)stream;
+	int rc = e->core.run(trace & 1, (trace & 2) != 0);
+	hipError_t s = hipStreamSynchronize(e->be.stream);
+	if (s != hipSuccess) e->be.note(s);
+	e->committed = false;       // the rand streams advance when the next batch is uploaded (or on download)
+	return engine_status(e, rc);
+}
+
+extern "C" int psvr_engine_download(psvr_engine_t *e, psvr_read_result_t *reads, psvr_pair_result_t *pairs, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used)
+{
+	if (!e) return set_error(PSVR_ERR_ARG, "psvr_engine_download: null engine");
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	auto &c = e->core;
+	if (c.P == 0) { if (cigar_used) *cigar_used = 0; return PSVR_OK; }
+	unsigned long long top = 0;
+	PSVR_HIP(hipMemcpy(&top, c.c.cig.top, 8, hipMemcpyDeviceToHost));
+	if (cigar_used) *cigar_used = (int64_t)top;
+	if ((int64_t)top > cigar_cap) return set_error(PSVR_ERR_OVERFLOW, "cigar arena too small: need %llu uint32, have %lld", top, (long long)cigar_cap);
+	if (reads) PSVR_HIP(hipMemcpy(reads, c.c.res, c.R * sizeof(psvr_read_result_t), hipMemcpyDeviceToHost));
+	if (pairs) PSVR_HIP(hipMemcpy(pairs, c.c.pres, c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost));
+	if (cigar && top) PSVR_HIP(hipMemcpy(cigar, c.c.cig.base, top * 4, hipMemcpyDeviceToHost));
+	return PSVR_OK;
+}
+
+extern "C" int psvr_engine_align_batch(psvr_engine_t *e, int64_t n_pairs, const char *bases, const int64_t *base_off, const psvr_ori_t *ori,
+                                       psvr_read_result_t *reads, psvr_pair_result_t *pairs, uint32_t *cigar, int64_t cigar_cap, int trace)
+{
+	int rc = psvr_engine_upload(e, n_pairs, bases, base_off, ori);
+	if (rc) return rc;
+	rc = psvr_engine_run(e, trace, nullptr);
+	if (rc) return rc;
+	return psvr_engine_download(e, reads, pairs, cigar, cigar_cap, nullptr);
+}
+
+extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
+{
+	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
+	const RunStats &s = e->core.stats;
+	snprintf(buf, n,
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
+	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
+	return PSVR_OK;
+}

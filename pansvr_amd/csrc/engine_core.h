@@ -244,11 +244,11 @@ template <class BE> struct EngineCore {
 			return *p != nullptr;
 		};
 		bool ok = true;
-		if (n > dp_cap_n || !dp.qlen) {
+		if (n + 2 > dp_cap_n || !dp.qlen) {
 			long long cap = 0;
-			for (void **p : {(void **)&dp.qlen, (void **)&dp.tlen}) { cap = dp_cap_n; ok &= grow(p, cap, n, 4); }
-			for (void **p : {(void **)&dp.q_off, (void **)&dp.t_off}) { cap = dp_cap_n; ok &= grow(p, cap, n + 1, 8); }
-			cap = dp_cap_n; ok &= grow((void **)&dp.ez, cap, n, sizeof(psvr_extz_t));
+			void **arr[5] = {(void **)&dp.qlen, (void **)&dp.tlen, (void **)&dp.q_off, (void **)&dp.t_off, (void **)&dp.ez};
+			const size_t el[5] = {4, 4, 8, 8, sizeof(psvr_extz_t)};
+			for (int k = 0; k < 5; ++k) { cap = 0; if (*arr[k]) be.dfree(*arr[k]); *arr[k] = nullptr; ok &= grow(arr[k], cap, n + 2, el[k]); }
 			dp_cap_n = cap;
 		}
 		ok &= grow((void **)&dp.qbuf, dp_cap_q, qb + 64, 1);

@@ -38,7 +38,8 @@ struct DpBatch { // device pointers of one batch
 	const uint8_t *qseq; const int64_t *q_off; const int32_t *qlen;
 	const uint8_t *tseq; const int64_t *t_off; const int32_t *tlen;
 	psvr_extz_t *ez; uint32_t *cigar;
-	uint8_t *pslab; const int64_t *p_off;   // lds kernel only: direction-byte slab
+	uint8_t *pslab; const int64_t *p_off;   // lds kernel only: direction-byte slab, offsets in (1 << p_unit_shift)-byte units
+	int32_t p_unit_shift;
 };
 
 template <int K> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip

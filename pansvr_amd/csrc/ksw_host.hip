@@ -209,7 +209,7 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 	B.qseq = d_qseq, B.q_off = d_q_off, B.qlen = pl->d_qlen.as<int32_t>();
 	B.tseq = d_tseq, B.t_off = d_t_off, B.tlen = pl->d_tlen.as<int32_t>();
 	B.ez = d_ez, B.cigar = d_cigar;
-	B.pslab = (uint8_t *)d_work, B.p_off = pl->d_poff.as<int64_t>();
+	B.pslab = (uint8_t *)d_work, B.p_off = pl->d_poff.as<int64_t>(), B.p_unit_shift = 0;
 	for (const Launch &L : pl->launches) {
 		B.idx = pl->d_idx.as<int32_t>() + L.first;
 		dim3 grid((unsigned)L.count), block(64);

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void extd2_lds_kernel(DpBatch B, DpParams P)
 	uint8_t *sf = (uint8_t*)(sa + T), *qr = sf + T;
 	const int img = NARR * T + T + QL + 16;            // bytes of the byte image (+16 calloc tail)
 	int32_t *H = (int32_t*)(lds + ((img + 15) & ~15));
-	uint8_t *Pm = B.pslab + B.p_off[pid];
+	uint8_t *Pm = B.pslab + (B.p_off[pid] << B.p_unit_shift);
 	const int flag = P.flag;
 	const int with_cigar = !(flag & PSVR_EZ_SCORE_ONLY), approx_max = !!(flag & PSVR_EZ_APPROX_MAX);
 	const int right = with_cigar && (flag & PSVR_EZ_RIGHT);
