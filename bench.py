@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- signal reads realigned / sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole `aln` hot path (prep -> seeding -> chaining -> candidate
+selection -> extension DP -> assembly -> pairing, incl. the speculative rand()-offset rounds) over one
+batch of synthetic 150 bp read pairs that is already resident in HBM (configs[1]: 1 M pairs vs a
+10 k-anchor SV reference).  With --gpus N every rank owns one GPU and an independent shard of the
+same size (weak scaling, no data-path collective: read pairs are independent given the replicated
+index); time is max over ranks between barriers.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     HBM roofline of the dominant kernel, timed live with HIP events on its launch stream
+  "cpu_baseline": the oracle restatement (kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU (configs[1]: 1 M)")
+    ap.add_argument("--anchors", type=int, default=10000)
+    ap.add_argument("--cpu-pairs", type=int, default=60000, help="pairs of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    import bench_data
+    from pansvr_amd import aln
+
+    t_setup = time.time()
+    anc = bench_data.make_anchors(args.anchors, seed=11)
+    ix_arrays = bench_data.build_index(anc, dense=True)
+    index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
+    ix_sparse, ix_small = ix_arrays["hash_sparse"], {k: v for k, v in ix_arrays.items() if k != "hash"}
+    del ix_arrays
+    bases, base_off, ori, isize = bench_data.make_reads(anc, args.pairs, seed=13 + rank)
+    eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
+    eng.upload(bases, base_off, ori)
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run()
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        eng.run()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    reads_per_step = 2 * args.pairs * world
+    value = reads_per_step * args.steps / dt
+
+    # one extra instrumented pass (not timed above): per-kernel HIP-event durations + work counters
+    eng.run(stats=True, timing=True)
+    st = eng.stats()
+    kern = st["kernels"]
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    roofline, cpu = None, None
+    if rank == 0:
+        # algorithmic bytes per read, counted by the oracle on the CPU sample below
+        tmp = tempfile.mkdtemp(prefix="psvr_bench_")
+        n_cpu = min(args.cpu_pairs, args.pairs)
+        bytes_per_read, seed_bytes_per_read = None, None
+        if n_cpu > 0:
+            ix_small["hash_sparse"] = ix_sparse
+            bench_data.write_index_dir(ix_small, os.path.join(tmp, "idx"))
+            bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, n_pairs=n_cpu)
+            with open(os.path.join(tmp, "header.sam"), "w") as f:
+                f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")
+            exe = os.path.join(ROOT, "oracle", "aln_oracle")
+            tc = time.time()
+            out = subprocess.run([exe, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam"), "--stats"],
+                                 stdout=subprocess.PIPE, check=True).stdout.decode()
+            tc = time.time() - tc
+            # subtract the index/FASTQ load by timing a zero-read run
+            tl = time.time()
+            subprocess.run([exe, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam"), "--stats", "--limit", "0"],
+                           stdout=subprocess.PIPE, check=True)
+            tl = time.time() - tl
+            cs = json.loads(out.strip().split("\n")[-1])
+            cpu = {"value": round(2 * n_cpu / max(tc - tl, 1e-9), 1), "unit": "reads/s", "cores": 1, "kind": "port",
+                   "sample": "first %d pairs of the same workload, oracle/aln_oracle -t 1 equivalent (scalar C++ restatement), index load excluded" % n_cpu}
+            bytes_per_read = cs["bytes"]["total"] / (2.0 * n_cpu)
+            seed_bytes_per_read = (cs["bytes"]["probe"] + cs["bytes"]["hit"] + cs["bytes"]["read"]) / (2.0 * n_cpu)
+        launches = max(1, kern[dom]["launches"])
+        avg_ms = kern[dom]["ms"] / launches
+        share = {"k_seed": seed_bytes_per_read}.get(dom, bytes_per_read)
+        if share is not None:
+            # first launch of the dominant kernel covers all 2P reads of the batch; later (speculative) launches cover few
+            alg_bytes = share * 2 * args.pairs
+            achieved = alg_bytes / (kern[dom]["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
+                        "traffic": None, "alg_bytes_per_read": round(share, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
+                        "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4)}
+    if rank == 0:
+        line = {"metric": "signal reads realigned/sec (150 bp PE); bit-exact CIGAR vs CPU ref", "value": round(value, 1), "unit": "reads/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (2-bit k-mers, 8-bit DP deltas, 32-bit scores)",
+                "data": "synthetic", "config": {"workload": "configs[1]: %d synthetic 150 bp PE signal read pairs per GPU vs %d-anchor SV reference (%.1f Mbp), `panSVR aln` hot path"
+                                                 % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
+                                                 "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated)" % world,
+                                                 "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
+                "roofline": roofline, "cpu_baseline": cpu,
+                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
+                "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    index.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""ctypes bindings of the index + engine entry points (seam B1) of include/psvr_engine.h."""
+import ctypes as C
+import json
+
+import numpy as np
+
+from ._lib import check, lib
+
+ORI_DTYPE = np.dtype([("chr_id", "<i4"), ("ref_bg", "<u4"), ("read_bg", "<u4"), ("align_score", "<u4"),
+                      ("mapq", "u1"), ("direction", "u1"), ("unmapped", "u1"), ("reserved", "u1")])
+CAND_DTYPE = np.dtype([("align_score", "<u4"), ("chain_score", "<u4"), ("ref_bg", "<u4"), ("read_bg", "<u4"), ("chr_id", "<i4"), ("sv_id", "<i4"),
+                       ("max_index", "<u4"), ("n_cigar", "<u4"), ("cigar_off", "<i8"), ("direction", "u1"), ("mapq", "u1"), ("reserved", "u1", 6)], align=True)
+READ_DTYPE = np.dtype([("n_result", "<i4"), ("unmapped", "u1"), ("early_out", "u1"), ("is_str", "u1"), ("reserved", "u1"),
+                       ("primary", "<i4"), ("secondary", "<i4"), ("has_mate", "<i4"), ("mate_chr_id", "<i4"), ("mate_ref_bg", "<u4"),
+                       ("prim_sv_id", "<i4"), ("mate_sv_id", "<i4"), ("n_seed", "<u4", 2), ("seed_hash", "<u8", 2), ("chain_hash", "<u8", 2),
+                       ("cand", CAND_DTYPE, 12)], align=True)
+PAIR_DTYPE = np.dtype([("max_score", "<i4"), ("cur_isize", "<i4"), ("proper", "<i4"), ("gain", "<i4"), ("max1", "<i4"), ("max2", "<i4")])
+
+
+class AlnParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("match", "mismatch", "gap_open", "gap_ex", "gap_open2", "gap_ex2", "zdrop",
+                                          "normal_read_length", "isize_min", "isize_max", "min_filter_score")]
+
+
+class IndexView(C.Structure):
+    _fields_ = [("ref_seq", C.c_void_p), ("n_ref_seq", C.c_uint64), ("seq", C.c_void_p), ("n_seq", C.c_uint64),
+                ("seqf", C.c_void_p), ("n_seqf", C.c_uint64), ("pos", C.c_void_p), ("n_pos", C.c_uint64),
+                ("posp", C.c_void_p), ("n_posp", C.c_uint64), ("hash", C.c_void_p), ("n_hash", C.c_uint64),
+                ("kmer", C.c_void_p), ("n_kmer", C.c_uint64), ("off", C.c_void_p), ("n_off", C.c_uint64),
+                ("chr_text", C.c_char_p), ("header_names", C.POINTER(C.c_char_p)), ("n_header", C.c_int32)]
+
+
+def default_params(stat=None):
+    p = AlnParams()
+    lib().psvr_aln_params_default(C.byref(p))
+    if stat is not None:  # STAT_len_min_mid_max of the first read (load_reads, read_realignment.cpp:134-148)
+        p.normal_read_length, p.isize_min, p.isize_max = stat[0], stat[1], stat[3]
+        p.min_filter_score = max(50, stat[0] * p.match * 2 - 80)
+    return p
+
+
+class Index:
+    def __init__(self, arrays, header_names, device=0):
+        """arrays: dict with ref_seq, seq, seqf, pos, posp, hash, off (uint64), kmer (uint32), chr (str)."""
+        L = lib()
+        L.psvr_index_device_bytes.restype = C.c_int64
+        self._keep = {k: np.ascontiguousarray(v) for k, v in arrays.items() if k != "chr"}
+        v = IndexView()
+        for f, k in (("ref_seq", "ref_seq"), ("seq", "seq"), ("seqf", "seqf"), ("pos", "pos"), ("posp", "posp"), ("hash", "hash"), ("kmer", "kmer"), ("off", "off")):
+            a = self._keep[k]
+            setattr(v, f, a.ctypes.data)
+            setattr(v, "n_" + f, a.shape[0])
+        v.chr_text = arrays["chr"].encode()
+        names = (C.c_char_p * len(header_names))(*[n.encode() for n in header_names])
+        v.header_names, v.n_header = names, len(header_names)
+        self.h = C.c_void_p()
+        check(L.psvr_index_create(C.byref(v), device, C.byref(self.h)))
+        self.device_bytes = int(L.psvr_index_device_bytes(self.h))
+        self._keep = None  # host copies are no longer needed: the index lives in HBM
+
+    def close(self):
+        if self.h:
+            lib().psvr_index_destroy(self.h)
+            self.h = None
+
+
+class Engine:
+    def __init__(self, index, params=None):
+        self.index = index
+        self.h = C.c_void_p()
+        self.params = params or default_params()
+        check(lib().psvr_engine_create(index.h, C.byref(self.params), C.byref(self.h)))
+        self.n_pairs = 0
+
+    def upload(self, bases, base_off, ori):
+        """bases: uint8 ASCII array; base_off: int64[2P+1]; ori: ORI_DTYPE[2P]."""
+        self._b = np.ascontiguousarray(bases, dtype=np.uint8)
+        self._o = np.ascontiguousarray(base_off, dtype=np.int64)
+        self._r = np.ascontiguousarray(ori, dtype=ORI_DTYPE)
+        self.n_pairs = (len(self._o) - 1) // 2
+        check(lib().psvr_engine_upload(self.h, C.c_int64(self.n_pairs), self._b.ctypes.data_as(C.c_char_p), self._o.ctypes.data_as(C.c_void_p),
+                                       self._r.ctypes.data_as(C.c_void_p)))
+
+    def run(self, trace=False, stats=False, timing=False, stream=None):
+        check(lib().psvr_engine_run(self.h, (1 if trace else 0) | (2 if stats else 0) | (4 if timing else 0), C.c_void_p(stream)))
+
+    def stats(self):
+        buf = C.create_string_buffer(8192)
+        check(lib().psvr_engine_stats(self.h, buf, 8192))
+        return json.loads(buf.value.decode())
+
+    def download(self):
+        P = self.n_pairs
+        used = C.c_int64(0)
+        rc = lib().psvr_engine_download(self.h, None, None, None, C.c_int64(0), C.byref(used))
+        if rc not in (0, 6):
+            check(rc)
+        reads = np.zeros(2 * P, dtype=READ_DTYPE)
+        pairs = np.zeros(P, dtype=PAIR_DTYPE)
+        cig = np.zeros(int(used.value) + 1, dtype=np.uint32)
+        check(lib().psvr_engine_download(self.h, reads.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p),
+                                         C.c_int64(len(cig)), C.byref(used)))
+        return reads, pairs, cig
+
+    def close(self):
+        if self.h:
+            lib().psvr_engine_destroy(self.h)
+            self.h = None

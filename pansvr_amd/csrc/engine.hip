@@ -174,6 +174,34 @@ struct GpuBE {
 	DpParams dpP;
 	bool dp_ready = false;
 
+	// live per-kernel timing with HIP events on the launch stream (bench.py's roofline figure)
+	bool timing = false;
+	struct Ev { const char *name; hipEvent_t a, b; };
+	std::vector<Ev> evs;
+	std::vector<std::pair<std::string, std::pair<double, long long>>> timed;   // name -> (ms, launches)
+	void t0(const char *name)
+	{
+		if (!timing) return;
+		Ev e{name, nullptr, nullptr};
+		note(hipEventCreate(&e.a)), note(hipEventCreate(&e.b));
+		note(hipEventRecord(e.a, stream));
+		evs.push_back(e);
+	}
+	void t1() { if (timing && !evs.empty()) note(hipEventRecord(evs.back().b, stream)); }
+	void collect_timing()
+	{
+		for (Ev &e : evs) {
+			float ms = 0;
+			note(hipEventSynchronize(e.b));
+			note(hipEventElapsedTime(&ms, e.a, e.b));
+			bool found = false;
+			for (auto &t : timed) if (t.first == e.name) { t.second.first += ms, t.second.second++; found = true; break; }
+			if (!found) timed.push_back({e.name, {ms, 1}});
+			(void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
+		}
+		evs.clear();
+	}
+
 	void note(hipError_t e) { if (e != hipSuccess && last == hipSuccess) last = e; }
 	void *dalloc(size_t n) { void *p = nullptr; hipError_t e = hipMalloc(&p, n ? n : 16); note(e); return e == hipSuccess ? p : nullptr; }
 	void dfree(void *p) { if (p) (void)hipFree(p); }
@@ -187,7 +215,7 @@ struct GpuBE {
 #define PSVR_STAGE(name, kern, mult, blk)                                                                          \
 	void name(const Ctx &c, const int32_t *w, long long n)                                                         \
 	{                                                                                                              \
-		if (n > 0) hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n, blk)), dim3(blk), 0, stream, c, w, n);       \
+		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n, blk)), dim3(blk), 0, stream, c, w, n); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
 	PSVR_STAGE(st_prep, k_prep, 2, kBlock)
@@ -201,7 +229,7 @@ struct GpuBE {
 #undef PSVR_STAGE
 	void st_assemble(const Ctx &c, long long b, long long e)
 	{
-		if (e > b) hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b, 64)), dim3(64), 0, stream, c, b, e);
+		if (e > b) { t0("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b, 64)), dim3(64), 0, stream, c, b, e); t1(); }
 		note(hipGetLastError());
 	}
 	void st_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
@@ -273,7 +301,9 @@ struct GpuBE {
 		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 128 * 8, hipMemcpyHostToDevice, stream));
 		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
 		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
+		t0("k_dp_fetch");
 		hipLaunchKernelGGL(k_dp_fetch, dim3((unsigned)n), dim3(64), 0, stream, c, d.begin, (const long long *)d.q_off, (const long long *)d.t_off, d.qbuf, d.tbuf);
+		t1();
 		PSVR_HIP(hipGetLastError());
 		DpBatch B;
 		B.qseq = d.qbuf, B.q_off = (const int64_t *)d.q_off, B.qlen = d.qlen;
@@ -283,6 +313,8 @@ struct GpuBE {
 		for (const Launch3 &L : ls) {
 			B.idx = plan_idx.as<int32_t>() + L.first;
 			dim3 grid((unsigned)L.count), block(64);
+			static const char *knames[6] = {"extd2_lds_kernel<0>", "extd2_reg_kernel<1>", "extd2_reg_kernel<2>", "extd2_reg_kernel<3>", "extd2_reg_kernel<4>", "extd2_reg_kernel<5>"};
+			t0(knames[L.kind]);
 			switch (L.kind) {
 			case 1: hipLaunchKernelGGL(extd2_reg_kernel<1>, grid, block, L.lds, stream, B, dpP); break;
 			case 2: hipLaunchKernelGGL(extd2_reg_kernel<2>, grid, block, L.lds, stream, B, dpP); break;
@@ -296,6 +328,7 @@ struct GpuBE {
 				hipLaunchKernelGGL(extd2_lds_kernel<0>, grid, block, L.lds, stream, G, dpP);
 			}
 			}
+			t1();
 			PSVR_HIP(hipGetLastError());
 		}
 		return PSVR_OK;
@@ -452,9 +485,12 @@ extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
 	if (!e) return set_error(PSVR_ERR_ARG, "psvr_engine_run: null engine");
 	PSVR_HIP(hipSetDevice(e->ix->device));
 	e->be.stream = (hipStream_t)stream;
+	e->be.timing = (trace & 4) != 0;
+	e->be.timed.clear();
 	int rc = e->core.run(trace & 1, (trace & 2) != 0);
 	hipError_t s = hipStreamSynchronize(e->be.stream);
 	if (s != hipSuccess) e->be.note(s);
+	e->be.collect_timing();
 	e->committed = false;       // the rand streams advance when the next batch is uploaded (or on download)
 	return engine_status(e, rc);
 }
@@ -494,5 +530,16 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
 	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
+	std::string t = buf;
+	t.pop_back();
+	t += ",\"kernels\":{";
+	bool first = true;
+	for (auto &k : e->be.timed) {
+		char b[256];
+		snprintf(b, sizeof b, "%s\"%s\":{\"ms\":%.4f,\"launches\":%lld}", first ? "" : ",", k.first.c_str(), k.second.first, k.second.second);
+		t += b, first = false;
+	}
+	t += "}}";
+	snprintf(buf, n, "%s", t.c_str());
 	return PSVR_OK;
 }
