@@ -134,7 +134,7 @@ def main():
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated)" % world,
                                                  "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu,
-                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
+                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)
     eng.close()

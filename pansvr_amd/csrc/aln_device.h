@@ -136,9 +136,13 @@ struct Ctx {
 	// rand streams: rand() and the two per-handler random_r streams (rr.hpp:340)
 	const int32_t *grand; long long grand_n; long long grand_base;
 	const int32_t *hrand[2]; long long hrand_n; long long hrand_base[2];
-	// per pair-item (3 per pair: read1, read2, pairing) draw offsets and counts
-	long long *roff; int32_t *rcnt;
-	long long *hoff; int32_t *hcnt;          // per read: random_r offsets / counts
+	// Work items are SLOTS: slot < n_pairs is a real pair, slot >= n_pairs a shadow evaluation of pair src[slot]
+	// at another rand() offset (engine_core.h).  All per-read state below is indexed by 2*slot + mate.
+	long long n_slots;
+	const int32_t *src;                      // slot -> input pair (nullptr: identity)
+	long long *poff;                         // per slot: rand() stream offset of the pair (mate 0 draws first, then mate 1, then pairing)
+	int32_t *rcnt;                           // per slot x {mate0, mate1, pairing}: draws consumed
+	long long *hoff; int32_t *hcnt;          // per read: random_r offsets / counts (one stream per mate)
 	// per read
 	uint8_t *active; uint8_t *unmapped; uint8_t *is_str;
 	int32_t *read_l;
@@ -170,6 +174,11 @@ PSVR_HD void stat_add(const Ctx &c, int k, unsigned long long v)
 #endif
 }
 
+PSVR_HD long long src_read(const Ctx &c, long long read)
+{
+	return c.src ? (long long)c.src[read >> 1] * 2 + (read & 1) : read;
+}
+
 PSVR_HD uint64_t fnv1a(uint64_t h, uint64_t v)
 {
 	for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ULL; }
@@ -197,8 +206,9 @@ PSVR_HD int base_at(const uint64_t *w, uint64_t i) { return (int)((w[i >> 5] >> 
 // ---------------------------------------------------------------------------------------------
 PSVR_HDN inline void prep_read(const Ctx &c, long long read)
 {
-	const psvr_ori_t &o = c.ori[read];
-	const int L = (int)(c.base_off[read + 1] - c.base_off[read]);
+	const long long sr = src_read(c, read);
+	const psvr_ori_t &o = c.ori[sr];
+	const int L = (int)(c.base_off[sr + 1] - c.base_off[sr]);
 	c.read_l[read] = L;
 	bool unm = o.unmapped != 0;
 	if ((uint32_t)o.chr_id > 24u) unm = true;                          // rr.cpp:413
@@ -212,11 +222,12 @@ PSVR_HDN inline void prep_read(const Ctx &c, long long read)
 	if (L > kMaxReadLen || L < kLenKmer) { c.active[read] = 0; if (L > kMaxReadLen) *c.err = 1; return; }
 	if (!unm && o.align_score == (uint32_t)(L * c.par.match)) { c.active[read] = 0; return; }   // rr.cpp:414
 	c.active[read] = 1;
-	const char *s = c.bases + c.base_off[read];
+	const char *s = c.bases + c.base_off[sr];
 	uint8_t *b0 = c.bin + (read * 2) * (long long)c.lmax, *b1 = b0 + c.lmax;
 	uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
 	for (int i = 0; i < c.wmax; ++i) w0[i] = 0, w1[i] = 0;
-	long long ro = c.roff[item];
+	// mate 1 draws after mate 0 of the same pair (mate 0's stages have completed: engine_core.h runs the mates in turn)
+	long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0);
 	int draws = 0;
 	for (int i = 0; i < L; ++i) {
 		char ch = s[i];
@@ -642,7 +653,7 @@ PSVR_HDN inline void select_read(const Ctx &c, long long read)
 {
 	if (!c.active[read]) return;
 	const long long item = (read >> 1) * 3 + (read & 1);
-	const long long ro = c.roff[item] + c.rcnt[item];   // after the N draws of prep_read
+	const long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0) + c.rcnt[item];   // after the N draws of prep_read
 	int draws = 0;
 	ChainCand *cc = c.ccand + read * 12;
 	int n = 0;
@@ -960,7 +971,7 @@ PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i)
 		p.align_score = d.align_score, p.chr_id = (uint32_t)d.chr_id, p.ref_bg = d.ref_bg, p.direction = d.direction, p.is_ori = 0, p.sv_id = d.sv_id;
 		p.end_offset = c.idx.sv[d.sv_id].end_offset;
 	} else {
-		const psvr_ori_t &o = c.ori[read];
+		const psvr_ori_t &o = c.ori[src_read(c, read)];
 		p.align_score = o.align_score, p.chr_id = (uint32_t)o.chr_id, p.ref_bg = o.ref_bg >= 0x7fffffffu ? 1u : o.ref_bg, p.direction = o.direction, p.is_ori = 1, p.sv_id = -1, p.end_offset = 0;
 	}
 	return p;
@@ -974,7 +985,7 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 		psvr_read_result_t &rr = c.res[r0 + e];
 		rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
 	}
-	const long long ro = c.roff[item];
+	const long long ro = c.poff[pair] + c.rcnt[pair * 3] + c.rcnt[pair * 3 + 1];
 	int draws = 0;
 	const int max_isize = c.par.isize_max + 200;
 	int min_isize = c.par.isize_min - 200;
@@ -1059,14 +1070,14 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 }
 
 // which pairs consumed draws from an offset that the scan of the actual draw counts has since moved?
-// Also adopts the new offsets.  (engine_core.h, "rand() order")
+// Also adopts the new offsets.  (engine_core.h, "rand() order")  Real pairs only.
 PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, const long long *nhoff)
 {
-	int dirty = 0;                   // 0 clean, 1 only the pairing stage drew from a stale offset, 2 a read did
-	for (int k = 0; k < 3; ++k) {
-		long long i = pair * 3 + k;
-		if (c.rcnt[i] > 0 && c.roff[i] != noff[i]) dirty = k == 2 ? (dirty > 1 ? dirty : 1) : 2;
-		c.roff[i] = noff[i];
+	int dirty = 0;                   // 0 clean, 1 only the pairing stage must be repeated, 2 the whole pair
+	if (c.poff[pair] != noff[pair]) {
+		if (c.rcnt[pair * 3] > 0 || c.rcnt[pair * 3 + 1] > 0) dirty = 2;
+		else if (c.rcnt[pair * 3 + 2] > 0) dirty = 1;
+		c.poff[pair] = noff[pair];
 	}
 	for (int k = 0; k < 2; ++k) {
 		long long r = pair * 2 + k;

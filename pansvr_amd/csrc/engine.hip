@@ -20,33 +20,77 @@ static inline unsigned grid_for(long long n, int block = kBlock) { return (unsig
 
 __device__ __forceinline__ long long pair_of(const int32_t *work, long long i) { return work ? (long long)work[i] : i; }
 
-// ---- stage kernels: one thread per item -------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n)
+// ---- stage kernels: one thread per item; the read-level stages run per mate ------------------------
+__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < 2 * n) prep_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+	if (i < n) prep_read(c, pair_of(work, i) * 2 + mate);
 }
-__global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *work, long long n)
+
+// STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are staged in LDS and every lane
+// counts the equals of its own k-mers against all of them (LDS broadcast reads) -- same result as the
+// per-read std::map of the reference / str_detect() in aln_device.h, without its O(n^2) per thread.
+__global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *work, long long n, int mate, int kmax)
 {
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < 2 * n) str_detect(c, pair_of(work, i >> 1) * 2 + (i & 1));
+	extern __shared__ __align__(16) uint8_t str_lds[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
+	if (wi >= n) return;
+	const long long read = pair_of(work, wi) * 2 + mate;
+	if (!c.active[read]) return;
+	uint64_t *km = (uint64_t *)(str_lds + (size_t)wave * ((size_t)kmax * 9 + 16));
+	uint8_t *sl = (uint8_t *)(km + kmax);
+	const int L = c.read_l[read];
+	const uint64_t *rb = c.rb + (read * 2) * (long long)c.wmax;
+	const int kn = L - kLenKmer + 1;
+	for (int i = lane; i < kn; i += 64) km[i] = get_kmer((uint32_t)i, rb);
+	int distinct = 0;
+	for (int i0 = 0; i0 < kn; i0 += 64) {
+		const int i = i0 + lane;
+		const uint64_t mine = i < kn ? km[i] : 0;
+		int cnt = 0, earlier = 0;
+		for (int j = 0; j < kn; ++j) {
+			const bool eq = km[j] == mine;
+			cnt += eq, earlier += eq && j < i;
+		}
+		if (i < kn) sl[i] = cnt >= 4 ? 0 : 1;
+		distinct += __popcll(__ballot(i < kn && earlier == 0));
+	}
+	if (!((uint32_t)distinct < (uint32_t)kn - 15u)) { if (lane == 0) c.is_str[read] = 0; return; }
+	if (lane == 0) {
+		c.is_str[read] = 1;
+		int bg = 0, ed = 0;
+		for (int o = 0; o < kSeedStep; ++o) {
+			bg += sl[o] == 0, ed += sl[L - kLenKmer - o] == 0;
+			sl[o] += 2, sl[L - kLenKmer - o] += 4;
+		}
+		if (bg < kSeedStep && ed < kSeedStep) {
+			int tot = 0;
+			for (int o = 0; tot < kSeedStep && o < kn; ++o) {
+				if (sl[o] > 0) continue;
+				sl[o] += 8, tot++;
+			}
+		}
+	}
+	uint8_t *out = c.seed_list + read * (long long)c.lmax;
+	for (int i = lane; i < kn; i += 64) out[i] = sl[i];
 }
 // K1 seed_probe + K2 mem_extend: hash gather, bucket search, unipath lookup, MEM extension
-__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n)
+__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n, int mate)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < 4 * n) seed_strand(c, pair_of(work, i >> 2) * 4 + (i & 3));
+	if (i < 2 * n) seed_strand(c, (pair_of(work, i >> 1) * 2 + mate) * 2 + (i & 1));
 }
 // K3 chain: merge, expand, sort, sparse chaining DP
-__global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *work, long long n)
+__global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *work, long long n, int mate)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < 2 * n) chain_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+	if (i < n) chain_read(c, pair_of(work, i) * 2 + mate);
 }
-__global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *work, long long n)
+__global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *work, long long n, int mate)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < 2 * n) select_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+	if (i < n) select_read(c, pair_of(work, i) * 2 + mate);
 }
 __global__ __launch_bounds__(64) void k_walk(Ctx c, const int32_t *work, long long n)
 {
@@ -84,6 +128,43 @@ __global__ void k_fill_i64(long long *p, long long n, int stride, int off, long 
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) p[off + i * stride] = v;
+}
+
+__global__ void k_iota(int32_t *w, long long at, long long start, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) w[at + i] = (int32_t)(start + i);
+}
+__global__ void k_gather_i64(const long long *a, const int32_t *idx, long long n, long long *out)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) out[i] = a[idx[i]];
+}
+__global__ void k_gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) out[i] = a[idx[i]];
+}
+__global__ void k_scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) a[idx[i]] = val[i];
+}
+__global__ void k_hoff_shadows(Ctx c, long long P, long long n)
+{
+	long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	for (int k = 0; k < 2; ++k) c.hoff[2 * (P + j) + k] = c.hoff[2 * (long long)c.src[P + j] + k];
+}
+// total draws of the evaluated slots; a real pair whose total changed since its previous evaluation is count-sensitive
+__global__ void k_totals(Ctx c, const int32_t *work, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, int detect)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	long long s = pair_of(work, i);
+	int32_t t = c.rcnt[3 * s] + c.rcnt[3 * s + 1] + c.rcnt[3 * s + 2];
+	if (detect && s < c.n_pairs && t != ctot[s] && !sens[s]) { sens[s] = 1; slist[atomicAdd(cnt, 1ull)] = (int32_t)s; }
+	ctot[s] = t;
 }
 
 // exclusive scan of int32 counts into int64 offsets; one 1024-thread workgroup walks the array in tiles
@@ -212,21 +293,69 @@ struct GpuBE {
 	{
 		if (n) hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, stride, off, v);
 	}
+#define PSVR_STAGE_M(name, kern, mult)                                                                             \
+	void name(const Ctx &c, const int32_t *w, long long n, int mate)                                               \
+	{                                                                                                              \
+		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n)), dim3(kBlock), 0, stream, c, w, n, mate); t1(); } \
+		note(hipGetLastError());                                                                                   \
+	}
+	PSVR_STAGE_M(st_prep, k_prep, 1)
+	PSVR_STAGE_M(st_seed, k_seed, 2)
+	PSVR_STAGE_M(st_chain, k_chain, 1)
+	PSVR_STAGE_M(st_select, k_select, 1)
+#undef PSVR_STAGE_M
+	void st_str(const Ctx &c, const int32_t *w, long long n, int mate)
+	{
+		if (n <= 0) return;
+		const int kmax = c.lmax;                                  // >= L - 19 k-mers
+		const size_t lds = (size_t)(kBlock / 64) * ((size_t)kmax * 9 + 16);
+		t0("k_str_detect");
+		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), lds, stream, c, w, n, mate, kmax);
+		t1();
+		note(hipGetLastError());
+	}
 #define PSVR_STAGE(name, kern, mult, blk)                                                                          \
 	void name(const Ctx &c, const int32_t *w, long long n)                                                         \
 	{                                                                                                              \
 		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n, blk)), dim3(blk), 0, stream, c, w, n); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
-	PSVR_STAGE(st_prep, k_prep, 2, kBlock)
-	PSVR_STAGE(st_str, k_str_detect, 2, kBlock)
-	PSVR_STAGE(st_seed, k_seed, 4, kBlock)
-	PSVR_STAGE(st_chain, k_chain, 2, kBlock)
-	PSVR_STAGE(st_select, k_select, 2, kBlock)
 	PSVR_STAGE(st_walk, k_walk, 24, 64)
 	PSVR_STAGE(st_finalize, k_finalize, 2, kBlock)
 	PSVR_STAGE(st_pair, k_pair, 1, kBlock)
 #undef PSVR_STAGE
+	DevBuf tmp_idx, tmp_val, tmp_out;
+	void fill_iota(int32_t *p, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, 0ll, 0ll, n); }
+	void append_iota(int32_t *w, long long at, long long start, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, start, n); }
+	void gather_i64(const long long *a, const int32_t *idx, long long n, long long *out)
+	{
+		if (!n) return;
+		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 8));
+		h2d(tmp_idx.p, idx, n * 4);
+		hipLaunchKernelGGL(k_gather_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
+		d2h(out, tmp_out.p, n * 8);
+	}
+	void gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out)
+	{
+		if (!n) return;
+		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 8));
+		h2d(tmp_idx.p, idx, n * 4);
+		hipLaunchKernelGGL(k_gather_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, (int32_t *)tmp_out.p);
+		d2h(out, tmp_out.p, n * 4);
+	}
+	void scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n)
+	{
+		if (!n) return;
+		note(tmp_idx.ensure(n * 4)), note(tmp_val.ensure(n * 4));
+		h2d(tmp_idx.p, idx, n * 4), h2d(tmp_val.p, val, n * 4);
+		hipLaunchKernelGGL(k_scatter_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n);
+	}
+	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n) { if (n) hipLaunchKernelGGL(k_hoff_shadows, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, P, n); }
+	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
+	{
+		if (n > 0) hipLaunchKernelGGL(k_totals, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, ctot, sens, slist, cnt, detect ? 1 : 0);
+		note(hipGetLastError());
+	}
 	void st_assemble(const Ctx &c, long long b, long long e)
 	{
 		if (e > b) { t0("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b, 64)), dim3(64), 0, stream, c, b, e); t1(); }
@@ -526,9 +655,9 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
 	const RunStats &s = e->core.stats;
 	snprintf(buf, n,
-	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
-	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();

@@ -6,16 +6,23 @@
 //
 // rand() order: the reference consumes one process-wide rand() stream in input order
 // (N-base substitution, tied chains, tied pair scores) plus one random_r stream per handler
-// (expand_seed sampling).  The streams are precomputed tables in HBM; every pair gets its stream
-// offsets from an exclusive scan of per-item draw counts.  Counts are only known after a pair ran, so
-// the batch runs speculatively: run all pairs with guessed offsets, scan the counts, re-run exactly
-// those pairs that drew from a wrong offset, repeat until no pair is dirty.  The first dirty pair of
-// every round is final afterwards, so the loop terminates; in practice it takes 2-3 rounds over
-// ~1 % of the pairs.
+// (expand_seed sampling).  The streams are precomputed tables in HBM.  A pair is the atomic unit: its
+// mate 0 runs prep..select first, mate 1 starts where mate 0 stopped, the pairing stage where mate 1
+// stopped, so the draws D_p of pair p are a pure function of its stream offset O_p, and
+// O_{p+1} = O_p + D_p(O_p).  D_p is almost always independent of O_p, so the batch runs speculatively:
+//   1. run every pair at a guessed offset, scan the counts into offsets, re-run the pairs that drew from
+//      a stale offset (most of them only need the pairing stage again);
+//   2. pairs whose count CHANGED between two evaluations are "sensitive" (~0.1 %: e.g. a substituted N
+//      base that decides whether two pair scores tie).  They form a serial chain that would cost one
+//      round per flip; instead each sensitive pair is evaluated at a WINDOW of offsets in the same round
+//      (shadow slots), and the chain O_{s+1} = O_s + D_s(O_s) is walked on the host through those tables;
+//   3. repeat until no pair is dirty (a handful of rounds).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "aln_device.h"
@@ -67,7 +74,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 };
 
 struct RunStats {
-	long long rounds = 0, pairs_run = 0, pair_only = 0, dp_problems = 0, cands = 0;
+	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0;
 	unsigned long long counters[16] = {0};
 };
 
@@ -83,7 +90,12 @@ template <class BE> struct EngineCore {
 	// device buffers owned here
 	std::vector<void *> owned;
 	long long *d_noff = nullptr, *d_nhoff = nullptr;
-	int32_t *d_work = nullptr, *d_work2 = nullptr, *d_workp = nullptr;   // full re-run lists (ping-pong) and the pair-stage-only list
+	int32_t *d_work = nullptr, *d_workp = nullptr;   // full re-run list (real pairs then shadow slots) and the pairing-only list
+	int32_t *d_ctot = nullptr, *d_src = nullptr;     // per slot: total draws of the last evaluation; slot -> input pair
+	uint8_t *d_sens = nullptr;                       // per pair: known count-sensitive
+	int32_t *d_slist = nullptr;                      // newly detected sensitive pairs
+	long long S = 0;                                 // slots = P real pairs + shadow capacity
+	static const int kWin = 32;                      // offsets evaluated per sensitive pair and round
 	unsigned long long *d_tops = nullptr;     // [8] arena tops + dirty count
 	int32_t *d_flags = nullptr;               // [8] overflow flags + err
 	unsigned long long cap_mem = 0, cap_us = 0, cap_seg = 0, cap_dp = 0, cap_cw = 0, cap_cig = 0;
@@ -174,24 +186,30 @@ template <class BE> struct EngineCore {
 		char *d_bases = alloc<char>(total_bases + 16);
 		long long *d_off = alloc<long long>(R + 1);
 		psvr_ori_t *d_ori = alloc<psvr_ori_t>(R);
-		c.roff = alloc<long long>(3 * P), c.rcnt = alloc<int32_t>(3 * P), d_noff = alloc<long long>(3 * P);
-		c.hoff = alloc<long long>(R), c.hcnt = alloc<int32_t>(R), d_nhoff = alloc<long long>(R);
-		c.active = alloc<uint8_t>(R), c.unmapped = alloc<uint8_t>(R), c.is_str = alloc<uint8_t>(R);
-		c.read_l = alloc<int32_t>(R);
-		c.bin = alloc<uint8_t>((unsigned long long)R * 2 * c.lmax);
-		c.rb = alloc<uint64_t>((unsigned long long)R * 2 * c.wmax);
-		c.seed_list = alloc<uint8_t>((unsigned long long)R * c.lmax);
-		c.strand = alloc<Strand>(2 * R);
-		c.ccand = alloc<ChainCand>(12 * R), c.n_ccand = alloc<int32_t>(R);
-		c.res = alloc<psvr_read_result_t>(R), c.pres = alloc<psvr_pair_result_t>(P);
-		d_work = alloc<int32_t>(P), d_work2 = alloc<int32_t>(P), d_workp = alloc<int32_t>(P);
-		d_tops = alloc<unsigned long long>(8), d_flags = alloc<int32_t>(8);
-		cap_mem = (unsigned long long)2 * R * kMemSlot + (unsigned long long)R * 16 + 4096;
-		cap_us = (unsigned long long)R * 48 + 65536;
-		cap_cw = (unsigned long long)R * 3 + 1024;
+		const long long shadow_cap = P / 8 + 4096;
+		S = P + shadow_cap;
+		const long long RS = 2 * S;                                 // reads incl. shadow slots
+		c.n_slots = S;
+		c.poff = alloc<long long>(S), c.rcnt = alloc<int32_t>(3 * S), d_noff = alloc<long long>(S);
+		c.hoff = alloc<long long>(RS), c.hcnt = alloc<int32_t>(RS), d_nhoff = alloc<long long>(RS);
+		c.active = alloc<uint8_t>(RS), c.unmapped = alloc<uint8_t>(RS), c.is_str = alloc<uint8_t>(RS);
+		c.read_l = alloc<int32_t>(RS);
+		c.bin = alloc<uint8_t>((unsigned long long)RS * 2 * c.lmax);
+		c.rb = alloc<uint64_t>((unsigned long long)RS * 2 * c.wmax);
+		c.seed_list = alloc<uint8_t>((unsigned long long)RS * c.lmax);
+		c.strand = alloc<Strand>(2 * RS);
+		c.ccand = alloc<ChainCand>(12 * RS), c.n_ccand = alloc<int32_t>(RS);
+		c.res = alloc<psvr_read_result_t>(RS), c.pres = alloc<psvr_pair_result_t>(S);
+		d_work = alloc<int32_t>(S), d_workp = alloc<int32_t>(P);
+		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
+		d_tops = alloc<unsigned long long>(16), d_flags = alloc<int32_t>(8);
+		const long long R2 = RS;
+		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
+		cap_us = (unsigned long long)R2 * 48 + 65536;
+		cap_cw = (unsigned long long)R2 * 3 + 1024;
 		cap_seg = cap_cw * 12;
-		cap_dp = (unsigned long long)R * 4 + 1024;
-		cap_cig = (unsigned long long)R * 48 + 4096;
+		cap_dp = (unsigned long long)R2 * 4 + 1024;
+		cap_cig = (unsigned long long)R2 * 48 + 4096;
 		c.stats = alloc<unsigned long long>(16);
 		for (void *p : owned) if (!p) { err = "device allocation failed"; return PSVR_ERR_NOMEM; }
 		free_arenas();
@@ -226,7 +244,7 @@ template <class BE> struct EngineCore {
 		if (depth > 8) { err = "scratch arena overflow persists after 8 growth steps"; return PSVR_ERR_OVERFLOW; }
 		unsigned long long *caps[6] = {&cap_mem, &cap_us, &cap_seg, &cap_dp, &cap_cw, &cap_cig};
 		for (int k = 0; k < 6; ++k) if (flags[k]) *caps[k] *= 4;
-		if (flags[0]) cap_mem += (unsigned long long)2 * R * kMemSlot;
+		if (flags[0]) cap_mem += (unsigned long long)4 * S * kMemSlot;
 		fprintf(stderr, "[psvr] scratch arena overflow (mem %d us %d seg %d dp %d cand %d cigar %d): growing 4x and re-running the batch\n", flags[0], flags[1], flags[2], flags[3],
 		        flags[4], flags[5]);
 		free_arenas();
@@ -257,6 +275,37 @@ template <class BE> struct EngineCore {
 		return ok;
 	}
 
+	// the stages of one round over a list of slots: mate 0, then mate 1 (continues mate 0's draws), then the
+	// candidate / DP / pairing stages
+	int run_slots(const int32_t *work, long long nwork, long long &dp_done, long long &cw_done)
+	{
+		if (nwork <= 0) return PSVR_OK;
+		for (int mate = 0; mate < 2; ++mate) {
+			be.st_prep(c, work, nwork, mate);
+			be.st_str(c, work, nwork, mate);
+			be.st_seed(c, work, nwork, mate);
+			be.st_chain(c, work, nwork, mate);
+			be.st_select(c, work, nwork, mate);
+		}
+		be.st_walk(c, work, nwork);
+		unsigned long long tops[8];
+		be.d2h(tops, d_tops, 64);
+		long long dp_end = (long long)tops[3], cw_end = (long long)tops[4];
+		if (dp_end > (long long)cap_dp || cw_end > (long long)cap_cw) return -1000 - (dp_end > (long long)cap_dp ? 1 : 0) - (cw_end > (long long)cap_cw ? 2 : 0);
+		if (dp_end > dp_done) {
+			dp.begin = dp_done, dp.end = dp_end;
+			int rc = be.st_dp(*this);
+			if (rc) return rc;
+		}
+		c.dp_ez = dp.ez ? dp.ez - dp_done : nullptr, c.dp_cig = dp.cig;   // DP ids are absolute, the result buffers are per round
+		if (cw_end > cw_done) be.st_assemble(c, cw_done, cw_end);
+		stats.dp_problems += dp_end - dp_done, stats.cands += cw_end - cw_done;
+		dp_done = dp_end, cw_done = cw_end;
+		be.st_finalize(c, work, nwork);
+		be.st_pair(c, work, nwork);
+		return PSVR_OK;
+	}
+
 	// ---- one full run of the uploaded batch (rand state is NOT advanced: call commit() for that)
 	int run(int trace, bool want_stats, int depth = 0)
 	{
@@ -265,58 +314,85 @@ template <class BE> struct EngineCore {
 		if (P == 0) return PSVR_OK;
 		unsigned long long *stats_ptr = c.stats;
 		if (!want_stats) c.stats = nullptr;
-		be.dzero(d_tops, 8 * 8), be.dzero(d_flags, 8 * 4), be.dzero(stats_ptr, 16 * 8);
-		unsigned long long mem0 = (unsigned long long)2 * R * kMemSlot;   // bump region starts behind the per-strand slots
+		be.dzero(d_tops, 16 * 8), be.dzero(d_flags, 8 * 4), be.dzero(stats_ptr, 16 * 8);
+		unsigned long long mem0 = (unsigned long long)4 * S * kMemSlot;   // bump region starts behind the per-strand slots
 		be.h2d(c.mem.top, &mem0, 8);
-		// initial guess: nobody draws.  roff = stream position at batch start, hoff likewise
 		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
-		be.fill_i64(c.roff, 3 * P, 1, 0, grand_pos);
-		be.fill_i64(c.hoff, P, 2, 0, hrand_pos[0]);
-		be.fill_i64(c.hoff, P, 2, 1, hrand_pos[1]);
-		be.dzero(c.rcnt, 3 * P * 4), be.dzero(c.hcnt, R * 4);
-		long long nwork = P, npair_only = 0;
-		const int32_t *work = nullptr;                 // nullptr = identity list
+		// initial guess: nobody draws
+		be.fill_i64(c.poff, S, 1, 0, grand_pos);
+		be.fill_i64(c.hoff, S, 2, 0, hrand_pos[0]);
+		be.fill_i64(c.hoff, S, 2, 1, hrand_pos[1]);
+		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_sens, P);
+		be.fill_iota(d_src, S);
+		c.src = d_src;
 		long long dp_done = 0, cw_done = 0;
 		int rc = PSVR_OK;
+		std::vector<int32_t> sens;                      // sensitive pairs, ascending
+		std::vector<long long> sens_est;                // offset each was last evaluated at
+		std::vector<int32_t> sens_used;                 // count that the last scan assumed for it
+		long long nfull = P, npair_only = 0, nshadow = 0;
+		const int32_t *work = nullptr;                  // nullptr = identity list (first round: every real pair)
+		std::vector<int32_t> sh_src; std::vector<long long> sh_off;
 		for (;;) {
-			stats.rounds++, stats.pairs_run += nwork;
-			be.st_prep(c, work, nwork);
-			be.st_str(c, work, nwork);
-			be.st_seed(c, work, nwork);
-			be.st_chain(c, work, nwork);
-			be.st_select(c, work, nwork);
-			be.st_walk(c, work, nwork);
-			unsigned long long tops[8];
-			be.d2h(tops, d_tops, 64);
-			long long dp_end = (long long)tops[3], cw_end = (long long)tops[4];
-			if (dp_end > (long long)cap_dp || cw_end > (long long)cap_cw) {
-				int32_t fl[8] = {0, 0, 0, dp_end > (long long)cap_dp, cw_end > (long long)cap_cw, 0, 0, 0};
+			stats.rounds++, stats.pairs_run += nfull, stats.shadow_runs += nshadow, stats.pair_only += npair_only;
+			rc = run_slots(work, nfull + nshadow, dp_done, cw_done);
+			if (rc <= -1000) {
+				int32_t fl[8] = {0, 0, 0, ((-rc - 1000) & 1), ((-rc - 1000) & 2) >> 1, 0, 0, 0};
 				c.stats = stats_ptr;
 				return grow_and_rerun(fl, trace, want_stats, depth);
 			}
-			if (dp_end > dp_done) {
-				dp.begin = dp_done, dp.end = dp_end;
-				rc = be.st_dp(*this);
-				if (rc) break;
+			if (rc) break;
+			if (npair_only) be.st_pair(c, d_workp, npair_only);
+			// totals of the evaluated slots; real pairs whose total changed since their previous evaluation are sensitive
+			be.dzero(d_tops + 8, 8);
+			be.st_totals(c, work, nfull + nshadow, d_ctot, d_sens, d_slist, d_tops + 8, stats.rounds > 1);
+			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_sens, d_slist, d_tops + 8, true);
+			unsigned long long nnew = 0;
+			be.d2h(&nnew, d_tops + 8, 8);
+			if (nnew) {
+				std::vector<int32_t> add(nnew);
+				be.d2h(add.data(), d_slist, nnew * 4);
+				sens.insert(sens.end(), add.begin(), add.end());
+				std::sort(sens.begin(), sens.end());
+				sens.erase(std::unique(sens.begin(), sens.end()), sens.end());
+				stats.sensitive = (long long)sens.size();
 			}
-			c.dp_ez = dp.ez ? dp.ez - dp_done : nullptr, c.dp_cig = dp.cig;   // DP ids are absolute, the result buffers are per round
-			if (cw_end > cw_done) be.st_assemble(c, cw_done, cw_end);
-			stats.dp_problems += dp_end - dp_done, stats.cands += cw_end - cw_done;
-			dp_done = dp_end, cw_done = cw_end;
-			be.st_finalize(c, work, nwork);
-			be.st_pair(c, work, nwork);
-			if (npair_only) be.st_pair(c, d_workp, npair_only), stats.pair_only += npair_only;
-			// new offsets from the draw counts; which pairs drew from a stale offset?
-			be.st_scan(c.rcnt, 3 * P, 1, 0, grand_pos, d_noff);
+			// walk the chain of sensitive pairs through the offset windows evaluated this round
+			if (nshadow > 0) {
+				std::vector<int32_t> tot(nshadow);
+				be.d2h(tot.data(), d_ctot + P, nshadow * 4);
+				std::vector<int32_t> real_tot(sens_est.size());
+				be.gather_i32(d_ctot, sens_used_idx.data(), (long long)sens_used_idx.size(), real_tot.data());
+				// D_s is known at est (the real slot) and at the shadow offsets; the true offset of s is est + the drift
+				// accumulated from the sensitive pairs before it
+				long long shift = 0;
+				size_t sh = 0;
+				std::vector<int32_t> res_idx, res_val;
+				for (size_t i = 0; i < sens_used_idx.size(); ++i) {
+					const int32_t s = sens_used_idx[i];
+					const long long est = sens_est[i], t = est + shift;
+					int32_t d_at = real_tot[i];
+					long long best_dist = std::llabs(t - est);
+					while (sh < sh_src.size() && sh_src[sh] == s) {
+						long long dist = std::llabs(sh_off[sh] - t);
+						if (dist < best_dist) best_dist = dist, d_at = tot[sh];
+						++sh;
+					}
+					if (best_dist != 0) stats.window_miss++;
+					shift += (long long)d_at - sens_used[i];
+					res_idx.push_back(s), res_val.push_back(d_at);
+				}
+				be.scatter_i32(d_ctot, res_idx.data(), res_val.data(), (long long)res_idx.size());
+			}
+			// new offsets from the totals; which pairs drew from a stale offset?
+			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
 			be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);
 			be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
 			be.dzero(d_tops + 6, 16);
-			be.st_dirty(c, d_noff, d_nhoff, d_work2, d_tops + 6, d_workp, d_tops + 7);
+			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 6, d_workp, d_tops + 7);
 			unsigned long long nd[2] = {0, 0};
 			int32_t flags[8];
 			be.d2h(nd, d_tops + 6, 16);
-			const unsigned long long ndirty = nd[0];
-			npair_only = (long long)nd[1];
 			be.d2h(flags, d_flags, 32);
 			if (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5]) { c.stats = stats_ptr; return grow_and_rerun(flags, trace, want_stats, depth); }
 			if (flags[6] == 2 || flags[6] == 3) {      // a rand table ran out: extend and restart the batch
@@ -327,32 +403,56 @@ template <class BE> struct EngineCore {
 				return run(trace, want_stats, depth);
 			}
 			if (flags[6]) { char b[128]; snprintf(b, sizeof b, "device stage error %d (the reference would abort here)", flags[6]); err = b; rc = PSVR_ERR_UNSUPPORTED; break; }
-			if (ndirty == 0 && npair_only == 0) break;
-			int32_t *t = d_work; d_work = d_work2; d_work2 = t;
-			work = d_work, nwork = (long long)ndirty;
+			nfull = (long long)nd[0], npair_only = (long long)nd[1], nshadow = 0;
+			if (nfull == 0 && npair_only == 0) break;
+			if (stats.rounds > 200) { err = "rand()-order resolution did not converge in 200 rounds"; rc = PSVR_ERR_UNSUPPORTED; break; }
+			work = d_work;
+			// shadow evaluations: every sensitive pair at kWin offsets around its new estimate
+			sens_used_idx.clear(), sens_est.clear(), sens_used.clear(), sh_src.clear(), sh_off.clear();
+			if (!sens.empty()) {
+				std::vector<long long> est(sens.size());
+				std::vector<int32_t> used(sens.size());
+				be.gather_i64(c.poff, sens.data(), (long long)sens.size(), est.data());
+				be.gather_i32(d_ctot, sens.data(), (long long)sens.size(), used.data());
+				const long long cap = S - P;
+				for (size_t i = 0; i < sens.size(); ++i) {
+					sens_used_idx.push_back(sens[i]), sens_est.push_back(est[i]), sens_used.push_back(used[i]);
+					if ((long long)sh_src.size() + kWin - 1 > cap) continue;
+					for (int k = -kWin / 2; k < kWin / 2; ++k) {
+						if (k == 0 || est[i] + k < grand_pos) continue;
+						sh_src.push_back(sens[i]), sh_off.push_back(est[i] + k);
+					}
+				}
+				nshadow = (long long)sh_src.size();
+				if (nshadow) {
+					be.h2d(d_src + P, sh_src.data(), nshadow * 4);
+					be.h2d(c.poff + P, sh_off.data(), nshadow * 8);
+					be.copy_hoff_to_shadows(c, P, nshadow);
+					be.append_iota(d_work, nfull, P, nshadow);      // work list: dirty real pairs, then the shadow slots
+				}
+			}
 		}
 		c.stats = stats_ptr;
 		if (rc == PSVR_OK && want_stats) be.d2h(stats.counters, stats_ptr, 16 * 8);
 		return rc;
 	}
+	std::vector<int32_t> sens_used_idx;
 
 	// advance the rand streams past this batch (the reference's generators keep running across batches)
 	void commit()
 	{
 		if (P == 0) return;
-		long long last[3];
-		int32_t lc;
-		be.d2h(&last[0], c.roff + (3 * P - 1), 8);
-		be.d2h(&lc, c.rcnt + (3 * P - 1), 4);
-		long long new_g = last[0] + lc;
+		long long lo; int32_t lc;
+		be.d2h(&lo, c.poff + (P - 1), 8);
+		be.d2h(&lc, d_ctot + (P - 1), 4);
 		long long hp[2];
 		for (int k = 0; k < 2; ++k) {
 			long long ho; int32_t hc;
-			be.d2h(&ho, c.hoff + (R - 2 + k), 8);
-			be.d2h(&hc, c.hcnt + (R - 2 + k), 4);
+			be.d2h(&ho, c.hoff + (2 * (P - 1) + k), 8);
+			be.d2h(&hc, c.hcnt + (2 * (P - 1) + k), 4);
 			hp[k] = ho + hc;
 		}
-		grand_pos = new_g, hrand_pos[0] = hp[0], hrand_pos[1] = hp[1];
+		grand_pos = lo + lc, hrand_pos[0] = hp[0], hrand_pos[1] = hp[1];
 		grand_dev_n = hrand_dev_n = 0;          // tables are relative to the stream position: refresh on next run
 	}
 };

@@ -26,17 +26,35 @@ struct CpuBE {
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
 	void fill_i64(long long *p, long long n, int stride, int off, long long v) { for (long long i = 0; i < n; ++i) p[off + i * stride] = v; }
 	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
-	void st_prep(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) prep_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
-	void st_str(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) str_detect(c, pr(w, i >> 1) * 2 + (i & 1)); }
-	void st_seed(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 4 * n; ++i) seed_strand(c, pr(w, i >> 2) * 4 + (i & 3)); }
-	void st_chain(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) chain_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
-	void st_select(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) select_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
+	void fill_iota(int32_t *p, long long n) { for (long long i = 0; i < n; ++i) p[i] = (int32_t)i; }
+	void append_iota(int32_t *w, long long at, long long start, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = (int32_t)(start + i); }
+	void gather_i64(const long long *a, const int32_t *idx, long long n, long long *out) { for (long long i = 0; i < n; ++i) out[i] = a[idx[i]]; }
+	void gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out) { for (long long i = 0; i < n; ++i) out[i] = a[idx[i]]; }
+	void scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n) { for (long long i = 0; i < n; ++i) a[idx[i]] = val[i]; }
+	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n)
+	{
+		for (long long j = 0; j < n; ++j) for (int k = 0; k < 2; ++k) c.hoff[2 * (P + j) + k] = c.hoff[2 * (long long)c.src[P + j] + k];
+	}
+	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) prep_read(c, pr(w, i) * 2 + mate); }
+	void st_str(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) str_detect(c, pr(w, i) * 2 + mate); }
+	void st_seed(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < 2 * n; ++i) seed_strand(c, (pr(w, i >> 1) * 2 + mate) * 2 + (i & 1)); }
+	void st_chain(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) chain_read(c, pr(w, i) * 2 + mate); }
+	void st_select(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) select_read(c, pr(w, i) * 2 + mate); }
 	void st_walk(const Ctx &c, const int32_t *w, long long n)
 	{
 		for (long long i = 0; i < 2 * n; ++i) {
 			long long r = pr(w, i >> 1) * 2 + (i & 1);
 			if (!c.active[r]) continue;
 			for (int k = 0; k < c.n_ccand[r]; ++k) walk_candidate(c, r, k);
+		}
+	}
+	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
+	{
+		for (long long i = 0; i < n; ++i) {
+			long long s = pr(w, i);
+			int32_t t = c.rcnt[3 * s] + c.rcnt[3 * s + 1] + c.rcnt[3 * s + 2];
+			if (detect && s < c.n_pairs && t != ctot[s] && !sens[s]) sens[s] = 1, slist[(*cnt)++] = (int32_t)s;
+			ctot[s] = t;
 		}
 	}
 	void st_assemble(const Ctx &c, long long b, long long e) { for (long long i = b; i < e; ++i) assemble_candidate(c, i); }
@@ -114,8 +132,8 @@ int main(int argc, char **argv)
 		}
 		core.commit();
 		pair_base += fb.n_pairs();
-		fprintf(stderr, "[emu] batch of %lld pairs: %lld rounds, %lld pair-runs (+%lld pairing-only), %lld DP problems, %lld candidates\n", fb.n_pairs(), core.stats.rounds,
-		        core.stats.pairs_run, core.stats.pair_only, core.stats.dp_problems, core.stats.cands);
+		fprintf(stderr, "[emu] batch of %lld pairs: %lld rounds, %lld pair-runs (+%lld pairing-only, +%lld shadow, %lld sensitive, %lld window misses), %lld DP problems, %lld candidates\n", fb.n_pairs(), core.stats.rounds,
+		        core.stats.pairs_run, core.stats.pair_only, core.stats.shadow_runs, core.stats.sensitive, core.stats.window_miss, core.stats.dp_problems, core.stats.cands);
 	}
 	return 0;
 }
