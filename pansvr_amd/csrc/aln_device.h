@@ -143,6 +143,9 @@ struct Ctx {
 	long long *poff;                         // per slot: rand() stream offset of the pair (mate 0 draws first, then mate 1, then pairing)
 	int32_t *rcnt;                           // per slot x {mate0, mate1, pairing}: draws consumed
 	long long *hoff; int32_t *hcnt;          // per read: random_r offsets / counts (one stream per mate)
+	// forced N-substitution draws of "variant" shadow slots (engine_core.h): read r = 2*slot+mate replaces its first
+	// force[4r] N draws by the residues force[4r+1..3]
+	const uint8_t *force;
 	// per read
 	uint8_t *active; uint8_t *unmapped; uint8_t *is_str;
 	int32_t *read_l;
@@ -233,7 +236,9 @@ PSVR_HDN inline void prep_read(const Ctx &c, long long read)
 		char ch = s[i];
 		if (ch == 'N') {
 			long long k = ro + draws - c.grand_base;
-			int32_t r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
+			int32_t r;
+			if (c.force && draws < (int)c.force[4 * read]) r = c.force[4 * read + 1 + draws];
+			else r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
 			ch = "ACGT"[r % 4];
 			++draws;
 		}

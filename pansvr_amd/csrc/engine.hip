@@ -115,14 +115,27 @@ __global__ __launch_bounds__(kBlock) void k_pair(Ctx c, const int32_t *work, lon
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) pair_reads(c, pair_of(work, i));
 }
+// compaction of the dirty pairs into the two work lists; one global atomic per list and workgroup
 __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt,
                                                   int32_t *outp, unsigned long long *cntp)
 {
+	__shared__ unsigned int n_full, n_pair;
+	__shared__ unsigned long long b_full, b_pair;
+	if (threadIdx.x == 0) n_full = n_pair = 0;
+	__syncthreads();
 	long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (p >= c.n_pairs) return;
-	int d = mark_dirty(c, p, noff, nhoff);
-	if (d == 2) out[atomicAdd(cnt, 1ull)] = (int32_t)p;
-	else if (d == 1) outp[atomicAdd(cntp, 1ull)] = (int32_t)p;
+	int d = p < c.n_pairs ? mark_dirty(c, p, noff, nhoff) : 0;
+	unsigned int me = 0;
+	if (d == 2) me = atomicAdd(&n_full, 1u);
+	else if (d == 1) me = atomicAdd(&n_pair, 1u);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		b_full = n_full ? atomicAdd(cnt, (unsigned long long)n_full) : 0;
+		b_pair = n_pair ? atomicAdd(cntp, (unsigned long long)n_pair) : 0;
+	}
+	__syncthreads();
+	if (d == 2) out[b_full + me] = (int32_t)p;
+	else if (d == 1) outp[b_pair + me] = (int32_t)p;
 }
 __global__ void k_fill_i64(long long *p, long long n, int stride, int off, long long v)
 {
@@ -167,41 +180,82 @@ __global__ void k_totals(Ctx c, const int32_t *work, long long n, int32_t *ctot,
 	ctot[s] = t;
 }
 
-// exclusive scan of int32 counts into int64 offsets; one 1024-thread workgroup walks the array in tiles
-// (the arrays are a few MB: this is launch-latency, not bandwidth)
-__global__ __launch_bounds__(1024) void k_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
+// exclusive scan of int32 counts into int64 offsets, three small launches: per-tile sums, scan of the tile sums
+// (one workgroup), per-tile exclusive scan + tile base
+static const int kScanTile = 2048;      // elements per 256-thread workgroup
+__global__ __launch_bounds__(256) void k_scan_sums(const int32_t *cnt, long long n, int stride, int off, long long *tile_sum)
+{
+	__shared__ long long red[256];
+	const long long base = blockIdx.x * (long long)kScanTile;
+	long long s = 0;
+	for (int k = 0; k < kScanTile / 256; ++k) {
+		long long i = base + k * 256 + threadIdx.x;
+		if (i < n) s += cnt[off + i * stride];
+	}
+	red[threadIdx.x] = s;
+	__syncthreads();
+	for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+	if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(1024) void k_scan_tiles(long long *tile_sum, long long ntile, long long base)
 {
 	__shared__ long long part[1024];
 	__shared__ long long carry;
 	const int tid = threadIdx.x;
 	if (tid == 0) carry = base;
 	__syncthreads();
-	const int per = 8;
-	for (long long tile = 0; tile < n; tile += 1024 * per) {
-		long long v[per], s = 0;
-		for (int k = 0; k < per; ++k) {
-			long long i = tile + (long long)tid * per + k;
-			v[k] = i < n ? cnt[off + i * stride] : 0;
-			s += v[k];
-		}
-		part[tid] = s;
+	for (long long t0 = 0; t0 < ntile; t0 += 1024) {
+		long long i = t0 + tid;
+		long long v = i < ntile ? tile_sum[i] : 0;
+		part[tid] = v;
 		__syncthreads();
-		for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan of the per-thread sums
+		for (int d = 1; d < 1024; d <<= 1) {
 			long long t = tid >= d ? part[tid - d] : 0;
 			__syncthreads();
 			part[tid] += t;
 			__syncthreads();
 		}
-		long long run = carry + part[tid] - s;
-		for (int k = 0; k < per; ++k) {
-			long long i = tile + (long long)tid * per + k;
-			if (i < n) out[off + i * stride] = run;
-			run += v[k];
-		}
+		if (i < ntile) tile_sum[i] = carry + part[tid] - v;
 		__syncthreads();
 		if (tid == 1023) carry += part[1023];
 		__syncthreads();
 	}
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, long long n, int stride, int off, const long long *tile_base, long long *out)
+{
+	__shared__ long long part[256];
+	const long long base = blockIdx.x * (long long)kScanTile;
+	const int per = kScanTile / 256;
+	long long v[per], s = 0;
+	for (int k = 0; k < per; ++k) {
+		long long i = base + (long long)threadIdx.x * per + k;
+		v[k] = i < n ? cnt[off + i * stride] : 0;
+		s += v[k];
+	}
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (int d = 1; d < 256; d <<= 1) {
+		long long t = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += t;
+		__syncthreads();
+	}
+	long long run = tile_base[blockIdx.x] + part[threadIdx.x] - s;
+	for (int k = 0; k < per; ++k) {
+		long long i = base + (long long)threadIdx.x * per + k;
+		if (i < n) out[off + i * stride] = run;
+		run += v[k];
+	}
+}
+__global__ void k_mask_totals(const int32_t *ctot, const uint8_t *mask, long long n, int32_t *out)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) out[i] = mask[i] ? 0 : ctot[i];
+}
+__global__ void k_scatter_u8(uint8_t *a, const int32_t *idx, long long n, uint8_t v)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) a[idx[i]] = v;
 }
 
 // ---- DP planning on the device ---------------------------------------------------------------
@@ -216,27 +270,42 @@ struct DpPlanDev {
 };
 __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w)
 {
+	__shared__ unsigned int lh[128];
+	if (threadIdx.x < 128) lh[threadIdx.x] = 0;
+	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i >= d.n) return;
-	const DpDesc &x = d.desc[i];
-	d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
-	int need;
-	int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need);
-	int cls = 0;
-	while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
-	d.plen[i] = kind == 0 ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
-	int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
-	d.bucket[i] = b;
-	atomicAdd(d.hist + b, 1ull);
+	if (i < d.n) {
+		const DpDesc &x = d.desc[i];
+		d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
+		int need;
+		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need);
+		int cls = 0;
+		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
+		d.plen[i] = kind == 0 ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
+		int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
+		d.bucket[i] = b;
+		atomicAdd(&lh[b], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 128 && lh[threadIdx.x]) atomicAdd(d.hist + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
 }
 __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
 {
+	__shared__ unsigned int lh[128];
+	__shared__ unsigned long long lb[128];
+	if (threadIdx.x < 128) lh[threadIdx.x] = 0;
+	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i >= d.n) return;
-	int b = d.bucket[i];
-	unsigned long long k = atomicAdd(d.hist + 128 + b, 1ull);
-	d.idx[bucket_start[b] + k] = (int32_t)i;
-	d.ez[i].cigar_off = d.q_off[i] + d.t_off[i] + 2 * i;
+	int b = 0;
+	unsigned int me = 0;
+	if (i < d.n) { b = d.bucket[i]; me = atomicAdd(&lh[b], 1u); }
+	__syncthreads();
+	if (threadIdx.x < 128 && lh[threadIdx.x]) lb[threadIdx.x] = atomicAdd(d.hist + 128 + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
+	__syncthreads();
+	if (i < d.n) {
+		d.idx[bucket_start[b] + lb[b] + me] = (int32_t)i;
+		d.ez[i].cigar_off = d.q_off[i] + d.t_off[i] + 2 * i;
+	}
 }
 // K5 ref_fetch: unpack the 2-bit reference window / slice the read for every queued DP problem
 __global__ __launch_bounds__(64) void k_dp_fetch(Ctx c, long long begin, const long long *q_off, const long long *t_off, uint8_t *qbuf, uint8_t *tbuf)
@@ -361,10 +430,28 @@ struct GpuBE {
 		if (e > b) { t0("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b, 64)), dim3(64), 0, stream, c, b, e); t1(); }
 		note(hipGetLastError());
 	}
+	DevBuf scan_tmp;
 	void st_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
 	{
-		if (n > 0) hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, cnt, n, stride, off, base, out);
+		if (n <= 0) return;
+		const long long ntile = (n + kScanTile - 1) / kScanTile;
+		note(scan_tmp.ensure((ntile + 1) * 8));
+		long long *ts = scan_tmp.as<long long>();
+		hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)ntile), dim3(256), 0, stream, cnt, n, stride, off, ts);
+		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, ts, ntile, base);
+		hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntile), dim3(256), 0, stream, cnt, n, stride, off, (const long long *)ts, out);
 		note(hipGetLastError());
+	}
+	void st_mask_totals(const int32_t *ctot, const uint8_t *mask, long long n, int32_t *out)
+	{
+		if (n > 0) hipLaunchKernelGGL(k_mask_totals, dim3(grid_for(n)), dim3(kBlock), 0, stream, ctot, mask, n, out);
+	}
+	void scatter_u8(uint8_t *a, const int32_t *idx, long long n, uint8_t v)
+	{
+		if (!n) return;
+		note(tmp_idx.ensure(n * 4));
+		h2d(tmp_idx.p, idx, n * 4);
+		hipLaunchKernelGGL(k_scatter_u8, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, v);
 	}
 	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
 	{
@@ -402,10 +489,11 @@ struct GpuBE {
 		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
 		pd.hist = plan_hist.as<unsigned long long>(), pd.idx = plan_idx.as<int32_t>(), pd.ez = d.ez;
+		PSVR_HIP(hipMemsetAsync(d.qlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(d.tlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(pd.plen + n, 0, 4, stream));
 		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200);
-		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const int32_t *)d.qlen, n + 1, 1, 0, 0ll, d.q_off);
-		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
-		hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
+		st_scan((const int32_t *)d.qlen, n + 1, 1, 0, 0ll, d.q_off);
+		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
+		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
 		PSVR_HIP(hipGetLastError());
 		unsigned long long hist[128];
 		long long tot[3];

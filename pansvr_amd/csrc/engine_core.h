@@ -12,11 +12,14 @@
 // O_{p+1} = O_p + D_p(O_p).  D_p is almost always independent of O_p, so the batch runs speculatively:
 //   1. run every pair at a guessed offset, scan the counts into offsets, re-run the pairs that drew from
 //      a stale offset (most of them only need the pairing stage again);
-//   2. pairs whose count CHANGED between two evaluations are "sensitive" (~0.1 %: e.g. a substituted N
-//      base that decides whether two pair scores tie).  They form a serial chain that would cost one
-//      round per flip; instead each sensitive pair is evaluated at a WINDOW of offsets in the same round
-//      (shadow slots), and the chain O_{s+1} = O_s + D_s(O_s) is walked on the host through those tables;
-//   3. repeat until no pair is dirty (a handful of rounds).
+//   2. the pairs whose count does depend on the drawn values form a serial chain that would cost one round
+//      per flip.  Almost all of them contain N bases: D_p then depends on the substituted residues, not on
+//      the offset, so every pair with 1..3 N draws is ALSO evaluated once per residue combination in
+//      round 1 ("variant" shadow slots with forced draws, ~6 % extra work) and the chain
+//      O_{s+1} = O_s + D_s(stream content at O_s) is walked exactly on the host through those tables;
+//   3. any other pair whose count changes between two evaluations (tied chains in repeats) is evaluated at
+//      a window of offsets around its estimate in the next round and joins the same host walk;
+//   4. repeat until no pair is dirty (3-4 rounds in practice).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -94,7 +97,12 @@ template <class BE> struct EngineCore {
 	int32_t *d_ctot = nullptr, *d_src = nullptr;     // per slot: total draws of the last evaluation; slot -> input pair
 	uint8_t *d_sens = nullptr;                       // per pair: known count-sensitive
 	int32_t *d_slist = nullptr;                      // newly detected sensitive pairs
-	long long S = 0;                                 // slots = P real pairs + shadow capacity
+	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
+	int32_t *d_cmask = nullptr;                      // totals with the host-resolved pairs masked out
+	struct Special { int32_t pair; uint8_t n1, n2; int32_t vslot, nvar; };
+	std::vector<Special> special;                    // pairs with 1..3 N draws, ascending
+	long long V = 0;                                 // variant slots [P, P+V)
+	long long S = 0;                                 // slots = P real pairs + V variants + window-shadow capacity
 	static const int kWin = 32;                      // offsets evaluated per sensitive pair and round
 	unsigned long long *d_tops = nullptr;     // [8] arena tops + dirty count
 	int32_t *d_flags = nullptr;               // [8] overflow flags + err
@@ -186,8 +194,29 @@ template <class BE> struct EngineCore {
 		char *d_bases = alloc<char>(total_bases + 16);
 		long long *d_off = alloc<long long>(R + 1);
 		psvr_ori_t *d_ori = alloc<psvr_ori_t>(R);
-		const long long shadow_cap = P / 8 + 4096;
-		S = P + shadow_cap;
+		// pairs whose reads will draw for 1..3 N bases (early-out reads draw nothing: rr.cpp:414 returns first)
+		special.clear();
+		V = 0;
+		for (long long p = 0; p < P; ++p) {
+			int nn[2];
+			for (int k = 0; k < 2; ++k) {
+				long long r = 2 * p + k;
+				const char *b = bases + base_off[r];
+				long long L = base_off[r + 1] - base_off[r];
+				int n = 0;
+				for (const char *q = (const char *)memchr(b, 'N', L); q; q = (const char *)memchr(q + 1, 'N', b + L - (q + 1))) ++n;
+				bool unm = ori[r].unmapped || (uint32_t)ori[r].chr_id > 24u;
+				if ((!unm && ori[r].align_score == (uint32_t)(L * c.par.match)) || L < kLenKmer) n = 0;
+				nn[k] = n;
+			}
+			if (nn[0] + nn[1] >= 1 && nn[0] + nn[1] <= 3) {
+				Special sp{(int32_t)p, (uint8_t)nn[0], (uint8_t)nn[1], (int32_t)(P + V), 1 << (2 * (nn[0] + nn[1]))};
+				special.push_back(sp);
+				V += sp.nvar;
+			}
+		}
+		const long long shadow_cap = P / 16 + 8192;
+		S = P + V + shadow_cap;
 		const long long RS = 2 * S;                                 // reads incl. shadow slots
 		c.n_slots = S;
 		c.poff = alloc<long long>(S), c.rcnt = alloc<int32_t>(3 * S), d_noff = alloc<long long>(S);
@@ -202,6 +231,7 @@ template <class BE> struct EngineCore {
 		c.res = alloc<psvr_read_result_t>(RS), c.pres = alloc<psvr_pair_result_t>(S);
 		d_work = alloc<int32_t>(S), d_workp = alloc<int32_t>(P);
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
+		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
 		d_tops = alloc<unsigned long long>(16), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
@@ -307,6 +337,7 @@ template <class BE> struct EngineCore {
 	}
 
 	// ---- one full run of the uploaded batch (rand state is NOT advanced: call commit() for that)
+	struct Win { int32_t pair; long long eval_off; int32_t eval_tot; std::vector<long long> off; std::vector<int32_t> tot; };   // window-resolved pair
 	int run(int trace, bool want_stats, int depth = 0)
 	{
 		stats = RunStats();
@@ -322,19 +353,45 @@ template <class BE> struct EngineCore {
 		be.fill_i64(c.poff, S, 1, 0, grand_pos);
 		be.fill_i64(c.hoff, S, 2, 0, hrand_pos[0]);
 		be.fill_i64(c.hoff, S, 2, 1, hrand_pos[1]);
-		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_sens, P);
+		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_sens, P), be.dzero(d_mask, P);
 		be.fill_iota(d_src, S);
-		c.src = d_src;
+		c.src = d_src, c.force = d_force;
+		// variant slots: pair s at every combination of its N-substitution residues
+		{
+			std::vector<uint8_t> force((size_t)8 * S, 0);
+			std::vector<int32_t> vsrc(V);
+			std::vector<int32_t> sp_idx(special.size());
+			for (size_t i = 0; i < special.size(); ++i) {
+				const Special &sp = special[i];
+				sp_idx[i] = sp.pair;
+				for (int v = 0; v < sp.nvar; ++v) {
+					long long slot = sp.vslot + v;
+					vsrc[slot - P] = sp.pair;
+					int code = v;
+					for (int k = 0; k < 2; ++k) {
+						int n = k == 0 ? sp.n1 : sp.n2;
+						uint8_t *f = &force[4 * (2 * slot + k)];
+						f[0] = (uint8_t)n;
+						for (int j = 0; j < n; ++j) f[1 + j] = (uint8_t)(code & 3), code >>= 2;
+					}
+				}
+			}
+			be.h2d(d_force, force.data(), force.size());
+			if (V) be.h2d(d_src + P, vsrc.data(), V * 4);
+			if (!special.empty()) { std::vector<int32_t> ones(special.size(), 1); be.scatter_u8(d_mask, sp_idx.data(), (long long)sp_idx.size(), 1); }
+		}
 		long long dp_done = 0, cw_done = 0;
 		int rc = PSVR_OK;
-		std::vector<int32_t> sens;                      // sensitive pairs, ascending
-		std::vector<long long> sens_est;                // offset each was last evaluated at
-		std::vector<int32_t> sens_used;                 // count that the last scan assumed for it
-		long long nfull = P, npair_only = 0, nshadow = 0;
-		const int32_t *work = nullptr;                  // nullptr = identity list (first round: every real pair)
+		std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
+		std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
+		std::vector<char> is_special(special.size(), 1);  // a special pair whose prediction failed falls back to the window method
+		long long nfull = P + V, npair_only = 0, nshadow = 0;
+		const int32_t *work = nullptr;                    // nullptr = identity: round 1 runs every real pair and every variant slot
 		std::vector<int32_t> sh_src; std::vector<long long> sh_off;
 		for (;;) {
-			stats.rounds++, stats.pairs_run += nfull, stats.shadow_runs += nshadow, stats.pair_only += npair_only;
+			stats.rounds++;
+			if (stats.rounds == 1) stats.pairs_run += P, stats.shadow_runs += V; else stats.pairs_run += nfull, stats.shadow_runs += nshadow;
+			stats.pair_only += npair_only;
 			rc = run_slots(work, nfull + nshadow, dp_done, cw_done);
 			if (rc <= -1000) {
 				int32_t fl[8] = {0, 0, 0, ((-rc - 1000) & 1), ((-rc - 1000) & 2) >> 1, 0, 0, 0};
@@ -343,47 +400,83 @@ template <class BE> struct EngineCore {
 			}
 			if (rc) break;
 			if (npair_only) be.st_pair(c, d_workp, npair_only);
-			// totals of the evaluated slots; real pairs whose total changed since their previous evaluation are sensitive
+			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
 			be.dzero(d_tops + 8, 8);
 			be.st_totals(c, work, nfull + nshadow, d_ctot, d_sens, d_slist, d_tops + 8, stats.rounds > 1);
 			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_sens, d_slist, d_tops + 8, true);
 			unsigned long long nnew = 0;
 			be.d2h(&nnew, d_tops + 8, 8);
+			if (stats.rounds == 1 && V) { vcnt.resize(3 * V); be.d2h(vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
+			// window tables of the pairs evaluated with offset shadows this round
+			if (nshadow > 0) {
+				std::vector<int32_t> tot(nshadow);
+				be.d2h(tot.data(), d_ctot + (P + V), nshadow * 4);
+				size_t sh = 0;
+				for (Win &w : wins) {
+					w.off.clear(), w.tot.clear();
+					while (sh < sh_src.size() && sh_src[sh] == w.pair) w.off.push_back(sh_off[sh]), w.tot.push_back(tot[sh]), ++sh;
+				}
+			}
 			if (nnew) {
 				std::vector<int32_t> add(nnew);
 				be.d2h(add.data(), d_slist, nnew * 4);
-				sens.insert(sens.end(), add.begin(), add.end());
-				std::sort(sens.begin(), sens.end());
-				sens.erase(std::unique(sens.begin(), sens.end()), sens.end());
-				stats.sensitive = (long long)sens.size();
-			}
-			// walk the chain of sensitive pairs through the offset windows evaluated this round
-			if (nshadow > 0) {
-				std::vector<int32_t> tot(nshadow);
-				be.d2h(tot.data(), d_ctot + P, nshadow * 4);
-				std::vector<int32_t> real_tot(sens_est.size());
-				be.gather_i32(d_ctot, sens_used_idx.data(), (long long)sens_used_idx.size(), real_tot.data());
-				// D_s is known at est (the real slot) and at the shadow offsets; the true offset of s is est + the drift
-				// accumulated from the sensitive pairs before it
-				long long shift = 0;
-				size_t sh = 0;
-				std::vector<int32_t> res_idx, res_val;
-				for (size_t i = 0; i < sens_used_idx.size(); ++i) {
-					const int32_t s = sens_used_idx[i];
-					const long long est = sens_est[i], t = est + shift;
-					int32_t d_at = real_tot[i];
-					long long best_dist = std::llabs(t - est);
-					while (sh < sh_src.size() && sh_src[sh] == s) {
-						long long dist = std::llabs(sh_off[sh] - t);
-						if (dist < best_dist) best_dist = dist, d_at = tot[sh];
-						++sh;
-					}
-					if (best_dist != 0) stats.window_miss++;
-					shift += (long long)d_at - sens_used[i];
-					res_idx.push_back(s), res_val.push_back(d_at);
+				for (int32_t s : add) {
+					for (size_t i = 0; i < special.size(); ++i) if (special[i].pair == s) is_special[i] = 0;
+					Win w; w.pair = s, w.eval_off = -1, w.eval_tot = 0;
+					wins.push_back(w);
 				}
-				be.scatter_i32(d_ctot, res_idx.data(), res_val.data(), (long long)res_idx.size());
+				std::sort(wins.begin(), wins.end(), [](const Win &a, const Win &b) { return a.pair < b.pair; });
+				be.scatter_u8(d_mask, add.data(), (long long)add.size(), 1);
+				stats.sensitive = (long long)wins.size();
 			}
+			// every host-resolved pair: its last evaluation (offset, total) and the masked prefix in front of it
+			std::vector<int32_t> listed;
+			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
+			for (const Win &w : wins) listed.push_back(w.pair);
+			std::sort(listed.begin(), listed.end());
+			std::vector<long long> pre(listed.size()), cur_off(listed.size());
+			std::vector<int32_t> cur_tot(listed.size()), res(listed.size());
+			be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
+			be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
+			if (!listed.empty()) {
+				be.gather_i64(d_noff, listed.data(), (long long)listed.size(), pre.data());
+				be.gather_i64(c.poff, listed.data(), (long long)listed.size(), cur_off.data());
+				be.gather_i32(d_ctot, listed.data(), (long long)listed.size(), cur_tot.data());
+			}
+			// walk O_{s+1} = O_s + D_s through the tables
+			{
+				long long acc = 0;
+				size_t si = 0, wi = 0;
+				for (size_t i = 0; i < listed.size(); ++i) {
+					const int32_t s = listed[i];
+					const long long t = grand_pos + pre[i] + acc;
+					int32_t D = cur_tot[i];
+					while (si < special.size() && special[si].pair < s) ++si;
+					while (wi < wins.size() && wins[wi].pair < s) ++wi;
+					if (si < special.size() && special[si].pair == s && is_special[si] && !vcnt.empty()) {
+						const Special &sp = special[si];
+						grand.ensure(t + 64);
+						int code = 0, sh2 = 0;
+						for (int j = 0; j < sp.n1; ++j) code |= (grand.host[t + j] & 3) << sh2, sh2 += 2;
+						const int32_t c1 = vcnt[3 * (sp.vslot - P + code)];          // mate 0 does not depend on mate 1's residues
+						for (int j = 0; j < sp.n2; ++j) code |= (grand.host[t + c1 + j] & 3) << sh2, sh2 += 2;
+						const int32_t *vc = &vcnt[3 * (sp.vslot - P + code)];
+						D = vc[0] + vc[1] + vc[2];
+					} else if (wi < wins.size() && wins[wi].pair == s) {
+						Win &w = wins[wi];
+						w.eval_off = cur_off[i], w.eval_tot = cur_tot[i];
+						long long best = std::llabs(t - w.eval_off);
+						for (size_t k = 0; k < w.off.size(); ++k) {
+							long long d = std::llabs(w.off[k] - t);
+							if (d < best) best = d, D = w.tot[k];
+						}
+						if (best != 0) stats.window_miss++;
+					}
+					res[i] = D, acc += D;
+					cur_off[i] = t;                                  // where the pair must be evaluated next
+				}
+			}
+			if (!listed.empty()) be.scatter_i32(d_ctot, listed.data(), res.data(), (long long)listed.size());
 			// new offsets from the totals; which pairs drew from a stale offset?
 			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
 			be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);
@@ -407,36 +500,34 @@ template <class BE> struct EngineCore {
 			if (nfull == 0 && npair_only == 0) break;
 			if (stats.rounds > 200) { err = "rand()-order resolution did not converge in 200 rounds"; rc = PSVR_ERR_UNSUPPORTED; break; }
 			work = d_work;
-			// shadow evaluations: every sensitive pair at kWin offsets around its new estimate
-			sens_used_idx.clear(), sens_est.clear(), sens_used.clear(), sh_src.clear(), sh_off.clear();
-			if (!sens.empty()) {
-				std::vector<long long> est(sens.size());
-				std::vector<int32_t> used(sens.size());
-				be.gather_i64(c.poff, sens.data(), (long long)sens.size(), est.data());
-				be.gather_i32(d_ctot, sens.data(), (long long)sens.size(), used.data());
-				const long long cap = S - P;
-				for (size_t i = 0; i < sens.size(); ++i) {
-					sens_used_idx.push_back(sens[i]), sens_est.push_back(est[i]), sens_used.push_back(used[i]);
-					if ((long long)sh_src.size() + kWin - 1 > cap) continue;
+			// offset windows for the tie-sensitive pairs that move
+			sh_src.clear(), sh_off.clear();
+			const long long cap = S - P - V;
+			{
+				size_t li = 0;
+				for (Win &w : wins) {
+					while (li < listed.size() && listed[li] < w.pair) ++li;
+					const long long t = li < listed.size() && listed[li] == w.pair ? cur_off[li] : w.eval_off;
+					if (t == w.eval_off && !w.off.empty()) continue;            // evaluated there already
+					if ((long long)sh_src.size() + kWin > cap) break;
 					for (int k = -kWin / 2; k < kWin / 2; ++k) {
-						if (k == 0 || est[i] + k < grand_pos) continue;
-						sh_src.push_back(sens[i]), sh_off.push_back(est[i] + k);
+						if (k == 0 || t + k < grand_pos) continue;
+						sh_src.push_back(w.pair), sh_off.push_back(t + k);
 					}
 				}
-				nshadow = (long long)sh_src.size();
-				if (nshadow) {
-					be.h2d(d_src + P, sh_src.data(), nshadow * 4);
-					be.h2d(c.poff + P, sh_off.data(), nshadow * 8);
-					be.copy_hoff_to_shadows(c, P, nshadow);
-					be.append_iota(d_work, nfull, P, nshadow);      // work list: dirty real pairs, then the shadow slots
-				}
+			}
+			nshadow = (long long)sh_src.size();
+			if (nshadow) {
+				be.h2d(d_src + P + V, sh_src.data(), nshadow * 4);
+				be.h2d(c.poff + P + V, sh_off.data(), nshadow * 8);
+				be.copy_hoff_to_shadows(c, P + V, nshadow);
+				be.append_iota(d_work, nfull, P + V, nshadow);      // work list: dirty real pairs, then the shadow slots
 			}
 		}
 		c.stats = stats_ptr;
 		if (rc == PSVR_OK && want_stats) be.d2h(stats.counters, stats_ptr, 16 * 8);
 		return rc;
 	}
-	std::vector<int32_t> sens_used_idx;
 
 	// advance the rand streams past this batch (the reference's generators keep running across batches)
 	void commit()

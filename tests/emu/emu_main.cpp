@@ -30,6 +30,8 @@ struct CpuBE {
 	void append_iota(int32_t *w, long long at, long long start, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = (int32_t)(start + i); }
 	void gather_i64(const long long *a, const int32_t *idx, long long n, long long *out) { for (long long i = 0; i < n; ++i) out[i] = a[idx[i]]; }
 	void gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out) { for (long long i = 0; i < n; ++i) out[i] = a[idx[i]]; }
+	void scatter_u8(uint8_t *a, const int32_t *idx, long long n, uint8_t v) { for (long long i = 0; i < n; ++i) a[idx[i]] = v; }
+	void st_mask_totals(const int32_t *ctot, const uint8_t *mask, long long n, int32_t *out) { for (long long i = 0; i < n; ++i) out[i] = mask[i] ? 0 : ctot[i]; }
 	void scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n) { for (long long i = 0; i < n; ++i) a[idx[i]] = val[i]; }
 	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n)
 	{
