@@ -699,12 +699,12 @@ struct WalkState {
 	long long read; int strand;
 	int32_t read_score; uint32_t total_q_len;
 	bool is_simple;
-	Seg *seg; int n_seg; int bad;
+	Seg *seg; int n_seg; int bad; int seg_cap;
 };
 
 PSVR_HD void seg_lit(WalkState &w, int type, int size)
 {
-	if (w.n_seg >= kSegMax) { w.bad = 1; return; }
+	if (w.n_seg >= w.seg_cap) { w.bad = 1; return; }
 	Seg &s = w.seg[w.n_seg++];
 	s.kind = 0, s.a = type, s.b = (int32_t)(int16_t)(uint16_t)size;   // CIGAR_PATH(char, uint16_t) -> int16_t size
 }
@@ -769,7 +769,7 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 		return;
 	}
 	long long id = arena_alloc(c.dp, 1);
-	if (id < 0 || w.n_seg >= kSegMax) { w.bad = 1; return; }
+	if (id < 0 || w.n_seg >= w.seg_cap) { w.bad = 1; return; }
 	DpDesc &d = c.dp.base[id];
 	d.read = (int32_t)w.read, d.strand = w.strand, d.q_st = read_st, d.qlen = (int32_t)qlen, d.ref_st = (uint32_t)ref_st, d.tlen = (int32_t)tlen, d.type = type, d.pad = 0;
 	Seg &s = w.seg[w.n_seg++];
@@ -789,10 +789,15 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
 	const int read_l = c.read_l[read];
 	long long cwi = arena_alloc(c.cw, 1);
 	if (cwi < 0) return;
-	Seg lseg[kSegMax];
+	int n_nodes = 0;
+	for (int node = (int)cc.max_index; node != -1; node = dp[node].pre_node) ++n_nodes;
+	int seg_cap = 3 * n_nodes + 4;                        // per chain node: at most 'M' + alignment (+ negative D); + tail M + left extension
+	if (seg_cap > kSegMax) seg_cap = kSegMax;
+	long long so = arena_alloc(c.seg, (unsigned long long)seg_cap);
+	if (so < 0) return;
 	WalkState w;
 	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
-	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = lseg, w.n_seg = 0, w.bad = 0;
+	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap;
 	const int BIG = 0x7fffffff;
 	int aln_read_begin = read_l, aln_read_end = read_l, aln_ref_begin = BIG, aln_ref_end = BIG;
 	int last_aln_begin = read_l, last_ref_begin = BIG, unitig_mis = 0;
@@ -839,9 +844,6 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
 	}
 	w.read_score += (int32_t)((read_l - (int)w.total_q_len) * c.par.match);
 	w.read_score -= unitig_mis * (c.par.match + c.par.mismatch);
-	long long so = arena_alloc(c.seg, (unsigned long long)w.n_seg);
-	if (so < 0) return;
-	for (int i = 0; i < w.n_seg; ++i) c.seg.base[so + i] = lseg[i];
 	CandWork &cw = c.cw.base[cwi];
 	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = rba, cw.bad = w.bad, cw.seg_off = so;
 	if (w.bad) *c.err = 10 + w.bad;

@@ -10,6 +10,7 @@
 #include "engine_core.h"
 #include "host_io.h"
 #include "ksw_device.h"
+#include "ksw_launch.h"
 
 namespace psvr {
 
@@ -21,10 +22,80 @@ static inline unsigned grid_for(long long n, int block = kBlock) { return (unsig
 __device__ __forceinline__ long long pair_of(const int32_t *work, long long i) { return work ? (long long)work[i] : i; }
 
 // ---- stage kernels: one thread per item; the read-level stages run per mate ------------------------
+// prep (prep_read in aln_device.h), one wavefront per read: coalesced base loads, N draws ordered by a ballot
+// prefix, 2-bit codes staged in LDS, packed words built from wave ballots (no per-base read-modify-write).
+__device__ __forceinline__ uint64_t spread_bits(uint32_t x)
+{
+	uint64_t v = x;
+	v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+	v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+	v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	v = (v | (v << 2)) & 0x3333333333333333ull;
+	v = (v | (v << 1)) & 0x5555555555555555ull;
+	return v;
+}
 __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate)
 {
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < n) prep_read(c, pair_of(work, i) * 2 + mate);
+	extern __shared__ __align__(16) uint8_t prep_lds[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
+	if (wi >= n) return;
+	const long long read = pair_of(work, wi) * 2 + mate;
+	uint8_t *codes = prep_lds + (size_t)wave * c.lmax;
+	const long long sr = src_read(c, read);
+	const psvr_ori_t o = c.ori[sr];
+	const int L = (int)(c.base_off[sr + 1] - c.base_off[sr]);
+	const long long item = (read >> 1) * 3 + (read & 1);
+	bool unm = o.unmapped != 0 || (uint32_t)o.chr_id > 24u;
+	bool act = !(L > kMaxReadLen || L < kLenKmer) && !(!unm && o.align_score == (uint32_t)(L * c.par.match));
+	if (lane == 0) {
+		c.read_l[read] = L, c.unmapped[read] = unm, c.is_str[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
+		if (L > kMaxReadLen) *c.err = 1;
+	}
+	if (lane < 2) { Strand &st = c.strand[read * 2 + lane]; st.mem_n = st.us_n = 0; st.mem_off = st.us_off = 0; st.seed_hash = st.chain_hash = 1469598103934665603ULL; }
+	if (!act) { if (lane == 0) c.rcnt[item] = 0; return; }
+	const char *s = c.bases + c.base_off[sr];
+	uint8_t *b0 = c.bin + (read * 2) * (long long)c.lmax, *b1 = b0 + c.lmax;
+	uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
+	const long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0);
+	int draws = 0;
+	for (int i0 = 0; i0 < L; i0 += 64) {
+		const int i = i0 + lane;
+		char ch = i < L ? s[i] : 'A';
+		const bool isn = i < L && ch == 'N';
+		const unsigned long long m = __ballot(isn);
+		if (isn) {
+			const int d = draws + __popcll(m & ((1ull << lane) - 1));
+			long long k = ro + d - c.grand_base;
+			int32_t r;
+			if (c.force && d < (int)c.force[4 * read]) r = c.force[4 * read + 1 + d];
+			else r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
+			ch = "ACGT"[r % 4];
+		}
+		draws += __popcll(m);
+		const uint8_t code = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0;
+		if (i < L) codes[i] = code, b0[i] = code, b1[L - 1 - i] = code ^ 3;
+	}
+	// packed words of both strands (binary_read_64_bit, rr.cpp:295-300): word = OR of code << 2*(31 - (i & 31)); a code of 4
+	// (lower-case n) spills its third bit into the neighbouring base exactly as the reference's shift does
+	for (int s2 = 0; s2 < 2; ++s2) {
+		uint64_t *wout = s2 ? w1 : w0;
+		for (int i0 = 0; i0 < c.wmax * 32; i0 += 64) {
+			const int i = i0 + lane;
+			const unsigned code = i < L ? (s2 ? (unsigned)(codes[L - 1 - i] ^ 3) : (unsigned)codes[i]) : 0u;
+			const unsigned long long m0 = __ballot(code & 1), m1 = __ballot(code & 2), m2 = __ballot(code & 4);
+			if (lane < 2) {
+				const int w = (i0 >> 5) + lane;
+				if (w < c.wmax) {
+					const uint32_t l0 = (uint32_t)(m0 >> (32 * lane)), l1 = (uint32_t)(m1 >> (32 * lane)), l2 = (uint32_t)(m2 >> (32 * lane));
+					uint64_t word = spread_bits(__brev(l0)) | (spread_bits(__brev(l1)) << 1);
+					word |= (spread_bits(__brev(l2)) << 2);          // bit 2 of base i lands on bit 0 of base i-1; the top base's is shifted out
+					wout[w] = word;
+				}
+			}
+		}
+	}
+	if (lane == 0) { c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1); }
 }
 
 // STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are staged in LDS and every lane
@@ -270,8 +341,8 @@ struct DpPlanDev {
 };
 __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w)
 {
-	__shared__ unsigned int lh[128];
-	if (threadIdx.x < 128) lh[threadIdx.x] = 0;
+	__shared__ unsigned int lh[256];
+	lh[threadIdx.x] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < d.n) {
@@ -281,26 +352,26 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w)
 		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need);
 		int cls = 0;
 		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
-		d.plen[i] = kind == 0 ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
+		d.plen[i] = (kind == 0 || kind > 5) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
 		int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
 		d.bucket[i] = b;
 		atomicAdd(&lh[b], 1u);
 	}
 	__syncthreads();
-	if (threadIdx.x < 128 && lh[threadIdx.x]) atomicAdd(d.hist + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
+	if (lh[threadIdx.x]) atomicAdd(d.hist + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
 }
 __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
 {
-	__shared__ unsigned int lh[128];
-	__shared__ unsigned long long lb[128];
-	if (threadIdx.x < 128) lh[threadIdx.x] = 0;
+	__shared__ unsigned int lh[256];
+	__shared__ unsigned long long lb[256];
+	lh[threadIdx.x] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	int b = 0;
 	unsigned int me = 0;
 	if (i < d.n) { b = d.bucket[i]; me = atomicAdd(&lh[b], 1u); }
 	__syncthreads();
-	if (threadIdx.x < 128 && lh[threadIdx.x]) lb[threadIdx.x] = atomicAdd(d.hist + 128 + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
+	if (lh[threadIdx.x]) lb[threadIdx.x] = atomicAdd(d.hist + 256 + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
 	__syncthreads();
 	if (i < d.n) {
 		d.idx[bucket_start[b] + lb[b] + me] = (int32_t)i;
@@ -368,11 +439,18 @@ struct GpuBE {
 		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n)), dim3(kBlock), 0, stream, c, w, n, mate); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
-	PSVR_STAGE_M(st_prep, k_prep, 1)
 	PSVR_STAGE_M(st_seed, k_seed, 2)
 	PSVR_STAGE_M(st_chain, k_chain, 1)
 	PSVR_STAGE_M(st_select, k_select, 1)
 #undef PSVR_STAGE_M
+	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate)
+	{
+		if (n <= 0) return;
+		t0("k_prep");
+		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * c.lmax, stream, c, w, n, mate);
+		t1();
+		note(hipGetLastError());
+	}
 	void st_str(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n <= 0) return;
@@ -474,17 +552,14 @@ struct GpuBE {
 			kp.w = 200, kp.zdrop = c.par.zdrop, kp.end_bonus = -1, kp.flag = 0;   // KSW_ALN_handler::copy_option, rr.cpp:817-827 (bandwith = 200)
 			int rc = make_dp_params(&kp, 0, &dpP);
 			if (rc) return rc;
-#define PSVR_ATTR(k) note(hipFuncSetAttribute((const void *)(k), hipFuncAttributeMaxDynamicSharedMemorySize, PSVR_DP_MAX_LDS))
-			PSVR_ATTR(extd2_reg_kernel<1>); PSVR_ATTR(extd2_reg_kernel<2>); PSVR_ATTR(extd2_reg_kernel<3>);
-			PSVR_ATTR(extd2_reg_kernel<4>); PSVR_ATTR(extd2_reg_kernel<5>); PSVR_ATTR(extd2_lds_kernel<0>);
-#undef PSVR_ATTR
+			note(dp_allow_big_lds());
 			dp_ready = true;
 		}
 		// upper bounds for the sequence buffers: every problem has qlen, tlen < 1600; size from the actual lens
 		if (!core.ensure_dp(n, 0, 0, 0)) return set_error(PSVR_ERR_NOMEM, "DP buffers");
 		PSVR_HIP(plan_bucket.ensure(n * 4)); PSVR_HIP(plan_idx.ensure(n * 4)); PSVR_HIP(plan_plen.ensure((n + 1) * 4)); PSVR_HIP(plan_poff.ensure((n + 1) * 8));
-		PSVR_HIP(plan_hist.ensure(256 * 8)); PSVR_HIP(plan_bstart.ensure(128 * 8));
-		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 256 * 8, stream));
+		PSVR_HIP(plan_hist.ensure(512 * 8)); PSVR_HIP(plan_bstart.ensure(256 * 8));
+		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 512 * 8, stream));
 		DpPlanDev pd;
 		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
@@ -495,9 +570,9 @@ struct GpuBE {
 		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
 		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
 		PSVR_HIP(hipGetLastError());
-		unsigned long long hist[128];
+		unsigned long long hist[256];
 		long long tot[3];
-		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 128 * 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 256 * 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[0], d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[1], d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[2], pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
@@ -505,17 +580,18 @@ struct GpuBE {
 		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
-		long long bstart[128], acc = 0;
+		long long bstart[256], acc = 0;
+		memset(bstart, 0, sizeof bstart);
 		std::vector<Launch3> ls;
-		const int kind_order[6] = {0, 5, 4, 3, 2, 1};
-		for (int ko = 0; ko < 6; ++ko)
+		const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
+		for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 			for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
 				int b = kind_order[ko] * PSVR_DP_NUM_LDS_CLASSES + cls;
 				bstart[b] = acc;
 				if (hist[b]) ls.push_back(Launch3{kind_order[ko], dp_lds_class_bytes(cls), acc, (long long)hist[b]});
 				acc += (long long)hist[b];
 			}
-		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 128 * 8, hipMemcpyHostToDevice, stream));
+		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 256 * 8, hipMemcpyHostToDevice, stream));
 		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
 		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
 		t0("k_dp_fetch");
@@ -525,26 +601,11 @@ struct GpuBE {
 		DpBatch B;
 		B.qseq = d.qbuf, B.q_off = (const int64_t *)d.q_off, B.qlen = d.qlen;
 		B.tseq = d.tbuf, B.t_off = (const int64_t *)d.t_off, B.tlen = d.tlen;
-		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = nullptr, B.p_unit_shift = 0;
-		// general-kernel problems address their direction bytes in 256-byte units: convert once
+		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = (const int64_t *)plan_poff.p, B.p_unit_shift = 8;   // slab offsets in 256-byte units
 		for (const Launch3 &L : ls) {
 			B.idx = plan_idx.as<int32_t>() + L.first;
-			dim3 grid((unsigned)L.count), block(64);
-			static const char *knames[6] = {"extd2_lds_kernel<0>", "extd2_reg_kernel<1>", "extd2_reg_kernel<2>", "extd2_reg_kernel<3>", "extd2_reg_kernel<4>", "extd2_reg_kernel<5>"};
-			t0(knames[L.kind]);
-			switch (L.kind) {
-			case 1: hipLaunchKernelGGL(extd2_reg_kernel<1>, grid, block, L.lds, stream, B, dpP); break;
-			case 2: hipLaunchKernelGGL(extd2_reg_kernel<2>, grid, block, L.lds, stream, B, dpP); break;
-			case 3: hipLaunchKernelGGL(extd2_reg_kernel<3>, grid, block, L.lds, stream, B, dpP); break;
-			case 4: hipLaunchKernelGGL(extd2_reg_kernel<4>, grid, block, L.lds, stream, B, dpP); break;
-			case 5: hipLaunchKernelGGL(extd2_reg_kernel<5>, grid, block, L.lds, stream, B, dpP); break;
-			default: {
-				DpBatch G = B;
-				G.p_off = (const int64_t *)plan_poff.p;
-				G.p_unit_shift = 8;
-				hipLaunchKernelGGL(extd2_lds_kernel<0>, grid, block, L.lds, stream, G, dpP);
-			}
-			}
+			t0(dp_kind_name(L.kind, 0));
+			dp_launch_kind(L.kind, 0, (unsigned)L.count, L.lds, stream, B, dpP);
 			t1();
 			PSVR_HIP(hipGetLastError());
 		}

@@ -237,7 +237,7 @@ template <class BE> struct EngineCore {
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
 		cap_us = (unsigned long long)R2 * 48 + 65536;
 		cap_cw = (unsigned long long)R2 * 3 + 1024;
-		cap_seg = cap_cw * 12;
+		cap_seg = cap_cw * 16;
 		cap_dp = (unsigned long long)R2 * 4 + 1024;
 		cap_cig = (unsigned long long)R2 * 48 + 4096;
 		c.stats = alloc<unsigned long long>(16);

@@ -42,7 +42,7 @@ struct DpBatch { // device pointers of one batch
 	int32_t p_unit_shift;
 };
 
-template <int K> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
+template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
 
 // ---- size classes shared by the host planner (ksw_host.hip) and the device-side planner (engine.hip)
@@ -75,13 +75,22 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 	int img = narr * T + T + QL + 16;
 	return ((img + 15) & ~15) + 4 * T;
 }
-// kind: 1..5 = extd2_reg_kernel<kind>, 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
+// Direction bytes stay in LDS only while the whole footprint is at most this (keeps >= 32 waves per CU resident);
+// larger problems stream them to an HBM slab and trace back through L2
+#define PSVR_DP_PG_THRESHOLD 4096
+#define PSVR_DP_NUM_KINDS 11
+// kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM),
+// 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
 __host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need)
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
 	int T = (tlen + 15) / 16 * 16;
 	long long n = dp_reg_lds_need(qlen, tlen, w);
-	if (fast_ok && T <= 320 && n <= PSVR_DP_MAX_LDS) { *need = (int)n; return (T + 63) / 64; }
+	if (fast_ok && T <= 320) {
+		if (n <= PSVR_DP_PG_THRESHOLD) { *need = (int)n; return (T + 63) / 64; }
+		*need = ((qlen + 16 + 15) & ~15) + 16;
+		return 5 + (T + 63) / 64;
+	}
 	int g = dp_lds_kernel_need(qlen, tlen, variant);
 	*need = g;
 	return g <= PSVR_DP_MAX_LDS ? 0 : -1;

@@ -7,6 +7,7 @@
 #include <vector>
 #include "common.h"
 #include "ksw_device.h"
+#include "ksw_launch.h"
 
 namespace psvr {
 
@@ -74,30 +75,8 @@ struct psvr_dp_plan {
 	std::string desc;
 };
 
-static int reg_lds_need(int qlen, int tlen, int w_in)
-{
-	int w = w_in < 0 ? std::max(qlen, tlen) : w_in;
-	int n_col = std::min(qlen, tlen);
-	n_col = (std::min(n_col, w + 1) + 15) / 16 + 1;
-	int64_t need = (int64_t)((qlen + 16 + 15) & ~15) + (int64_t)(qlen + tlen - 1) * n_col * 16 + 16;
-	return need > (1 << 30) ? (1 << 30) : (int)need;
-}
 
-static int64_t p_bytes(int qlen, int tlen, int w_in)
-{
-	int w = w_in < 0 ? std::max(qlen, tlen) : w_in;
-	int n_col = std::min(qlen, tlen);
-	n_col = (std::min(n_col, w + 1) + 15) / 16 + 1;
-	return ((int64_t)(qlen + tlen - 1) * n_col + 1) * 16;
-}
 
-static int lds_kernel_need(int qlen, int tlen, int variant)
-{
-	int T = (tlen + 15) / 16 * 16, QL = (qlen + 15) / 16 * 16;
-	int narr = variant == 0 ? 7 : 5;
-	int img = narr * T + T + QL + 16;
-	return ((img + 15) & ~15) + 4 * T;
-}
 
 extern "C" const char *psvr_last_error(void) { return last_error_ref().c_str(); }
 
@@ -121,8 +100,8 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	PSVR_HIP(hipSetDevice(device));
 	const int fast_flags = PSVR_EZ_EXTZ_ONLY | PSVR_EZ_REV_CIGAR | PSVR_EZ_SCORE_ONLY;
 	const bool fast_ok = variant == 0 && (par->flag & ~fast_flags) == 0;
-	// bucket = kind * kNumLdsClasses + lds class; kind 0 (general kernel) sorts last
-	std::vector<std::vector<int32_t>> bucket(6 * kNumLdsClasses);
+	// bucket = kind * classes + lds class
+	std::vector<std::vector<int32_t>> bucket(PSVR_DP_NUM_KINDS * kNumLdsClasses);
 	std::vector<int64_t> poff(n, 0);
 	int64_t pslab = 0;
 	for (int64_t i = 0; i < n; ++i) {
@@ -131,18 +110,12 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 			delete pl;
 			return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld: qlen=%d tlen=%d exceeds %d", (long long)i, ql, tl, kMaxLen);
 		}
-		int kind = 0, need;
-		if (ql <= 0 || tl <= 0 || pl->P.skip) { kind = 1; need = 0; }
-		else {
-			int T = (tl + 15) / 16 * 16;
-			need = reg_lds_need(ql, tl, par->w);
-			if (fast_ok && T <= 320 && need <= kMaxLds) kind = (T + 63) / 64;
-			else {
-				need = lds_kernel_need(ql, tl, variant);
-				if (need > kMaxLds) { delete pl; return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld needs %d B of LDS", (long long)i, need); }
-				poff[i] = pslab;
-				pslab += (p_bytes(ql, tl, par->w) + 255) & ~(int64_t)255;
-			}
+		int need = 0;
+		int kind = dp_classify(ql, tl, par->w, fast_ok, variant, pl->P.skip != 0, &need);
+		if (kind < 0) { delete pl; return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld needs %d B of LDS", (long long)i, need); }
+		if ((kind == 0 || kind > 5) && ql > 0 && tl > 0) {
+			poff[i] = pslab;
+			pslab += (dp_p_bytes(ql, tl, par->w) + 255) & ~(int64_t)255;
 		}
 		int cls = 0;
 		while (kLdsClasses[cls] < need) ++cls;
@@ -150,18 +123,17 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	}
 	std::vector<int32_t> idx;
 	idx.reserve(n);
-	// largest LDS classes first (longest-running workgroups first), general kernel first of all
-	const int kind_order[6] = {0, 5, 4, 3, 2, 1};
-	for (int ko = 0; ko < 6; ++ko)
+	// general kernel first, then the HBM-direction-byte kernels, then the LDS ones; large LDS classes first
+	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
+	for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 		for (int cls = kNumLdsClasses - 1; cls >= 0; --cls) {
 			auto &b = bucket[kind_order[ko] * kNumLdsClasses + cls];
 			if (b.empty()) continue;
 			Launch L{kind_order[ko], kLdsClasses[cls], (int64_t)idx.size(), (int64_t)b.size()};
 			pl->launches.push_back(L);
 			idx.insert(idx.end(), b.begin(), b.end());
-			char buf[128];
-			snprintf(buf, sizeof buf, "%s[lds=%d] x%lld; ", L.kind ? ("extd2_reg<" + std::to_string(L.kind) + ">").c_str() : (variant ? "extz2_lds" : "extd2_lds"),
-			         L.lds_bytes, (long long)L.count);
+			char buf[160];
+			snprintf(buf, sizeof buf, "%s[lds=%d] x%lld; ", dp_kind_name(L.kind, variant), L.lds_bytes, (long long)L.count);
 			pl->desc += buf;
 		}
 	pl->pslab_bytes = pslab;
@@ -175,12 +147,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 		PSVR_HIP(hipMemcpy(pl->d_qlen.p, qlen, n * 4, hipMemcpyHostToDevice));
 		PSVR_HIP(hipMemcpy(pl->d_tlen.p, tlen, n * 4, hipMemcpyHostToDevice));
 	}
-	// allow > 64 KiB of dynamic LDS on every kernel we may launch
-#define PSVR_ATTR(k) PSVR_HIP(hipFuncSetAttribute((const void *)(k), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
-	PSVR_ATTR(extd2_reg_kernel<1>); PSVR_ATTR(extd2_reg_kernel<2>); PSVR_ATTR(extd2_reg_kernel<3>);
-	PSVR_ATTR(extd2_reg_kernel<4>); PSVR_ATTR(extd2_reg_kernel<5>);
-	PSVR_ATTR(extd2_lds_kernel<0>); PSVR_ATTR(extd2_lds_kernel<1>);
-#undef PSVR_ATTR
+	PSVR_HIP(dp_allow_big_lds());
 	*out = pl;
 	return PSVR_OK;
 }
@@ -212,17 +179,7 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 	B.pslab = (uint8_t *)d_work, B.p_off = pl->d_poff.as<int64_t>(), B.p_unit_shift = 0;
 	for (const Launch &L : pl->launches) {
 		B.idx = pl->d_idx.as<int32_t>() + L.first;
-		dim3 grid((unsigned)L.count), block(64);
-		switch (L.kind) {
-		case 1: hipLaunchKernelGGL(extd2_reg_kernel<1>, grid, block, L.lds_bytes, stream, B, pl->P); break;
-		case 2: hipLaunchKernelGGL(extd2_reg_kernel<2>, grid, block, L.lds_bytes, stream, B, pl->P); break;
-		case 3: hipLaunchKernelGGL(extd2_reg_kernel<3>, grid, block, L.lds_bytes, stream, B, pl->P); break;
-		case 4: hipLaunchKernelGGL(extd2_reg_kernel<4>, grid, block, L.lds_bytes, stream, B, pl->P); break;
-		case 5: hipLaunchKernelGGL(extd2_reg_kernel<5>, grid, block, L.lds_bytes, stream, B, pl->P); break;
-		default:
-			if (pl->variant == 0) hipLaunchKernelGGL(extd2_lds_kernel<0>, grid, block, L.lds_bytes, stream, B, pl->P);
-			else hipLaunchKernelGGL(extd2_lds_kernel<1>, grid, block, L.lds_bytes, stream, B, pl->P);
-		}
+		dp_launch_kind(L.kind, pl->variant, (unsigned)L.count, L.lds_bytes, stream, B, pl->P);
 		PSVR_HIP(hipGetLastError());
 	}
 	return PSVR_OK;

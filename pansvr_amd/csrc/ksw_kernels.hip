@@ -23,7 +23,7 @@ __device__ __forceinline__ void write_ez(psvr_extz_t *o, const EzAcc &a, int n_c
 // ------------------------------------------------------------------------------------------
 // fast path
 // ------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool PG>
 __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 {
 	extern __shared__ __align__(16) uint8_t lds[];
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 	const int n_rows = qlen + tlen - 1;
 	const int qimg = (qlen + 16 + 15) & ~15;
 	uint8_t *QR = lds;                 // reversed query + >=16 zero bytes (the calloc'ed tail of `qr`, :100,121)
-	uint8_t *Pm = lds + qimg;          // direction bytes, row pitch rowb (:115)
+	// direction bytes, row pitch rowb (:115): behind the query image in LDS, or (PG) in this problem's slice of the HBM slab
+	uint8_t *Pm = PG ? B.pslab + (B.p_off[pid] << B.p_unit_shift) : lds + qimg;
 	const int p_end = n_rows * rowb + 16;
 	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
 
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 	}
 	int n_cigar = 0;
 	if (with_cigar) {
+		if (PG) __threadfence_block();
 		__syncthreads();
 		int i0 = -1, j0 = -1;
 		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
@@ -157,23 +159,31 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 			// ops are staged in the already-consumed tail of the direction-byte area (rows > r are dead)
 			uint32_t *stage_end = (uint32_t*)(Pm + p_end);
 			n_cigar = traceback(i0, j0, qlen, tlen, w,
-				[&](int r, int k) { return (int)Pm[r * rowb + k]; },
+				[&](int r, int k) { return PG ? (int)__builtin_nontemporal_load(Pm + (size_t)r * rowb + k) : (int)Pm[r * rowb + k]; },
 				[&](int k, uint32_t word) { if (lane == 0) stage_end[-1 - k] = word; });
+			if (PG) __threadfence_block();
 			__syncthreads();
 			uint32_t *dst = B.cigar + out->cigar_off;
 			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
-			for (int m = lane; m < n_cigar; m += 64)
-				dst[m] = rev ? stage_end[-1 - m] : stage_end[-n_cigar + m];
+			for (int m = lane; m < n_cigar; m += 64) {
+				const uint32_t *src = rev ? stage_end - 1 - m : stage_end - n_cigar + m;
+				dst[m] = PG ? __builtin_nontemporal_load(src) : *src;
+			}
 		}
 	}
 	if (lane == 0) write_ez(out, ez, n_cigar);
 }
 
-template __global__ void extd2_reg_kernel<1>(DpBatch, DpParams);
-template __global__ void extd2_reg_kernel<2>(DpBatch, DpParams);
-template __global__ void extd2_reg_kernel<3>(DpBatch, DpParams);
-template __global__ void extd2_reg_kernel<4>(DpBatch, DpParams);
-template __global__ void extd2_reg_kernel<5>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<1, false>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<2, false>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<3, false>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<4, false>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<5, false>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<1, true>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<2, true>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<3, true>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<4, true>(DpBatch, DpParams);
+template __global__ void extd2_reg_kernel<5, true>(DpBatch, DpParams);
 
 
 // ------------------------------------------------------------------------------------------
