@@ -147,7 +147,7 @@ struct Ctx {
 	// force[4r] N draws by the residues force[4r+1..3]
 	const uint8_t *force;
 	// per read
-	uint8_t *active; uint8_t *unmapped; uint8_t *is_str;
+	uint8_t *active; uint8_t *unmapped; uint8_t *is_str; uint8_t *has_n4;
 	int32_t *read_l;
 	uint8_t *bin;                // [read][2][lmax]
 	uint64_t *rb;                // [read][2][wmax]
@@ -204,6 +204,31 @@ PSVR_HD void hash_pair(const DevIndex &ix, uint64_t h, uint64_t &lo, uint64_t &h
 
 PSVR_HD int base_at(const uint64_t *w, uint64_t i) { return (int)((w[i >> 5] >> ((31 - (i & 0x1f)) << 1)) & 3); }
 
+// 32 bases starting at base offset `i` of a 2-bit packed sequence (MSB first), as one word
+PSVR_HD uint64_t window32(const uint64_t *w, uint64_t i)
+{
+	uint64_t k = i >> 5, sh = (i & 31) << 1;
+	uint64_t a = w[k];
+	return sh ? (a << sh) | (w[k + 1] >> (64 - sh)) : a;
+}
+// number of positions j < len with A[ia + j] != B[ib + j] (both 2-bit packed); stops counting once `cap` is reached
+PSVR_HD int mismatches_packed(const uint64_t *A, uint64_t ia, const uint64_t *B, uint64_t ib, int len, int cap)
+{
+	int nm = 0;
+	for (int j = 0; j < len && nm < cap; j += 32) {
+		uint64_t x = window32(A, ia + j) ^ window32(B, ib + j);
+		x = (x | (x >> 1)) & 0x5555555555555555ull;
+		int rem = len - j;
+		if (rem < 32) x &= ~0ull << ((32 - rem) << 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+		nm += __popcll(x);
+#else
+		nm += __builtin_popcountll(x);
+#endif
+	}
+	return nm < cap ? nm : cap;
+}
+
 // ---------------------------------------------------------------------------------------------
 // prep: parse-independent part of single_end_handler::align up to binary_read_2_bit (rr.cpp:406-416,646-654)
 // ---------------------------------------------------------------------------------------------
@@ -251,6 +276,7 @@ PSVR_HDN inline void prep_read(const Ctx &c, long long read)
 		w1[i >> 5] |= ((uint64_t)b1[i]) << ((31 - (i & 0x1f)) << 1);
 	}
 	c.rcnt[item] = draws;
+	{ uint8_t any4 = 0; for (int i = 0; i < L; ++i) any4 |= b0[i] > 3; c.has_n4[read] = any4; }
 	stat_add(c, ST_READS, 1);
 }
 
@@ -696,6 +722,8 @@ PSVR_HD void get_refseq(const DevIndex &ix, uint8_t *ref, uint32_t len, uint32_t
 struct WalkState {
 	const Ctx *c;
 	const uint8_t *read_str;
+	const uint64_t *read_w;      // the same strand 2-bit packed (exact unless the read holds a lower-case 'n', code 4)
+	bool packed_ok;
 	long long read; int strand;
 	int32_t read_score; uint32_t total_q_len;
 	bool is_simple;
@@ -716,8 +744,9 @@ PSVR_HD int walk_mismatch(WalkState &w, int read_st, int read_ed, int ref_st, in
 	if (ref_ed < ref_st) tlen = 0, qlen += (ref_st - ref_ed);
 	if (!(tlen < 1600)) { w.bad = 2; return 0; }
 	int nm = 0;
-	for (uint32_t i = 0; i < qlen && i < tlen; ++i) nm += w.read_str[read_st + i] != base_at(w.c->idx.ref_seq, (uint64_t)ref_st + i);
-	// (qlen == tlen on this call path; bases past tlen would be stale scratch in the reference)
+	const uint32_t n = qlen < tlen ? qlen : tlen;   // (qlen == tlen on this call path; bases past tlen would be stale scratch in the reference)
+	if (w.packed_ok) nm = mismatches_packed(w.read_w, (uint64_t)read_st, w.c->idx.ref_seq, (uint64_t)ref_st, (int)n, 0x7fffffff);
+	else for (uint32_t i = 0; i < n; ++i) nm += w.read_str[read_st + i] != base_at(w.c->idx.ref_seq, (uint64_t)ref_st + i);
 	return nm > 3 ? 3 : nm;
 }
 
@@ -735,7 +764,11 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 		w.is_simple = true;
 		nm = qlen + tlen;
 	} else if (qlen == tlen || type != 2) {
-		if (type == 0) {   // left extension compares the reversed sequences
+		if (w.packed_ok && tlen >= qlen) {
+			// the reference counts position-wise mismatches up to 6; a left extension compares the reversed sequences, i.e. the
+			// read piece against the LAST qlen bases of the reference window
+			nm = (uint32_t)mismatches_packed(w.read_w, (uint64_t)read_st, c.idx.ref_seq, (uint64_t)ref_st + (type == 0 ? tlen - qlen : 0), (int)qlen, 6);
+		} else if (type == 0) {   // left extension compares the reversed sequences
 			for (uint32_t i = 0; i < qlen && nm < 6; ++i) {
 				int tb = i < tlen ? base_at(c.idx.ref_seq, (uint64_t)ref_st + (tlen - 1 - i)) : 0;
 				nm += w.read_str[read_st + (qlen - 1 - i)] != tb;
@@ -797,6 +830,7 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
 	if (so < 0) return;
 	WalkState w;
 	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
+	w.read_w = c.rb + (read * 2 + is_rev) * (long long)c.wmax, w.packed_ok = c.has_n4[read] == 0;
 	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap;
 	const int BIG = 0x7fffffff;
 	int aln_read_begin = read_l, aln_read_end = read_l, aln_ref_begin = BIG, aln_ref_end = BIG;

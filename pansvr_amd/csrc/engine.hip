@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
 	const long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0);
 	int draws = 0;
+	bool any4 = false;
 	for (int i0 = 0; i0 < L; i0 += 64) {
 		const int i = i0 + lane;
 		char ch = i < L ? s[i] : 'A';
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 		draws += __popcll(m);
 		const uint8_t code = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0;
 		if (i < L) codes[i] = code, b0[i] = code, b1[L - 1 - i] = code ^ 3;
+		any4 |= __ballot(i < L && code > 3) != 0;
 	}
+	if (lane == 0) c.has_n4[read] = any4;
 	// packed words of both strands (binary_read_64_bit, rr.cpp:295-300): word = OR of code << 2*(31 - (i & 31)); a code of 4
 	// (lower-case n) spills its third bit into the neighbouring base exactly as the reference's shift does
 	for (int s2 = 0; s2 < 2; ++s2) {
@@ -98,10 +101,10 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	if (lane == 0) { c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1); }
 }
 
-// STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are staged in LDS and every lane
-// counts the equals of its own k-mers against all of them (LDS broadcast reads) -- same result as the
-// per-read std::map of the reference / str_detect() in aln_device.h, without its O(n^2) per thread.
-__global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *work, long long n, int mate, int kmax)
+// STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are counted in an open-addressing hash
+// table in LDS (64-bit compare-and-swap inserts, linear probing) -- same counts as the reference's per-read std::map /
+// str_detect() in aln_device.h, independent of insertion order.
+__global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *work, long long n, int mate, int tsize, int per_wave)
 {
 	extern __shared__ __align__(16) uint8_t str_lds[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -109,25 +112,39 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 	if (wi >= n) return;
 	const long long read = pair_of(work, wi) * 2 + mate;
 	if (!c.active[read]) return;
-	uint64_t *km = (uint64_t *)(str_lds + (size_t)wave * ((size_t)kmax * 9 + 16));
-	uint8_t *sl = (uint8_t *)(km + kmax);
+	unsigned long long *key = (unsigned long long *)(str_lds + (size_t)wave * (size_t)per_wave);   // keys | counts | seed_list staging
+	unsigned int *cnt = (unsigned int *)(key + tsize);
+	const unsigned long long EMPTY = ~0ull;               // a 20-mer has 40 significant bits
+	const unsigned mask = (unsigned)tsize - 1;
+	for (int i = lane; i < tsize; i += 64) key[i] = EMPTY, cnt[i] = 0;
 	const int L = c.read_l[read];
 	const uint64_t *rb = c.rb + (read * 2) * (long long)c.wmax;
 	const int kn = L - kLenKmer + 1;
-	for (int i = lane; i < kn; i += 64) km[i] = get_kmer((uint32_t)i, rb);
 	int distinct = 0;
 	for (int i0 = 0; i0 < kn; i0 += 64) {
 		const int i = i0 + lane;
-		const uint64_t mine = i < kn ? km[i] : 0;
-		int cnt = 0, earlier = 0;
-		for (int j = 0; j < kn; ++j) {
-			const bool eq = km[j] == mine;
-			cnt += eq, earlier += eq && j < i;
+		bool fresh = false;
+		if (i < kn) {
+			const unsigned long long km = get_kmer((uint32_t)i, rb);
+			unsigned h = (unsigned)((km * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+			for (;;) {
+				unsigned long long old = atomicCAS(&key[h], EMPTY, km);
+				if (old == EMPTY) { fresh = true; atomicAdd(&cnt[h], 1u); break; }
+				if (old == km) { atomicAdd(&cnt[h], 1u); break; }
+				h = (h + 1) & mask;
+			}
 		}
-		if (i < kn) sl[i] = cnt >= 4 ? 0 : 1;
-		distinct += __popcll(__ballot(i < kn && earlier == 0));
+		distinct += __popcll(__ballot(fresh));
 	}
 	if (!((uint32_t)distinct < (uint32_t)kn - 15u)) { if (lane == 0) c.is_str[read] = 0; return; }
+	// an STR read (rare): per-offset mask, then the begin/end rules, staged in the table's tail
+	uint8_t *sl = (uint8_t *)(cnt + tsize);
+	for (int i = lane; i < kn; i += 64) {
+		const unsigned long long km = get_kmer((uint32_t)i, rb);
+		unsigned h = (unsigned)((km * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+		while (key[h] != km) h = (h + 1) & mask;
+		sl[i] = cnt[h] >= 4 ? 0 : 1;
+	}
 	if (lane == 0) {
 		c.is_str[read] = 1;
 		int bg = 0, ed = 0;
@@ -163,13 +180,14 @@ __global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *work, l
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) select_read(c, pair_of(work, i) * 2 + mate);
 }
-__global__ __launch_bounds__(64) void k_walk(Ctx c, const int32_t *work, long long n)
+__global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *work, long long n)
 {
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per (read, candidate slot)
-	if (i >= 24 * n) return;
-	long long r = pair_of(work, i / 24) * 2 + ((i / 12) & 1);
-	int k = (int)(i % 12);
-	if (c.active[r] && k < c.n_ccand[r]) walk_candidate(c, r, k);
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
+	if (i >= 2 * n) return;
+	long long r = pair_of(work, i >> 1) * 2 + (i & 1);
+	if (!c.active[r]) return;
+	const int nc = c.n_ccand[r];
+	for (int k = 0; k < nc; ++k) walk_candidate(c, r, k);
 }
 __global__ __launch_bounds__(64) void k_assemble(Ctx c, long long begin, long long end)
 {
@@ -454,10 +472,13 @@ struct GpuBE {
 	void st_str(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n <= 0) return;
-		const int kmax = c.lmax;                                  // >= L - 19 k-mers
-		const size_t lds = (size_t)(kBlock / 64) * ((size_t)kmax * 9 + 16);
+		int tsize = 256;                                          // >= 2 x (L - 19) k-mers, power of two
+		while (tsize < 2 * c.lmax) tsize <<= 1;
+		// per wave: tsize keys (8 B) + tsize counts (4 B); the seed_list staging (<= lmax bytes) reuses the space behind them
+		const size_t per_wave = (size_t)tsize * 12 + (((size_t)c.lmax + 15) & ~(size_t)15);
+		const size_t lds = (size_t)(kBlock / 64) * per_wave;
 		t0("k_str_detect");
-		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), lds, stream, c, w, n, mate, kmax);
+		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), lds, stream, c, w, n, mate, tsize, (int)per_wave);
 		t1();
 		note(hipGetLastError());
 	}
@@ -467,7 +488,7 @@ struct GpuBE {
 		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n, blk)), dim3(blk), 0, stream, c, w, n); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
-	PSVR_STAGE(st_walk, k_walk, 24, 64)
+	PSVR_STAGE(st_walk, k_walk, 2, kBlock)
 	PSVR_STAGE(st_finalize, k_finalize, 2, kBlock)
 	PSVR_STAGE(st_pair, k_pair, 1, kBlock)
 #undef PSVR_STAGE
