@@ -333,6 +333,100 @@ PSVR_HD uint8_t seed_list_at(const uint8_t *sl, int len, int rev, int i)
 	return sl[len - 1 - i];
 }
 
+PSVR_HD int clz64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __clzll((long long)x);
+#else
+	return __builtin_clzll(x);
+#endif
+}
+PSVR_HD int ctz64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __ffsll((unsigned long long)x) - 1;
+#else
+	return __builtin_ctzll(x);
+#endif
+}
+// number of consecutive j in [0,max) with A[ia + j] == B[ib + j] (2-bit packed, 32 bases per step)
+PSVR_HD uint32_t match_right(const uint64_t *A, uint64_t ia, const uint64_t *B, uint64_t ib, uint32_t max)
+{
+	uint32_t n = 0;
+	while (n < max) {
+		uint64_t x = window32(A, ia + n) ^ window32(B, ib + n);
+		x = (x | (x >> 1)) & 0x5555555555555555ull;
+		uint32_t lim = max - n < 32 ? max - n : 32;
+		if (x) { uint32_t k = (uint32_t)clz64(x) >> 1; return n + (k < lim ? k : lim); }
+		n += lim;
+	}
+	return max;
+}
+// number of consecutive j in [0,max) with A[ia - 1 - j] == B[ib - 1 - j]; requires ia >= max and ib >= max
+PSVR_HD uint32_t match_left(const uint64_t *A, uint64_t ia, const uint64_t *B, uint64_t ib, uint32_t max)
+{
+	uint32_t n = 0;
+	while (n < max) {
+		uint32_t lim = max - n < 32 ? max - n : 32;
+		uint64_t x = window32(A, ia - n - lim) ^ window32(B, ib - n - lim);   // bases 0..lim-1 of the windows are the lim bases left of the cursor
+		x = (x | (x >> 1)) & 0x5555555555555555ull;
+		if (lim < 32) x &= ~0ull << ((32 - lim) << 1);
+		if (x) { uint32_t k = ((uint32_t)ctz64(x) - ((32 - lim) << 1)) >> 1; return n + k; }
+		n += lim;
+	}
+	return max;
+}
+
+// search_kmer (deBGA_index.cpp:84-101) + binsearch_range with k_off = 4 (binarys_qsort.c:25-100): index range of the 22-mers
+// whose first 20 bases equal `kmer`; returns the number of hits (0 = not found) and the first hit index
+PSVR_HD uint32_t probe_kmer(const DevIndex &ix, uint64_t kmer, uint64_t &first_hit)
+{
+	const uint64_t key = kmer & 0xfff, h = kmer >> 12;
+	uint64_t lo, hi;
+	hash_pair(ix, h, lo, hi);
+	long long l = 0, r = (long long)(hi - lo) - 1, first = -1, last = -1;
+	const uint32_t *v = ix.kmer + lo;
+	while (l <= r) {
+		long long m = (l + r) / 2;
+		uint32_t t = v[m] >> 4;
+		if (t == key) {
+			first = last = m;
+			long long sl2 = l, sr = m - 1;
+			while (sl2 <= sr) { long long sm = (sl2 + sr) / 2; uint32_t t2 = v[sm] >> 4; if (t2 == key) first = sm, sr = sm - 1; else if (t2 > key) sr = sm - 1; else sl2 = sm + 1; }
+			sl2 = m + 1, sr = r;
+			while (sl2 <= sr) { long long sm = (sl2 + sr) / 2; uint32_t t2 = v[sm] >> 4; if (t2 == key) last = sm, sl2 = sm + 1; else if (t2 > key) sr = sm - 1; else sl2 = sm + 1; }
+			break;
+		} else if (t > key) r = m - 1;
+		else l = m + 1;
+	}
+	if (first < 0) return 0;
+	first_hit = lo + (uint64_t)first;
+	return (uint32_t)(last - first + 1);
+}
+
+// UNITIG_MEM_search (deBGA_index.cpp:105-146) for index entry `hit`; returns right_i
+PSVR_HD uint32_t mem_for_hit(const DevIndex &ix, uint64_t hit, const uint64_t *rb, uint32_t off, int L, VMem &m)
+{
+	const uint64_t kp = ix.off[hit];
+	long long lo2 = 0, hi2 = (long long)ix.n_seqf - 1, uid = -1;
+	while (lo2 <= hi2) {                                    // binsearch_interval_unipath64 (binarys_qsort.c:162-187)
+		long long mid = (lo2 + hi2) >> 1;
+		uint64_t sv = ix.seqf[mid];
+		if (kp < sv) hi2 = mid - 1;
+		else if (kp > sv) lo2 = mid + 1;
+		else { uid = mid; break; }
+	}
+	if (uid < 0) uid = hi2;
+	const uint64_t f0 = ix.seqf[uid], f1 = ix.seqf[uid + 1];
+	const uint32_t ul = (uint32_t)(kp - f0), ur = (uint32_t)(f1 - (kp + kLenKmer));
+	const uint32_t lmax = ul < off ? ul : off, rmax0 = (uint32_t)(L - (int)off - kLenKmer), rmax = ur < rmax0 ? ur : rmax0;
+	const uint32_t li = 1 + match_left(ix.seq, kp, rb, off, lmax);
+	const uint32_t ri = 1 + match_right(ix.seq, kp + kLenKmer, rb, (uint64_t)off + kLenKmer, rmax);
+	m.uid = (uint64_t)uid, m.seed_id = 0, m.read_pos = off + 1 - li, m.uni_pos_off = ul + 1 - li;
+	m.length = kLenKmer + li + ri - 2, m.pos_n = (uint32_t)(ix.posp[uid + 1] - ix.posp[uid]), m.pad = 0;
+	return ri;
+}
+
 // seed loop of chainning_one_read (rr.cpp:614-635) for one strand: search_kmer + binsearch_range
 // (deBGA_index.cpp:84-101, binarys_qsort.c:25-100) and UNITIG_MEM_search (deBGA_index.cpp:105-146)
 PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
@@ -357,51 +451,17 @@ PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
 			if (off + kLenKmer - 1 <= msr) continue;
 			if (is_str && seed_list_at(sl, (int)kn, rev, off) == 0) continue;
 			uint64_t kmer = get_kmer(off, rb);
-			uint64_t key = kmer & 0xfff, h = kmer >> 12;
-			uint64_t lo, hi;
-			hash_pair(ix, h, lo, hi);
 			if (pass == 0) ++probes;
-			long long l = 0, r = (long long)(hi - lo) - 1, first = -1, last = -1;
-			const uint32_t *v = ix.kmer + lo;
-			while (l <= r) {                                            // binsearch_range with k_off = 4
-				long long m = (l + r) / 2;
-				uint32_t t = v[m] >> 4;
-				if (t == key) {
-					first = last = m;
-					long long sl2 = l, sr = m - 1;
-					while (sl2 <= sr) { long long sm = (sl2 + sr) / 2; uint32_t t2 = v[sm] >> 4; if (t2 == key) first = sm, sr = sm - 1; else if (t2 > key) sr = sm - 1; else sl2 = sm + 1; }
-					sl2 = m + 1, sr = r;
-					while (sl2 <= sr) { long long sm = (sl2 + sr) / 2; uint32_t t2 = v[sm] >> 4; if (t2 == key) last = sm, sl2 = sm + 1; else if (t2 > key) sr = sm - 1; else sl2 = sm + 1; }
-					break;
-				} else if (t > key) r = m - 1;
-				else l = m + 1;
-			}
-			if (first < 0) continue;
-			if ((uint64_t)(last - first + 1) > (uint64_t)kUniPosNMax) continue;
+			uint64_t first_hit = 0;
+			const uint32_t nh = probe_kmer(ix, kmer, first_hit);
+			if (nh == 0) continue;
+			if (nh > (uint32_t)kUniPosNMax) continue;
 			uint32_t mri = 1;
-			for (long long hit = (long long)lo + first; hit <= (long long)lo + last; ++hit) {
-				uint64_t kp = ix.off[hit];
-				long long lo2 = 0, hi2 = (long long)ix.n_seqf - 1, uid = -1;
-				while (lo2 <= hi2) {                                    // binsearch_interval_unipath64
-					long long mid = (lo2 + hi2) >> 1;
-					uint64_t sv = ix.seqf[mid];
-					if (kp < sv) hi2 = mid - 1;
-					else if (kp > sv) lo2 = mid + 1;
-					else { uid = mid; break; }
-				}
-				if (uid < 0) uid = hi2;
-				uint64_t f0 = ix.seqf[uid], f1 = ix.seqf[uid + 1];
-				uint32_t ul = (uint32_t)(kp - f0), ur = (uint32_t)(f1 - (kp + kLenKmer));
-				uint32_t li, ri;
-				for (li = 1; li <= ul && li <= off; li++)
-					if (base_at(ix.seq, kp - li) != base_at(rb, off - li)) break;
-				for (ri = 1; ri <= ur && ri <= (uint32_t)(L - off - kLenKmer); ri++)
-					if (base_at(ix.seq, kp + kLenKmer - 1 + ri) != base_at(rb, off + kLenKmer - 1 + ri)) break;
-				if (pass == 2 || n < (uint32_t)kMemSlot) {
-					VMem &m = c.mem.base[base + n];
-					m.uid = (uint64_t)uid, m.seed_id = n, m.read_pos = off + 1 - li, m.uni_pos_off = ul + 1 - li;
-					m.length = kLenKmer + li + ri - 2, m.pos_n = (uint32_t)(ix.posp[uid + 1] - ix.posp[uid]), m.pad = 0;
-				}
+			for (uint64_t hit = first_hit; hit < first_hit + nh; ++hit) {
+				VMem m;
+				const uint32_t ri = mem_for_hit(ix, hit, rb, off, L, m);
+				m.seed_id = n;
+				if (pass == 2 || n < (uint32_t)kMemSlot) c.mem.base[base + n] = m;
 				++n;
 				if (ri > mri) mri = ri;
 			}
