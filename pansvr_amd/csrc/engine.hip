@@ -163,119 +163,11 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 	uint8_t *out = c.seed_list + read * (long long)c.lmax;
 	for (int i = lane; i < kn; i += 64) out[i] = sl[i];
 }
-// K1 seed_probe + K2 mem_extend, one wavefront per read: lanes 0-31 probe the forward strand, lanes 32-63 the reverse
-// complement, so the 16-byte hash gathers of all stride-5 probes of a read are in flight together instead of one after
-// another.  Every probe is evaluated (hash gather, bucket bisection, unipath bisection, word-wise MEM extension); the
-// reference's sequential rule "skip a probe that the previous MEM already covers" (rr.cpp:617,634) is applied afterwards by
-// one lane per strand over the staged per-probe results, which yields exactly the reference's MEM list.
-// Reads with more than kSeedPMax probes per strand or more than kSeedMemCap staged MEMs fall back to seed_strand().
-static const int kSeedPMax = 64, kSeedMemCap = 96;
-struct SeedLds {
-	VMem mems[2][kSeedMemCap];
-	uint16_t mri[2][kSeedPMax], moff[2][kSeedPMax];
-	uint8_t cnt[2][kSeedPMax], keep[2][kSeedPMax];
-	uint16_t base[2][kSeedPMax];
-	int total[2], kept[2];
-	long long dst[2];
-};
-__global__ __launch_bounds__(64) void k_seed(Ctx c, const int32_t *work, long long n, int mate)
+// K1 seed_probe + K2 mem_extend: hash gather, bucket search, unipath lookup, MEM extension
+__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n, int mate)
 {
-	__shared__ SeedLds S;
-	const int lane = threadIdx.x, half = lane >> 5, pl = lane & 31;
-	const long long wi = blockIdx.x;
-	if (wi >= n) return;
-	const long long read = pair_of(work, wi) * 2 + mate;
-	if (!c.active[read]) return;
-	const long long rs = read * 2 + half;
-	const int L = c.read_l[read];
-	const int kn = L - kLenKmer + 1;
-	const int nprobe = (kn + kSeedStep - 1) / kSeedStep;
-	if (nprobe > kSeedPMax) {                              // very long read: the per-strand serial path
-		if (pl == 0) seed_strand(c, rs);
-		return;
-	}
-	const uint64_t *rb = c.rb + rs * (long long)c.wmax;
-	const uint8_t *sl = c.seed_list + read * (long long)c.lmax;
-	const bool is_str = c.is_str[read] != 0;
-	const DevIndex &ix = c.idx;
-	unsigned probes = 0;
-	// phase A: every probe's hit range
-	uint64_t first_hit[2] = {0, 0};
-	for (int it = 0; it < 2; ++it) {
-		const int p = it * 32 + pl;
-		unsigned nh = 0;
-		if (p < nprobe) {
-			const uint32_t off = (uint32_t)p * kSeedStep;
-			if (!(is_str && seed_list_at(sl, kn, half, (int)off) == 0)) {
-				nh = probe_kmer(ix, get_kmer(off, rb), first_hit[it]);
-				++probes;
-				if (nh > (unsigned)kUniPosNMax) nh = 0;
-			}
-			S.cnt[half][p] = (uint8_t)nh;
-		}
-	}
-	__syncthreads();
-	if (pl == 0) {
-		int acc = 0;
-		for (int p = 0; p < nprobe; ++p) { S.moff[half][p] = (uint16_t)acc; acc += S.cnt[half][p]; }
-		S.total[half] = acc;
-	}
-	__syncthreads();
-	const bool fallback = S.total[half] > kSeedMemCap;
-	// phase B: MEMs of every hit
-	if (!fallback) {
-		for (int it = 0; it < 2; ++it) {
-			const int p = it * 32 + pl;
-			if (p >= nprobe) continue;
-			const unsigned nh = S.cnt[half][p];
-			unsigned mri = 1;
-			for (unsigned h = 0; h < nh; ++h) {
-				VMem m;
-				const uint32_t ri = mem_for_hit(ix, first_hit[it] + h, rb, (uint32_t)p * kSeedStep, L, m);
-				S.mems[half][S.moff[half][p] + h] = m;
-				if (ri > mri) mri = ri;
-			}
-			S.mri[half][p] = (uint16_t)mri;
-		}
-	}
-	__syncthreads();
-	// phase C: the reference's sequential MEM-skip over the probes, one lane per strand
-	if (pl == 0 && !fallback) {
-		uint32_t msr = 0;
-		int kept = 0;
-		for (int p = 0; p < nprobe; ++p) {
-			const uint32_t off = (uint32_t)p * kSeedStep;
-			uint8_t k = 0;
-			if (!(off + kLenKmer - 1 <= msr) && S.cnt[half][p] > 0) {
-				k = 1;
-				S.base[half][p] = (uint16_t)kept;
-				kept += S.cnt[half][p];
-				msr = off + kLenKmer + S.mri[half][p] - 1;
-			}
-			S.keep[half][p] = k;
-		}
-		S.kept[half] = kept;
-		long long dst = rs * (long long)kMemSlot;
-		if (kept > kMemSlot) dst = arena_alloc(c.mem, (unsigned long long)kept);
-		S.dst[half] = dst;
-		Strand &st = c.strand[rs];
-		st.mem_off = dst < 0 ? 0 : dst, st.mem_n = dst < 0 ? 0 : (uint32_t)kept;
-	}
-	__syncthreads();
-	if (fallback) { if (pl == 0) seed_strand(c, rs); return; }
-	const long long dst = S.dst[half];
-	if (dst >= 0) {
-		for (int it = 0; it < 2; ++it) {
-			const int p = it * 32 + pl;
-			if (p >= nprobe || !S.keep[half][p]) continue;
-			for (unsigned h = 0; h < S.cnt[half][p]; ++h) {
-				VMem m = S.mems[half][S.moff[half][p] + h];
-				m.seed_id = S.base[half][p] + h;
-				c.mem.base[dst + m.seed_id] = m;
-			}
-		}
-	}
-	if (c.stats) { stat_add(c, ST_PROBES, probes); if (pl == 0) stat_add(c, ST_HITS, (unsigned long long)S.kept[half]); }
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < 2 * n) seed_strand(c, (pair_of(work, i >> 1) * 2 + mate) * 2 + (i & 1));
 }
 // K3 chain: merge, expand, sort, sparse chaining DP
 __global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *work, long long n, int mate)
@@ -565,6 +457,7 @@ struct GpuBE {
 		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n)), dim3(kBlock), 0, stream, c, w, n, mate); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
+	PSVR_STAGE_M(st_seed, k_seed, 2)
 	PSVR_STAGE_M(st_chain, k_chain, 1)
 	PSVR_STAGE_M(st_select, k_select, 1)
 #undef PSVR_STAGE_M
@@ -573,14 +466,6 @@ struct GpuBE {
 		if (n <= 0) return;
 		t0("k_prep");
 		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * c.lmax, stream, c, w, n, mate);
-		t1();
-		note(hipGetLastError());
-	}
-	void st_seed(const Ctx &c, const int32_t *w, long long n, int mate)
-	{
-		if (n <= 0) return;
-		t0("k_seed");
-		hipLaunchKernelGGL(k_seed, dim3((unsigned)n), dim3(64), 0, stream, c, w, n, mate);
 		t1();
 		note(hipGetLastError());
 	}
