@@ -53,6 +53,9 @@ struct DevIndex {
 	const uint32_t *chr_end_n, *chr_search_index;
 	const SvDev *sv;
 	int32_t chr_file_n;
+	// 1 bit per first-level bucket (32 MiB, stays resident in the 256 MiB Infinity Cache): set iff the bucket holds a k-mer.
+	// ~85 % of all probes (wrong strand, unrelated reads, mismatching positions) end here without touching the 2 GiB table.
+	const uint32_t *occ;
 	// tests/emu only (PSVR_EMU_SPARSE_HASH): non-empty first-level buckets instead of the dense 2 GiB table
 	const uint32_t *sp_id; const uint64_t *sp_start; uint64_t sp_n, n_kmer;
 };
@@ -198,6 +201,7 @@ PSVR_HD void hash_pair(const DevIndex &ix, uint64_t h, uint64_t &lo, uint64_t &h
 	};
 	lo = at(h), hi = at(h + 1);
 #else
+	if (ix.occ && !((ix.occ[h >> 5] >> (h & 31)) & 1u)) { lo = hi = 0; return; }
 	lo = ix.hash[h], hi = ix.hash[h + 1];
 #endif
 }

@@ -642,10 +642,21 @@ using namespace psvr;
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
+__global__ void k_build_occupancy(const uint64_t *hash, uint32_t *occ, long long nwords)
+{
+	long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (w >= nwords) return;
+	uint32_t bits = 0;
+	const uint64_t *h = hash + w * 32;
+	uint64_t prev = h[0];
+	for (int b = 0; b < 32; ++b) { uint64_t nx = h[b + 1]; bits |= (uint32_t)(nx != prev) << b; prev = nx; }
+	occ[w] = bits;
+}
+
 struct psvr_index {
 	int device = 0;
 	HostIndex host;          // small tables + strings stay on the host too (SAM formatting)
-	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv;
+	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ;
 	DevIndex dev;
 	int64_t bytes = 0;
 };
@@ -678,6 +689,14 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v)
 	d.posp = ix->posp.as<uint64_t>(), d.hash = ix->hash.as<uint64_t>(), d.off = ix->off.as<uint64_t>(), d.kmer = ix->kmer.as<uint32_t>();
 	d.n_seqf = v->n_seqf, d.chr_end_n = ix->chr_end.as<uint32_t>(), d.chr_search_index = ix->chr_idx.as<uint32_t>(), d.sv = ix->sv.as<SvDev>();
 	d.chr_file_n = h.chr_file_n;
+	// occupancy bitmap of the first level, derived on the device from the uploaded table
+	const long long nwords = ((long long)1 << 28) / 32;
+	PSVR_HIP(ix->occ.alloc(nwords * 4));
+	ix->bytes += nwords * 4;
+	hipLaunchKernelGGL(k_build_occupancy, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, nullptr, d.hash, ix->occ.as<uint32_t>(), nwords);
+	PSVR_HIP(hipGetLastError());
+	PSVR_HIP(hipDeviceSynchronize());
+	d.occ = ix->occ.as<uint32_t>();
 	return PSVR_OK;
 }
 
