@@ -87,7 +87,10 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 		for (int c = K - 1; c >= 0; --c) {
 			if (c < c_first || c > c_last) continue;
 			const int t = c * 64 + lane;
-			if (en >= r && t == r) { y[c] = neg_qe; y2[c] = neg_qe2; u[c] = ur; }   // (:153-156)
+			// branch-free: every lane computes, the state of lanes outside [st,en] is kept by selects (v_cndmask)
+			const bool act = (t >= st) & (t <= en);
+			const bool ovr = (en >= r) & (t == r);                                  // (:153-156); lane r is always inside [st,en]
+			const int yy = ovr ? neg_qe : y[c], yy2 = ovr ? neg_qe2 : y2[c], ut = ovr ? ur : u[c];
 			int cx = 0, cv = 0, cx2 = 0;
 			if (c > 0) {
 				cx = __builtin_amdgcn_readlane(x[c - 1], 63);
@@ -95,45 +98,51 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 				cx2 = __builtin_amdgcn_readlane(x2[c - 1], 63);
 			}
 			int xt1 = dpp_wave_shr1(x[c], cx), vt1 = dpp_wave_shr1(v[c], cv), x2t1 = dpp_wave_shr1(x2[c], cx2);
-			if (t == st && !adv) { xt1 = neg_qe; x2t1 = neg_qe2; vt1 = st > 0 ? neg_qe : ur; }    // (:142-152)
-			if (t >= st0 && t <= fresh_end) {                 // fresh score (:158-173)
-				int qb = QR[qbase + t];
-				int sc = tb[c] == qb ? P.sc_mch : P.sc_mis;
-				s[c] = (tb[c] == P.m1 || qb == P.m1) ? P.sc_N : sc;
-			}
-			if (t >= st && t <= en) {
-				int z = s[c], ut = u[c];
-				int a = s8(xt1 + vt1), b = s8(y[c] + ut), a2 = s8(x2t1 + vt1), b2 = s8(y2[c] + ut);
-				int d = 0;
-				if (a > z)  d = 1, z = a;
-				if (b > z)  d = 2, z = b;
-				if (a2 > z) d = 3, z = a2;
-				if (b2 > z) d = 4, z = b2;
-				z = min(z, P.sc_mch);
-				int un = s8(z - vt1), vn = s8(z - ut);
-				int tmp = s8(z - P.q);
-				a = s8(a - tmp), b = s8(b - tmp);
-				tmp = s8(z - P.q2);
-				a2 = s8(a2 - tmp), b2 = s8(b2 - tmp);
-				u[c] = un, v[c] = vn;
-				x[c]  = s8(max(a, 0) - qe8);   d |= a  > 0 ? 0x08 : 0;
-				y[c]  = s8(max(b, 0) - qe8);   d |= b  > 0 ? 0x10 : 0;
-				x2[c] = s8(max(a2, 0) - qe28); d |= a2 > 0 ? 0x20 : 0;
-				y2[c] = s8(max(b2, 0) - qe28); d |= b2 > 0 ? 0x40 : 0;
-				if (with_cigar) prow[t] = (uint8_t)d;
-				// exact H tracking (:316-351)
-				if (r == 0) { if (t == 0) H[c] = vn - P.qe_pre; }
-				else if (t >= st0 && t < en0) H[c] += vn;
-				else if (t == en0) H[c] = en0 > 0 ? h_prev + un : H[c] + vn;
-				if (t >= st0 && t <= en0) {
-					unsigned rank = t == en0 ? 0u : t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
-					                                        : 1u + 4u * 4096u + (unsigned)(t - st0);
-					if (H[c] > bh || (H[c] == bh && rank < bk)) bh = H[c], bk = rank;
-				}
-			}
+			const bool bnd = (t == st) & !adv;                                       // (:142-152)
+			xt1 = bnd ? neg_qe : xt1, x2t1 = bnd ? neg_qe2 : x2t1, vt1 = bnd ? (st > 0 ? neg_qe : ur) : vt1;
+			const bool fresh = (t >= st0) & (t <= fresh_end);                          // fresh score (:158-173)
+			const int qb = QR[fresh ? qbase + t : 0];
+			int sc = tb[c] == qb ? P.sc_mch : P.sc_mis;
+			sc = ((tb[c] == P.m1) | (qb == P.m1)) ? P.sc_N : sc;
+			const int sv = fresh ? sc : s[c];
+			s[c] = sv;
+			int z = sv;
+			int a = s8(xt1 + vt1), b = s8(yy + ut), a2 = s8(x2t1 + vt1), b2 = s8(yy2 + ut);
+			int d = a > z ? 1 : 0;   z = max(z, a);
+			d = b > z ? 2 : d;       z = max(z, b);
+			d = a2 > z ? 3 : d;      z = max(z, a2);
+			d = b2 > z ? 4 : d;      z = max(z, b2);
+			z = min(z, P.sc_mch);
+			const int un = s8(z - vt1), vn = s8(z - ut);
+			int tmp = s8(z - P.q);
+			a = s8(a - tmp), b = s8(b - tmp);
+			tmp = s8(z - P.q2);
+			a2 = s8(a2 - tmp), b2 = s8(b2 - tmp);
+			d |= (a > 0 ? 0x08 : 0) | (b > 0 ? 0x10 : 0) | (a2 > 0 ? 0x20 : 0) | (b2 > 0 ? 0x40 : 0);
+			u[c] = act ? un : u[c], v[c] = act ? vn : v[c];
+			x[c] = act ? s8(max(a, 0) - qe8) : x[c];
+			y[c] = act ? s8(max(b, 0) - qe8) : y[c];
+			x2[c] = act ? s8(max(a2, 0) - qe28) : x2[c];
+			y2[c] = act ? s8(max(b2, 0) - qe28) : y2[c];
+			if (act & (with_cigar != 0)) prow[t] = (uint8_t)d;
+			// exact H tracking (:316-351)
+			const int hold = H[c];
+			int hn = (t == en0) ? (en0 > 0 ? h_prev + un : hold + vn) : (((t >= st0) & (t < en0)) ? hold + vn : hold);
+			hn = r == 0 ? (t == 0 ? vn - P.qe_pre : hold) : hn;
+			hn = act ? hn : hold;
+			H[c] = hn;
+			const bool valid = (t >= st0) & (t <= en0);
+			const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
+			                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
+			const bool better = valid & ((hn > bh) | ((hn == bh) & (rank < bk)));
+			bh = better ? hn : bh, bk = better ? rank : bk;
 		}
 		const int max_H = wave_max_i32(bh);
-		const unsigned rk = wave_min_u32(bh == max_H ? bk : 0xffffffffu);
+		// arg-max with the reference's tie order: usually one lane holds the maximum, then its rank is a single v_readlane
+		const unsigned long long top = __ballot(bh == max_H);
+		unsigned rk;
+		if (__popcll(top) == 1) rk = (unsigned)__builtin_amdgcn_readlane((int)bk, __ffsll((unsigned long long)top) - 1);
+		else rk = wave_min_u32(bh == max_H ? bk : 0xffffffffu);
 		const int max_t = rk == 0 ? en0 : st0 + (int)((rk - 1u) & 4095u);
 		int H_en0 = 0, H_st0 = 0;
 #pragma unroll
