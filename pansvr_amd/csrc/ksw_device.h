@@ -30,6 +30,7 @@ struct DpParams {
 	int32_t w, zdrop, end_bonus, flag;
 	int32_t long_thres, long_diff;
 	int32_t skip;               // 1: parameter set makes the reference return right after reset (:68,93)
+	int32_t nowrap_ok;          // in-band values provably fit int8 for these scoring parameters
 	int8_t  mat[25];
 };
 
@@ -44,6 +45,11 @@ struct DpBatch { // device pointers of one batch
 
 template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
+
+// true when the band [(r-w+1)>>1, (r+w)>>1] never clips the DP matrix: then st0/en0 follow the matrix edges only, every
+// in-band cell's (r-1,t-1)/(r-1,t) neighbours are in-band or one of the explicit boundary values (ksw2_extd2_sse.c:142-156),
+// and the lanes of the 16-rounded blocks outside the band are never read back
+__host__ __device__ inline bool dp_band_never_binds(int qlen, int tlen, int w) { return qlen <= w && tlen <= w + 1; }
 
 // ---- size classes shared by the host planner (ksw_host.hip) and the device-side planner (engine.hip)
 #define PSVR_DP_NUM_LDS_CLASSES 13

@@ -46,6 +46,14 @@ int make_dp_params(const psvr_ksw_params_t *par, int variant, DpParams *P)
 	int min_sc = par->mat[1];
 	for (int t = 1; t < m * m; ++t) min_sc = std::min<int>(min_sc, par->mat[t]);
 	if (-min_sc > 2 * (q + e)) { P->skip = 1; return PSVR_OK; }                 // :93
+	{
+		// in-band deltas of the difference recurrences stay within [-(q2+e2) - max_sc, max_sc + 2(q2+e2)] and the sums the
+		// kernel forms within twice that: far inside int8 for the usual scoring (2/-12, 16+1, 32+0 -> |v| <= 100)
+		int max_sc = par->mat[0];
+		for (int t = 1; t < m * m; ++t) max_sc = std::max<int>(max_sc, par->mat[t]);
+		int g = std::max(q + e, q2 + e2);
+		P->nowrap_ok = (max_sc + 3 * g + std::max(-min_sc, 0) <= 127) && q >= 0 && e >= 0 && q2 >= 0 && e2 >= 0;
+	}
 	if (variant == 0) {
 		int lt = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;                             // :95-98
 		if (q2 + e2 + lt * e2 > q + e + lt * e) ++lt;

@@ -23,33 +23,14 @@ __device__ __forceinline__ void write_ez(psvr_extz_t *o, const EzAcc &a, int n_c
 // ------------------------------------------------------------------------------------------
 // fast path
 // ------------------------------------------------------------------------------------------
-template <int K, bool PG>
-__global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
+// the anti-diagonal sweep.  WRAP = emulate the 8-bit wrap-around of every SSE add/sub (needed whenever an in-band cell can
+// read a lane outside the band); without it the arithmetic stays in 32 bits, which is value-identical when wrap cannot be
+// observed (see extd2_reg_kernel).
+template <int K, bool WRAP>
+__device__ __forceinline__ void dp_main_loop(const DpParams &P, const uint8_t *target, int lane, int qlen, int tlen, int w, int rowb, int n_rows,
+                                             const uint8_t *QR, uint8_t *Pm, EzAcc &ez)
 {
-	extern __shared__ __align__(16) uint8_t lds[];
-	const int pid = B.idx[blockIdx.x];
-	const int lane = threadIdx.x;
-	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
-	psvr_extz_t *out = B.ez + pid;
-	EzAcc ez;
-	ez.reset();
-	if (P.skip || qlen <= 0 || tlen <= 0) {
-		if (lane == 0) write_ez(out, ez, 0);
-		return;
-	}
-	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
-	const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
-	int n_col = qlen < tlen ? qlen : tlen;
-	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
-	const int rowb = n_col * 16;
-	const int n_rows = qlen + tlen - 1;
-	const int qimg = (qlen + 16 + 15) & ~15;
-	uint8_t *QR = lds;                 // reversed query + >=16 zero bytes (the calloc'ed tail of `qr`, :100,121)
-	// direction bytes, row pitch rowb (:115): behind the query image in LDS, or (PG) in this problem's slice of the HBM slab
-	uint8_t *Pm = PG ? B.pslab + (B.p_off[pid] << B.p_unit_shift) : lds + qimg;
-	const int p_end = n_rows * rowb + 16;
-	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
-
+#define W8(e) (WRAP ? s8(e) : (int)(e))
 	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
 	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
 	int u[K], v[K], x[K], y[K], x2[K], y2[K], s[K], H[K], tb[K];
@@ -107,23 +88,23 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 			const int sv = fresh ? sc : s[c];
 			s[c] = sv;
 			int z = sv;
-			int a = s8(xt1 + vt1), b = s8(yy + ut), a2 = s8(x2t1 + vt1), b2 = s8(yy2 + ut);
+			int a = W8(xt1 + vt1), b = W8(yy + ut), a2 = W8(x2t1 + vt1), b2 = W8(yy2 + ut);
 			int d = a > z ? 1 : 0;   z = max(z, a);
 			d = b > z ? 2 : d;       z = max(z, b);
 			d = a2 > z ? 3 : d;      z = max(z, a2);
 			d = b2 > z ? 4 : d;      z = max(z, b2);
 			z = min(z, P.sc_mch);
-			const int un = s8(z - vt1), vn = s8(z - ut);
-			int tmp = s8(z - P.q);
-			a = s8(a - tmp), b = s8(b - tmp);
-			tmp = s8(z - P.q2);
-			a2 = s8(a2 - tmp), b2 = s8(b2 - tmp);
+			const int un = W8(z - vt1), vn = W8(z - ut);
+			int tmp = W8(z - P.q);
+			a = W8(a - tmp), b = W8(b - tmp);
+			tmp = W8(z - P.q2);
+			a2 = W8(a2 - tmp), b2 = W8(b2 - tmp);
 			d |= (a > 0 ? 0x08 : 0) | (b > 0 ? 0x10 : 0) | (a2 > 0 ? 0x20 : 0) | (b2 > 0 ? 0x40 : 0);
 			u[c] = act ? un : u[c], v[c] = act ? vn : v[c];
-			x[c] = act ? s8(max(a, 0) - qe8) : x[c];
-			y[c] = act ? s8(max(b, 0) - qe8) : y[c];
-			x2[c] = act ? s8(max(a2, 0) - qe28) : x2[c];
-			y2[c] = act ? s8(max(b2, 0) - qe28) : y2[c];
+			x[c] = act ? W8(max(a, 0) - qe8) : x[c];
+			y[c] = act ? W8(max(b, 0) - qe8) : y[c];
+			x2[c] = act ? W8(max(a2, 0) - qe28) : x2[c];
+			y2[c] = act ? W8(max(b2, 0) - qe28) : y2[c];
 			if (act & (with_cigar != 0)) prow[t] = (uint8_t)d;
 			// exact H tracking (:316-351)
 			const int hold = H[c];
@@ -156,6 +137,41 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 		if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H_en0;
 		last_st = st;
 	}
+#undef W8
+}
+
+template <int K, bool PG>
+__global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
+{
+	extern __shared__ __align__(16) uint8_t lds[];
+	const int pid = B.idx[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
+	psvr_extz_t *out = B.ez + pid;
+	EzAcc ez;
+	ez.reset();
+	if (P.skip || qlen <= 0 || tlen <= 0) {
+		if (lane == 0) write_ez(out, ez, 0);
+		return;
+	}
+	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
+	const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
+	int n_col = qlen < tlen ? qlen : tlen;
+	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
+	const int rowb = n_col * 16;
+	const int n_rows = qlen + tlen - 1;
+	const int qimg = (qlen + 16 + 15) & ~15;
+	uint8_t *QR = lds;                 // reversed query + >=16 zero bytes (the calloc'ed tail of `qr`, :100,121)
+	// direction bytes, row pitch rowb (:115): behind the query image in LDS, or (PG) in this problem's slice of the HBM slab
+	uint8_t *Pm = PG ? B.pslab + (B.p_off[pid] << B.p_unit_shift) : lds + qimg;
+	const int p_end = n_rows * rowb + 16;
+	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
+	// 8-bit wrap-around only has to be emulated when it can be observed: if the band never clips the matrix, in-band cells
+	// never read a lane outside the band (dp_band_never_binds) and all in-band values fit int8 for these scoring parameters
+	// (P.nowrap_ok, make_dp_params), so the sign-extension after every add/sub is dropped
+	if (P.nowrap_ok && dp_band_never_binds(qlen, tlen, w)) dp_main_loop<K, false>(P, target, lane, qlen, tlen, w, rowb, n_rows, QR, Pm, ez);
+	else dp_main_loop<K, true>(P, target, lane, qlen, tlen, w, rowb, n_rows, QR, Pm, ez);
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	int n_cigar = 0;
 	if (with_cigar) {
 		if (PG) __threadfence_block();
