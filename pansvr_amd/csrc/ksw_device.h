@@ -41,8 +41,11 @@ struct DpBatch { // device pointers of one batch
 	psvr_extz_t *ez; uint32_t *cigar;
 	uint8_t *pslab; const int64_t *p_off;   // lds kernel only: direction-byte slab, offsets in (1 << p_unit_shift)-byte units
 	int32_t p_unit_shift;
+	int32_t lds_per_wave;      // reg kernels: dynamic LDS bytes of one wavefront's problem
+	long long n;               // problems in this launch
 };
 
+static const int kDpWaves = 4;   // alignments (wavefronts) per workgroup of the register-resident kernels
 template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
 

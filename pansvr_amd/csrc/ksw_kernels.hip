@@ -43,7 +43,7 @@ __device__ __forceinline__ void dp_main_loop(const DpParams &P, const uint8_t *t
 		H[c] = PSVR_KSW_NEG_INF;
 		tb[c] = t < tlen ? target[t] : 0;
 	}
-	__syncthreads();
+	__builtin_amdgcn_wave_barrier();      // the query image was written by this wave's own lanes (LDS is in-order per wave)
 
 	int last_st = -1;
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
@@ -140,12 +140,18 @@ __device__ __forceinline__ void dp_main_loop(const DpParams &P, const uint8_t *t
 #undef W8
 }
 
+// kDpWaves independent alignments per workgroup (one per wavefront, no inter-wave communication): single-wave workgroups
+// run into the workgroups-per-CU limit long before the wave slots are full
 template <int K, bool PG>
-__global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
+__global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpParams P)
 {
-	extern __shared__ __align__(16) uint8_t lds[];
-	const int pid = B.idx[blockIdx.x];
-	const int lane = threadIdx.x;
+	extern __shared__ __align__(16) uint8_t lds_all[];
+	const int wave = threadIdx.x >> 6;
+	const long long slot = (long long)blockIdx.x * kDpWaves + wave;
+	if (slot >= B.n) return;
+	uint8_t *lds = lds_all + (size_t)wave * B.lds_per_wave;
+	const int pid = B.idx[slot];
+	const int lane = threadIdx.x & 63;
 	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
 	psvr_extz_t *out = B.ez + pid;
 	EzAcc ez;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 	int n_cigar = 0;
 	if (with_cigar) {
 		if (PG) __threadfence_block();
-		__syncthreads();
+		__builtin_amdgcn_wave_barrier();
 		int i0 = -1, j0 = -1;
 		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
 		else if (!ez.zdropped && (P.flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64) void extd2_reg_kernel(DpBatch B, DpParams P)
 				[&](int r, int k) { return PG ? (int)__builtin_nontemporal_load(Pm + (size_t)r * rowb + k) : (int)Pm[r * rowb + k]; },
 				[&](int k, uint32_t word) { if (lane == 0) stage_end[-1 - k] = word; });
 			if (PG) __threadfence_block();
-			__syncthreads();
+			__builtin_amdgcn_wave_barrier();
 			uint32_t *dst = B.cigar + out->cigar_off;
 			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
 			for (int m = lane; m < n_cigar; m += 64) {

@@ -14,9 +14,13 @@ inline const char *dp_kind_name(int kind, int variant)
 	return n[kind];
 }
 
-inline void dp_launch_kind(int kind, int variant, unsigned grid, int lds, hipStream_t stream, const DpBatch &B, const DpParams &P)
+inline void dp_launch_kind(int kind, int variant, unsigned count, int lds, hipStream_t stream, const DpBatch &B0, const DpParams &P)
 {
-	dim3 g(grid), b(64);
+	DpBatch B = B0;
+	B.n = count, B.lds_per_wave = lds;
+	const bool reg = kind >= 1;
+	dim3 g(reg ? (count + kDpWaves - 1) / kDpWaves : count), b(reg ? 64 * kDpWaves : 64);
+	if (reg) lds *= kDpWaves;
 	switch (kind) {
 	case 1: hipLaunchKernelGGL((extd2_reg_kernel<1, false>), g, b, lds, stream, B, P); break;
 	case 2: hipLaunchKernelGGL((extd2_reg_kernel<2, false>), g, b, lds, stream, B, P); break;
