@@ -6,7 +6,10 @@ selection -> extension DP -> assembly -> pairing, incl. the speculative rand()-o
 batch of synthetic 150 bp read pairs that is already resident in HBM (configs[1]: 1 M pairs vs a
 10 k-anchor SV reference).  With --gpus N every rank owns one GPU and an independent shard of the
 same size (weak scaling, no data-path collective: read pairs are independent given the replicated
-index); time is max over ranks between barriers.
+index); the shards form ONE input stream: after its run every rank all-gathers three integers (draws its shard consumed
+from the reference's rand()/random_r sequences) and rebases to start where the previous rank ended
+(pansvr_amd/dist.py), so N GPUs produce exactly the records of one `-t 1` pass over the concatenated shards.  Time is
+max over ranks between barriers.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel, timed live with HIP events on its launch stream
@@ -68,12 +71,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from pansvr_amd import dist as pdist
+
+    exchange_iters = []
+
+    def step():
+        if world == 1:
+            eng.run()
+            return
+
+        def run_at(pos):
+            eng.set_stream_pos(pos)
+            eng.run()
+            return eng.stream_end()
+
+        def rebase_to(pos):
+            eng.rebase(pos)
+            return eng.stream_end()
+
+        _, _, it = pdist.resolve_stream_order([2, 0, 0], run_at, rebase_to, device="cuda")
+        exchange_iters.append(it)
+
     for _ in range(args.warmup):
-        eng.run()
+        step()
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        eng.run()
+        step()
     barrier()
     dt = time.time() - t0
     if world > 1:
@@ -133,7 +157,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (2-bit k-mers, 8-bit DP deltas, 32-bit scores)",
                 "data": "synthetic", "config": {"workload": "configs[1]: %d synthetic 150 bp PE signal read pairs per GPU vs %d-anchor SV reference (%.1f Mbp), `panSVR aln` hot path"
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
-                                                 "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated)" % world,
+                                                 "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank, %d iteration(s)/step" % (max(exchange_iters) if exchange_iters else 0)),
                                                  "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu,
                 "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},

@@ -213,6 +213,19 @@ int psvr_engine_upload(psvr_engine_t *eng, int64_t n_pairs, const char *bases, c
 int psvr_engine_run(psvr_engine_t *eng, int trace, void *stream);
 int psvr_engine_download(psvr_engine_t *eng, psvr_read_result_t *reads, psvr_pair_result_t *pairs,
                          uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used);
+/*
+ * Multi-GPU: read pairs are independent given the index, except that the reference consumes ONE rand()/random_r draw
+ * sequence in input order.  When consecutive shards of a batch run on different GPUs, shard r starts at the stream
+ * position where shard r-1 ended.  pos/end = {rand() draws, handler-0 random_r draws, handler-1 random_r draws}.
+ *   psvr_engine_set_stream_pos : where the NEXT run starts (default: where the previous batch ended)
+ *   psvr_engine_stream_end     : where the last run ended
+ *   psvr_engine_rebase         : the last run should have started at `pos`: move it there, re-running only the pairs whose
+ *                                draws moved (results afterwards == a run started at `pos`)
+ * The exchange of the three integers between ranks is the caller's (one all-gather; see pansvr_amd/dist.py).
+ */
+int psvr_engine_set_stream_pos(psvr_engine_t *eng, const int64_t pos[3]);
+int psvr_engine_stream_end(psvr_engine_t *eng, int64_t end[3]);
+int psvr_engine_rebase(psvr_engine_t *eng, const int64_t pos[3], void *stream);
 /* work counters of the last run (probes, hits, dp problems, cells, speculative re-runs ...) as JSON */
 int psvr_engine_stats(const psvr_engine_t *eng, char *buf, size_t buflen);
 

@@ -84,6 +84,19 @@ class Engine:
     def run(self, trace=False, stats=False, timing=False, stream=None):
         check(lib().psvr_engine_run(self.h, (1 if trace else 0) | (2 if stats else 0) | (4 if timing else 0), C.c_void_p(stream)))
 
+    def set_stream_pos(self, pos):
+        a = (C.c_int64 * 3)(*[int(x) for x in pos])
+        check(lib().psvr_engine_set_stream_pos(self.h, a))
+
+    def stream_end(self):
+        a = (C.c_int64 * 3)()
+        check(lib().psvr_engine_stream_end(self.h, a))
+        return [int(x) for x in a]
+
+    def rebase(self, pos, stream=None):
+        a = (C.c_int64 * 3)(*[int(x) for x in pos])
+        check(lib().psvr_engine_rebase(self.h, a, C.c_void_p(stream)))
+
     def stats(self):
         buf = C.create_string_buffer(8192)
         check(lib().psvr_engine_stats(self.h, buf, 8192))

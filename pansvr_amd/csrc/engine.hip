@@ -813,6 +813,36 @@ extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
 	return engine_status(e, rc);
 }
 
+extern "C" int psvr_engine_set_stream_pos(psvr_engine_t *e, const int64_t pos[3])
+{
+	if (!e || !pos) return set_error(PSVR_ERR_ARG, "psvr_engine_set_stream_pos: null argument");
+	if (!e->committed) { e->core.commit(); e->committed = true; }
+	e->core.grand_pos = pos[0], e->core.hrand_pos[0] = pos[1], e->core.hrand_pos[1] = pos[2];
+	e->core.grand_dev_n = e->core.hrand_dev_n = 0;
+	return PSVR_OK;
+}
+
+extern "C" int psvr_engine_stream_end(psvr_engine_t *e, int64_t end[3])
+{
+	if (!e || !end) return set_error(PSVR_ERR_ARG, "psvr_engine_stream_end: null argument");
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	long long t[3];
+	e->core.stream_end(t);
+	end[0] = t[0], end[1] = t[1], end[2] = t[2];
+	return engine_status(e, PSVR_OK);
+}
+
+extern "C" int psvr_engine_rebase(psvr_engine_t *e, const int64_t pos[3], void *stream)
+{
+	if (!e || !pos) return set_error(PSVR_ERR_ARG, "psvr_engine_rebase: null argument");
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	e->be.stream = (hipStream_t)stream;
+	int rc = e->core.rebase(pos[0], pos[1], pos[2], e->core.c.trace, false);
+	hipError_t s = hipStreamSynchronize(e->be.stream);
+	if (s != hipSuccess) e->be.note(s);
+	return engine_status(e, rc);
+}
+
 extern "C" int psvr_engine_download(psvr_engine_t *e, psvr_read_result_t *reads, psvr_pair_result_t *pairs, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used)
 {
 	if (!e) return set_error(PSVR_ERR_ARG, "psvr_engine_download: null engine");

@@ -338,6 +338,13 @@ template <class BE> struct EngineCore {
 
 	// ---- one full run of the uploaded batch (rand state is NOT advanced: call commit() for that)
 	struct Win { int32_t pair; long long eval_off; int32_t eval_tot; std::vector<long long> off; std::vector<int32_t> tot; };   // window-resolved pair
+	// state of the current batch's resolution, kept so that rebase() can continue from it
+	std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
+	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
+	std::vector<char> is_special;                     // a special pair whose prediction failed falls back to the window method
+	long long dp_done = 0, cw_done = 0;
+	bool have_run = false;
+
 	int run(int trace, bool want_stats, int depth = 0)
 	{
 		stats = RunStats();
@@ -380,17 +387,40 @@ template <class BE> struct EngineCore {
 			if (V) be.h2d(d_src + P, vsrc.data(), V * 4);
 			if (!special.empty()) { std::vector<int32_t> ones(special.size(), 1); be.scatter_u8(d_mask, sp_idx.data(), (long long)sp_idx.size(), 1); }
 		}
-		long long dp_done = 0, cw_done = 0;
+		dp_done = 0, cw_done = 0;
+		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
+		have_run = true;
+		int rc = iterate(trace, want_stats, depth, stats_ptr, false);
+		return rc;
+	}
+
+	// The streams of this batch start somewhere else than assumed (another rank's shard precedes it): move every offset
+	// and re-run only what drew from a stale position.  Results and draw counts afterwards are those of a run() that had
+	// started at the new position.
+	int rebase(long long g, long long h0, long long h1, int trace, bool want_stats)
+	{
+		if (!have_run || P == 0) { grand_pos = g, hrand_pos[0] = h0, hrand_pos[1] = h1; return PSVR_OK; }
+		if (g == grand_pos && h0 == hrand_pos[0] && h1 == hrand_pos[1]) return PSVR_OK;
+		grand_pos = g, hrand_pos[0] = h0, hrand_pos[1] = h1;
+		grand_dev_n = hrand_dev_n = 0;                   // the device tables are relative to the stream position
+		unsigned long long *stats_ptr = c.stats;
+		if (!want_stats) c.stats = nullptr;
+		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
+		for (Win &w : wins) w.off.clear(), w.tot.clear(), w.eval_off = -1;
+		return iterate(trace, want_stats, 0, stats_ptr, true);
+	}
+
+	int iterate(int trace, bool want_stats, int depth, unsigned long long *stats_ptr, bool resume)
+	{
 		int rc = PSVR_OK;
-		std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
-		std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
-		std::vector<char> is_special(special.size(), 1);  // a special pair whose prediction failed falls back to the window method
-		long long nfull = P + V, npair_only = 0, nshadow = 0;
+		long long nfull = resume ? 0 : P + V, npair_only = 0, nshadow = 0;
 		const int32_t *work = nullptr;                    // nullptr = identity: round 1 runs every real pair and every variant slot
 		std::vector<int32_t> sh_src; std::vector<long long> sh_off;
+		bool skip_eval = resume;
 		for (;;) {
+			if (!skip_eval) {
 			stats.rounds++;
-			if (stats.rounds == 1) stats.pairs_run += P, stats.shadow_runs += V; else stats.pairs_run += nfull, stats.shadow_runs += nshadow;
+			if (work == nullptr) stats.pairs_run += P, stats.shadow_runs += V; else stats.pairs_run += nfull, stats.shadow_runs += nshadow;
 			stats.pair_only += npair_only;
 			rc = run_slots(work, nfull + nshadow, dp_done, cw_done);
 			if (rc <= -1000) {
@@ -402,11 +432,11 @@ template <class BE> struct EngineCore {
 			if (npair_only) be.st_pair(c, d_workp, npair_only);
 			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
 			be.dzero(d_tops + 8, 8);
-			be.st_totals(c, work, nfull + nshadow, d_ctot, d_sens, d_slist, d_tops + 8, stats.rounds > 1);
+			be.st_totals(c, work, nfull + nshadow, d_ctot, d_sens, d_slist, d_tops + 8, work != nullptr);
 			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_sens, d_slist, d_tops + 8, true);
 			unsigned long long nnew = 0;
 			be.d2h(&nnew, d_tops + 8, 8);
-			if (stats.rounds == 1 && V) { vcnt.resize(3 * V); be.d2h(vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
+			if (vcnt.empty() && V && work == nullptr) { vcnt.resize(3 * V); be.d2h(vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
 			// window tables of the pairs evaluated with offset shadows this round
 			if (nshadow > 0) {
 				std::vector<int32_t> tot(nshadow);
@@ -429,6 +459,8 @@ template <class BE> struct EngineCore {
 				be.scatter_u8(d_mask, add.data(), (long long)add.size(), 1);
 				stats.sensitive = (long long)wins.size();
 			}
+			}   // !skip_eval
+			skip_eval = false;
 			// every host-resolved pair: its last evaluation (offset, total) and the masked prefix in front of it
 			std::vector<int32_t> listed;
 			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
@@ -529,22 +561,32 @@ template <class BE> struct EngineCore {
 		return rc;
 	}
 
-	// advance the rand streams past this batch (the reference's generators keep running across batches)
-	void commit()
+	// where the three streams stand after this batch (valid after run()/rebase())
+	void stream_end(long long out[3])
 	{
+		out[0] = grand_pos, out[1] = hrand_pos[0], out[2] = hrand_pos[1];
 		if (P == 0) return;
 		long long lo; int32_t lc;
 		be.d2h(&lo, c.poff + (P - 1), 8);
 		be.d2h(&lc, d_ctot + (P - 1), 4);
-		long long hp[2];
+		out[0] = lo + lc;
 		for (int k = 0; k < 2; ++k) {
 			long long ho; int32_t hc;
 			be.d2h(&ho, c.hoff + (2 * (P - 1) + k), 8);
 			be.d2h(&hc, c.hcnt + (2 * (P - 1) + k), 4);
-			hp[k] = ho + hc;
+			out[1 + k] = ho + hc;
 		}
-		grand_pos = lo + lc, hrand_pos[0] = hp[0], hrand_pos[1] = hp[1];
+	}
+
+	// advance the rand streams past this batch (the reference's generators keep running across batches)
+	void commit()
+	{
+		if (P == 0) return;
+		long long e[3];
+		stream_end(e);
+		grand_pos = e[0], hrand_pos[0] = e[1], hrand_pos[1] = e[2];
 		grand_dev_n = hrand_dev_n = 0;          // tables are relative to the stream position: refresh on next run
+		have_run = false;
 	}
 };
 

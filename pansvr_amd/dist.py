@@ -1,0 +1,50 @@
+"""Sharding one batch of read pairs over ranks (one process per GPU, torch.distributed).
+
+Pairs are independent given the replicated index, so rank r simply takes the r-th contiguous block (concatenating the
+ranks' outputs restores input order).  The only coupling is the reference's single rand()/random_r draw sequence:
+shard r starts where shard r-1 ended.  `resolve_stream_order` finds those positions with one tiny all-gather per
+iteration: every rank runs (or rebases) its shard at its current start position, all ranks exchange how many draws their
+shards consumed, and each recomputes its start as first + sum of the draws of the ranks before it -- until no start
+moves (normally two iterations: draw counts almost never depend on the start position)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, order-preserving split: pair i belongs to rank floor(i * world / n)."""
+    lo = (n * rank + world - 1) // world
+    hi = (n * (rank + 1) + world - 1) // world
+    return lo, hi
+
+
+def all_gather_i64(vec, device=None):
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    t = torch.tensor([int(x) for x in vec], dtype=torch.int64, device=device)
+    if world == 1:
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def resolve_stream_order(first_pos, run_at, rebase_to, device=None, max_iter=16):
+    """first_pos: [g, h0, h1] where rank 0's shard starts.  run_at(pos) -> end runs this rank's shard from `pos`;
+    rebase_to(pos) -> end moves the finished run to `pos`.  Returns (start, end, iterations) of this rank."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    start = [int(x) for x in first_pos]
+    end = run_at(start)
+    it = 1
+    while True:
+        used = [e - s for e, s in zip(end, start)]
+        every = all_gather_i64(used, device)
+        new_start = [int(first_pos[k]) + sum(every[q][k] for q in range(rank)) for k in range(3)]
+        moved = new_start != start
+        flags = all_gather_i64([1 if moved else 0], device)
+        if not any(f[0] for f in flags):
+            return start, end, it
+        if it >= max_iter:
+            raise RuntimeError("stream-order resolution did not converge")
+        if moved:
+            start = new_start
+            end = rebase_to(start)
+        it += 1

@@ -105,9 +105,12 @@ int main(int argc, char **argv)
 	if (argc < 4) { fprintf(stderr, "usage: emu_aln <index_dir> <reads.fq> <header.sam> [--trace] [--batch N]\n"); return 1; }
 	bool trace = false;
 	long long batch = 1 << 20;
+	long long pos[3] = {-1, -1, -1}, from[3] = {-1, -1, -1};
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
 		else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoll(argv[++i]);
+		else if (!strcmp(argv[i], "--stream-pos") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &pos[0], &pos[1], &pos[2]);       // start of this shard in the three draw streams
+		else if (!strcmp(argv[i], "--rebase-from") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &from[0], &from[1], &from[2]);  // run there first, then rebase to --stream-pos
 	}
 	HostIndex hi;
 	hi.keep_sparse = true;       // PSVR_EMU_SPARSE_HASH build: no 2 GiB table on the CPU
@@ -124,15 +127,23 @@ int main(int argc, char **argv)
 	bool first = true;
 	long long pair_base = 0;
 	while (fb.read(fq, batch)) {
-		if (first) { fb.stat_params(&par); core.init(ix, par); first = false; }
+		if (first) {
+			fb.stat_params(&par);
+			core.init(ix, par);
+			first = false;
+			const long long *st = from[0] >= 0 ? from : pos;
+			if (st[0] >= 0) core.grand_pos = st[0], core.hrand_pos[0] = st[1], core.hrand_pos[1] = st[2];
+		}
 		int rc = core.upload(fb.n_pairs(), fb.bases.data(), (const int64_t *)fb.base_off.data(), fb.ori.data());
 		if (!rc) rc = core.run(trace, true);
+		if (!rc && from[0] >= 0 && pos[0] >= 0) { rc = core.rebase(pos[0], pos[1], pos[2], trace, true); from[0] = -1; }
 		if (rc) { fprintf(stderr, "emu error %d: %s\n", rc, core.err.c_str()); return 3; }
 		for (long long p = 0; p < fb.n_pairs(); ++p) {
 			int lens[2] = {(int)fb.recs[2 * p].seq.size(), (int)fb.recs[2 * p + 1].seq.size()};
 			puts(record_json(pair_base + p, core.c.res + 2 * p, core.c.pres[p], &fb.ori[2 * p], lens, core.c.cig.base, trace).c_str());
 		}
 		core.commit();
+		fprintf(stderr, "[emu] stream_end %lld %lld %lld\n", core.grand_pos, core.hrand_pos[0], core.hrand_pos[1]);
 		pair_base += fb.n_pairs();
 		fprintf(stderr, "[emu] batch of %lld pairs: %lld rounds, %lld pair-runs (+%lld pairing-only, +%lld shadow, %lld sensitive, %lld window misses), %lld DP problems, %lld candidates\n", fb.n_pairs(), core.stats.rounds,
 		        core.stats.pairs_run, core.stats.pair_only, core.stats.shadow_runs, core.stats.sensitive, core.stats.window_miss, core.stats.dp_problems, core.stats.cands);
