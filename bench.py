@@ -47,10 +47,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # PSVR_BENCH_REHEARSE=1: all ranks share GPU 0 and exchange over gloo (single-GPU rehearsal of the N>1 code path)
+        rehearse = os.environ.get("PSVR_BENCH_REHEARSE") == "1"
+        dist.init_process_group("gloo" if rehearse or not torch.cuda.is_available() else "nccl")
+        if rehearse:
+            local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
+    xdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else None
 
     import bench_data
     from pansvr_amd import aln
@@ -89,7 +94,7 @@ def main():
             eng.rebase(pos)
             return eng.stream_end()
 
-        _, _, it = pdist.resolve_stream_order([2, 0, 0], run_at, rebase_to, device="cuda")
+        _, _, it = pdist.resolve_stream_order([2, 0, 0], run_at, rebase_to, device=xdev)
         exchange_iters.append(it)
 
     for _ in range(args.warmup):
@@ -101,7 +106,7 @@ def main():
     barrier()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=xdev or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     reads_per_step = 2 * args.pairs * world
