@@ -134,6 +134,50 @@ static bool emit_record(FILE *out, const HeaderInfo &H, const std::string &name,
 	return true;
 }
 
+// single_end_handler::output_ori_bam (rr.cpp:656-717): the ORIGINAL alignment re-assembled from the comment's
+// FLAG_/CIGAR_/MATE_/TAG_ sections (+ MS:i:max_score); returns false when the record would not be written
+struct OriRecord { int flag = 0, mapq = 0, mate_chr = -1, mate_pos = 0, isize = 0; std::string cigar, tags; };
+static bool parse_ori_record(const std::string &comment, OriRecord *r)
+{
+	const char *c = comment.c_str();
+	const char *f = strstr(c, "FLAG_");
+	if (!f) return false;
+	unsigned fl = 0, q = 0;
+	if (sscanf(f + 5, "%u_%u_", &fl, &q) < 2) return false;
+	r->flag = (int)fl, r->mapq = (int)q;
+	const char *cg = strstr(f + 5, "CIGAR_");
+	if (!cg) return false;
+	cg += 6;
+	const char *ce = strchr(cg, '_');
+	if (!ce) return false;
+	r->cigar.assign(cg, ce - cg);
+	const char *mate = ce + 1 + 5;                           // skips "MATE_"
+	if (strlen(ce) < 6 || sscanf(mate, "%d_%d_%d_", &r->mate_chr, &r->mate_pos, &r->isize) < 3) return false;
+	r->mate_pos += 1;
+	const char *tg = strstr(mate, "TAG_");
+	if (!tg) return false;
+	std::string tags = tg + 4;
+	const int tl = (int)tags.size();
+	for (int i = 0; i < tl - 5; i++) if (tags[i] == '_' && tags[i + 3] == ':' && tags[i + 5] == ':') tags[i] = '\t';
+	if (tl > 0) tags.resize(tl - 1);
+	r->tags = tags;
+	return true;
+}
+
+// bam_has_clip_or_unmapped_ori (rr.cpp:721-733) on the CIGAR text
+static bool ori_has_clip(const std::string &cigar, int min_clip)
+{
+	if (cigar.empty() || cigar == "*") return true;
+	std::vector<std::pair<int, char>> ops;
+	int n = 0;
+	for (char ch : cigar) { if (ch >= '0' && ch <= '9') n = n * 10 + (ch - '0'); else { ops.push_back({n, ch}); n = 0; } }
+	if (ops.empty()) return true;
+	int tot = 0;
+	if (ops.front().second == 'S' || ops.front().second == 'H') tot += ops.front().first;
+	if (ops.back().second == 'S' || ops.back().second == 'H') tot += ops.back().first;
+	return tot >= min_clip;
+}
+
 static std::string cigar_string(const psvr_cand_t &c, const uint32_t *cig)
 {
 	std::string s;
@@ -286,6 +330,40 @@ int main(int argc, char **argv)
 				}
 				tags += "\tRC:Z:" + rec.comment;
 				emit_record(fo, H, rec.name, flag, chr_id, ref_bg, mapq, cg, rr.has_mate != 0, rr.mate_chr_id, rr.mate_ref_bg, isize, seq, qual, tags);
+			}
+		}
+		// ---- second file (rr.cpp:776-797): pairs neither the original aligner nor the re-aligner placed well
+		for (long long p = 0; p < P; ++p) {
+			const psvr_pair_result_t &pr = pres[p];
+			if (!(pr.max_score <= par.min_filter_score && fb.ori[2 * p].chr_id != -1 && fb.ori[2 * p + 1].chr_id != -1)) continue;
+			OriRecord orr[2];
+			bool ok = parse_ori_record(fb.recs[2 * p].comment, &orr[0]) && parse_ori_record(fb.recs[2 * p + 1].comment, &orr[1]);
+			if (!ok) continue;
+			bool proper = pr.proper != 0;
+			for (int k = 0; proper && k < 2; ++k) {
+				const int mx = k == 0 ? pr.max1 : pr.max2;
+				if (mx == -1) { proper = false; break; }
+				if (mx == -2) { if (ori_has_clip(orr[k].cigar, 25)) proper = false; }
+				else {                                               // bam_has_clip_or_unmapped_new (rr.cpp:735-743): sums the 'I' ops
+					const psvr_cand_t &cd = res[2 * p + k].cand[mx];
+					int tot = 0;
+					for (uint32_t j = 0; j < cd.n_cigar; ++j) { uint32_t wv = cig[cd.cigar_off + j]; if ((wv & 0xf) == 1) tot += (int)(int16_t)(wv >> 4); }
+					if (cd.n_cigar == 0 || tot >= 25) proper = false;
+				}
+			}
+			if (proper) continue;
+			for (int k = 0; k < 2; ++k) {
+				const FqRec &rec = fb.recs[2 * p + k];
+				const psvr_ori_t &ori = fb.ori[2 * p + k];
+				std::string seq = rec.seq, qual = rec.qual;
+				if (orr[k].flag & 0x10) rev_seq(seq), rev_qual(qual);
+				std::string tags;
+				if (!orr[k].tags.empty()) tags += "\t" + orr[k].tags;
+				char b[64];
+				snprintf(b, sizeof b, "\tMS:i:%d", pr.max_score);
+				tags += b;
+				const uint32_t ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg;
+				emit_record(fo_ori, H, rec.name, orr[k].flag, ori.chr_id, ref_bg + 1, orr[k].mapq, orr[k].cigar, true, orr[k].mate_chr, (uint32_t)orr[k].mate_pos, orr[k].isize, seq, qual, tags);
 			}
 		}
 		pair_base += P;
