@@ -149,12 +149,22 @@ def main():
         launches = max(1, kern[dom]["launches"])
         avg_ms = kern[dom]["ms"] / launches
         share = {"k_seed": seed_bytes_per_read}.get(dom, bytes_per_read)
+        # HBM-side traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/pmc_latest.json, written by tools/pmc_to_json.py; FETCH_SIZE/WRITE_SIZE are KiB per dispatch)
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            kd = pj["kernels"].get(dom.replace(",hbm>", ", true>").replace(",lds>", ", false>"))
+            if kd and pj.get("pairs_per_gpu") == args.pairs:
+                traffic = int((kd["fetch_KiB_per_step"] + kd["write_KiB_per_step"]) * 1024)
+        except Exception:
+            traffic = None
         if share is not None:
             # first launch of the dominant kernel covers all 2P reads of the batch; later (speculative) launches cover few
             alg_bytes = share * 2 * args.pairs
             achieved = alg_bytes / (kern[dom]["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
-                        "traffic": None, "alg_bytes_per_read": round(share, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
+                        "traffic": traffic, "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (KiB*1024) per step from profiles/pmc_latest.json; gfx950 FETCH_SIZE under-reports coalesced reads by up to 2x", "alg_bytes_per_read": round(share, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
                         "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4)}
     if rank == 0:
         line = {"metric": "signal reads realigned/sec (150 bp PE); bit-exact CIGAR vs CPU ref", "value": round(value, 1), "unit": "reads/s",
