@@ -52,6 +52,20 @@ def records(reads, pairs, cig, ori, lens, lo, hi):
     return out
 
 
+def canon(reads, cig):
+    """Arena offsets depend on the order in which device threads allocate: compare records with the offsets cleared and the
+    CIGAR words gathered in (read, candidate) order."""
+    r = reads.copy()
+    k = np.arange(12)[None, :] < r["n_result"][:, None]
+    off = r["cand"]["cigar_off"][k].astype(np.int64)
+    n = r["cand"]["n_cigar"][k].astype(np.int64)
+    tot = int(n.sum())
+    starts = np.repeat(off - np.concatenate([[0], np.cumsum(n)[:-1]]), n)
+    words = cig[starts + np.arange(tot)] if tot else np.zeros(0, np.uint32)
+    r["cand"]["cigar_off"] = 0
+    return r.tobytes(), words.tobytes()
+
+
 def test_fullsize_properties_and_prefix_parity():
     from pansvr_amd import aln
     anc = bench_data.make_anchors(10000, seed=11)
@@ -67,7 +81,7 @@ def test_fullsize_properties_and_prefix_parity():
     # --- idempotence
     eng.run()
     reads2, pairs2, cig2 = eng.download()
-    assert reads.tobytes() == reads2.tobytes() and pairs.tobytes() == pairs2.tobytes() and cig[:len(cig2)].tobytes() == cig2.tobytes()
+    assert canon(reads, cig) == canon(reads2, cig2) and pairs.tobytes() == pairs2.tobytes()
     # --- CIGAR / range invariants over ALL candidates
     n_res = reads["n_result"]
     assert n_res.min() >= 0 and n_res.max() <= 12
