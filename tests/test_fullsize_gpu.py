@@ -108,14 +108,14 @@ def test_fullsize_properties_and_prefix_parity():
     bench_data.write_index_dir(small, os.path.join(tmp, "idx"))
     bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, n_pairs=N_ORACLE)
     with open(os.path.join(tmp, "header.sam"), "w") as f:
-        f.write("@SQ\\tSN:chr1\\tLN:250000000\\n@SQ\\tSN:chr2\\tLN:250000000\\n")
+        f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")
     out = subprocess.run([ac.ORACLE_EXE, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam")],
                          stdout=subprocess.PIPE, check=True).stdout.decode()
-    want = [json.loads(l) for l in out.split("\\n") if l.strip()]
+    want = [json.loads(l) for l in out.split("\n") if l.strip()]
     got = records(reads, pairs, cig, ori, lens, 0, N_ORACLE)
     assert len(want) == N_ORACLE
     bad = [i for i in range(N_ORACLE) if want[i] != got[i]]
-    assert not bad, "%d/%d prefix pairs differ, first %d:\\noracle %s\\nengine %s" % (len(bad), N_ORACLE, bad[0], json.dumps(want[bad[0]]), json.dumps(got[bad[0]]))
+    assert not bad, "%d/%d prefix pairs differ, first %d:\noracle %s\nengine %s" % (len(bad), N_ORACLE, bad[0], json.dumps(want[bad[0]]), json.dumps(got[bad[0]]))
     # --- batch-split invariance (first 200 k pairs as 2 x 100 k with the stream state carried across)
     n2 = min(200000, N_PAIRS)
     h = n2 // 2
