@@ -48,7 +48,6 @@ struct DpBatch { // device pointers of one batch
 static const int kDpWaves = 4;   // alignments (wavefronts) per workgroup of the register-resident kernels
 template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
-template <int KP, bool PG> __global__ void extd2_pk_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 
 // true when the band [(r-w+1)>>1, (r+w)>>1] never clips the DP matrix: then st0/en0 follow the matrix edges only, every
 // in-band cell's (r-1,t-1)/(r-1,t) neighbours are in-band or one of the explicit boundary values (ksw2_extd2_sse.c:142-156),
@@ -88,21 +87,18 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 // Direction bytes stay in LDS only while the whole footprint is at most this (keeps >= 32 waves per CU resident);
 // larger problems stream them to an HBM slab and trace back through L2
 #define PSVR_DP_PG_THRESHOLD 4096
-#define PSVR_DP_NUM_KINDS 17
+#define PSVR_DP_NUM_KINDS 11
 // kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM),
-// 11..13 = extd2_pk_kernel<kind-10,false>, 14..16 = extd2_pk_kernel<kind-13,true> (packed 16-bit, only where 8-bit wrap is
-// unobservable), 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
-__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool nowrap_ok = false)
+// 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
+__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need)
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
 	int T = (tlen + 15) / 16 * 16;
 	long long n = dp_reg_lds_need(qlen, tlen, w);
 	if (fast_ok && T <= 320) {
-		const int ww = w < 0 ? (qlen > tlen ? qlen : tlen) : w;
-		const bool pk = nowrap_ok && dp_band_never_binds(qlen, tlen, ww);
-		if (n <= PSVR_DP_PG_THRESHOLD) { *need = (int)n; return pk ? 10 + (T + 127) / 128 : (T + 63) / 64; }
+		if (n <= PSVR_DP_PG_THRESHOLD) { *need = (int)n; return (T + 63) / 64; }
 		*need = ((qlen + 16 + 15) & ~15) + 16;
-		return pk ? 13 + (T + 127) / 128 : 5 + (T + 63) / 64;
+		return 5 + (T + 63) / 64;
 	}
 	int g = dp_lds_kernel_need(qlen, tlen, variant);
 	*need = g;

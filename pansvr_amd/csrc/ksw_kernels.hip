@@ -218,231 +218,6 @@ template __global__ void extd2_reg_kernel<5, true>(DpBatch, DpParams);
 
 
 // ------------------------------------------------------------------------------------------
-// packed fast path: two adjacent columns per lane in packed 16-bit arithmetic (v_pk_add/sub/max/min_i16).
-// Only launched where 8-bit wrap-around cannot be observed (P.nowrap_ok && dp_band_never_binds): every in-band value then fits
-// int8, hence int16, and the lanes outside the band are never read back, so 16-bit arithmetic yields the reference's values.
-// Lane L of chunk c owns columns t0 = 128c + 2L (low half) and t0 + 1 (high half); a chunk covers 128 columns, so every
-// alignment with tlen <= 128 is a single chunk per anti-diagonal.  Direction bytes, traceback and outputs are those of
-// extd2_reg_kernel.
-// ------------------------------------------------------------------------------------------
-typedef short pk2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk2 pk_of(unsigned v) { return __builtin_bit_cast(pk2, v); }
-__device__ __forceinline__ unsigned u_of(pk2 v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ pk2 pk_splat(int v) { pk2 r; r.x = (short)v, r.y = (short)v; return r; }
-__device__ __forceinline__ pk2 pk_max(pk2 a, pk2 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ pk2 pk_min(pk2 a, pk2 b) { return __builtin_elementwise_min(a, b); }
-// 0xFFFF in every half where v < 0
-__device__ __forceinline__ unsigned pk_neg_mask(pk2 v) { return u_of(v >> (short)15); }
-// per-half select: m ? a : b   (m = 0xFFFF / 0 per half)
-__device__ __forceinline__ unsigned bfi(unsigned m, unsigned a, unsigned b) { return (a & m) | (b & ~m); }
-__device__ __forceinline__ unsigned half_mask(bool lo, bool hi) { return (lo ? 0x0000FFFFu : 0u) | (hi ? 0xFFFF0000u : 0u); }
-
-template <int KP, bool PG>
-__global__ __launch_bounds__(64 * kDpWaves) void extd2_pk_kernel(DpBatch B, DpParams P)
-{
-	extern __shared__ __align__(16) uint8_t lds_all[];
-	const int wave = threadIdx.x >> 6;
-	const long long slot = (long long)blockIdx.x * kDpWaves + wave;
-	if (slot >= B.n) return;
-	uint8_t *lds = lds_all + (size_t)wave * B.lds_per_wave;
-	const int pid = B.idx[slot];
-	const int lane = threadIdx.x & 63;
-	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
-	psvr_extz_t *out = B.ez + pid;
-	EzAcc ez;
-	ez.reset();
-	if (P.skip || qlen <= 0 || tlen <= 0) {
-		if (lane == 0) write_ez(out, ez, 0);
-		return;
-	}
-	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
-	const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
-	int n_col = qlen < tlen ? qlen : tlen;
-	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
-	const int rowb = n_col * 16;
-	const int n_rows = qlen + tlen - 1;
-	const int qimg = (qlen + 16 + 15) & ~15;
-	uint8_t *QR = lds;
-	uint8_t *Pm = PG ? B.pslab + (B.p_off[pid] << B.p_unit_shift) : lds + qimg;
-	const int p_end = n_rows * rowb + 16;
-	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
-
-	const int neg_qe = -P.q - P.e, neg_qe2 = -P.q2 - P.e2;
-	const pk2 k_negqe = pk_splat(neg_qe), k_negqe2 = pk_splat(neg_qe2), k_qe = pk_splat(P.q + P.e), k_qe2 = pk_splat(P.q2 + P.e2);
-	const pk2 k_q = pk_splat(P.q), k_q2 = pk_splat(P.q2), k_mch = pk_splat(P.sc_mch), k_zero = pk_splat(0);
-	const unsigned k_mis = u_of(pk_splat(P.sc_mis)), k_mchu = u_of(k_mch), k_scN = u_of(pk_splat(P.sc_N)), k_m1 = u_of(pk_splat(P.m1));
-	pk2 u[KP], v[KP], x[KP], y[KP], x2[KP], y2[KP], s[KP];
-	int H0[KP], H1[KP];
-	unsigned tbp[KP];
-#pragma unroll
-	for (int c = 0; c < KP; ++c) {
-		const int t0 = c * 128 + 2 * lane;
-		u[c] = v[c] = x[c] = y[c] = k_negqe;
-		x2[c] = y2[c] = k_negqe2;
-		s[c] = k_zero;
-		H0[c] = H1[c] = PSVR_KSW_NEG_INF;
-		tbp[c] = (t0 < tlen ? (unsigned)target[t0] : 0u) | ((t0 + 1 < tlen ? (unsigned)target[t0 + 1] : 0u) << 16);
-	}
-	__builtin_amdgcn_wave_barrier();
-
-	int last_st = -1;
-	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
-	for (int r = 0; r < n_rows; ++r) {
-		int st0, en0, st, en;
-		if (!band_limits(r, qlen, tlen, w, st0, en0, st, en)) { ez.zdropped = 1; break; }
-		const bool adv = st > 0 && st > last_st;
-		const int ur = r == 0 ? neg_qe : r < P.long_thres ? -P.e : r == P.long_thres ? P.long_diff : -P.e2;
-		const int fresh_end = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;
-		const int qbase = qlen - 1 - r;
-		const int c_first = st >> 7, c_last = en >> 7;
-		const int en1 = st0 + (en0 - st0) / 4 * 4;
-		int h_prev = 0;
-		if (en0 > 0) {
-			const int tp = en0 - 1;
-#pragma unroll
-			for (int c = 0; c < KP; ++c)
-				if ((tp >> 7) == c) h_prev = __builtin_amdgcn_readlane((tp & 1) ? H1[c] : H0[c], (tp >> 1) & 63);
-		}
-		int bh = (int)0x80000000; unsigned bk = 0xffffffffu;
-		uint8_t *prow = Pm + r * rowb - st;
-		const unsigned ovr_on = en >= r ? 1u : 0u;
-		const unsigned bnd_val_x = (unsigned)(unsigned short)(short)neg_qe, bnd_val_x2 = (unsigned)(unsigned short)(short)neg_qe2;
-		const unsigned bnd_val_v = (unsigned)(unsigned short)(short)(st > 0 ? neg_qe : ur);
-#pragma unroll
-		for (int c = KP - 1; c >= 0; --c) {
-			if (c < c_first || c > c_last) continue;
-			const int t0 = c * 128 + 2 * lane, t1 = t0 + 1;
-			const bool act = (unsigned)(t0 - st) <= (unsigned)(en - st);             // st even, en odd: both halves agree
-			// (r-1,t) values with the top-row override at t == r (ksw2_extd2_sse.c:153-156)
-			const unsigned mo = ovr_on ? half_mask(t0 == r, t1 == r) : 0u;
-			const pk2 yy = pk_of(bfi(mo, u_of(k_negqe), u_of(y[c]))), yy2 = pk_of(bfi(mo, u_of(k_negqe2), u_of(y2[c])));
-			const pk2 ut = pk_of(bfi(mo, u_of(pk_splat(ur)), u_of(u[c])));
-			// (r-1,t-1) values: low half from the previous lane's high half, high half from the own low half
-			unsigned cx = 0, cv = 0, cx2 = 0;
-			if (c > 0) {
-				cx = (unsigned)__builtin_amdgcn_readlane((int)u_of(x[c - 1]), 63);
-				cv = (unsigned)__builtin_amdgcn_readlane((int)u_of(v[c - 1]), 63);
-				cx2 = (unsigned)__builtin_amdgcn_readlane((int)u_of(x2[c - 1]), 63);
-			}
-			unsigned xs = __builtin_amdgcn_alignbit(u_of(x[c]), (unsigned)dpp_wave_shr1((int)u_of(x[c]), (int)cx), 16);
-			unsigned vs = __builtin_amdgcn_alignbit(u_of(v[c]), (unsigned)dpp_wave_shr1((int)u_of(v[c]), (int)cv), 16);
-			unsigned x2s = __builtin_amdgcn_alignbit(u_of(x2[c]), (unsigned)dpp_wave_shr1((int)u_of(x2[c]), (int)cx2), 16);
-			const bool bnd = (t0 == st) & !adv;                                       // (:142-152), only the low half can be column st
-			xs = bnd ? (xs & 0xFFFF0000u) | bnd_val_x : xs;
-			vs = bnd ? (vs & 0xFFFF0000u) | bnd_val_v : vs;
-			x2s = bnd ? (x2s & 0xFFFF0000u) | bnd_val_x2 : x2s;
-			const pk2 xt1 = pk_of(xs), vt1 = pk_of(vs), x2t1 = pk_of(x2s);
-			// fresh scores (:158-173)
-			const bool f0 = (unsigned)(t0 - st0) <= (unsigned)(fresh_end - st0), f1 = (unsigned)(t1 - st0) <= (unsigned)(fresh_end - st0);
-			const unsigned q0 = QR[f0 ? qbase + t0 : 0], q1 = QR[f1 ? qbase + t1 : 0];
-			const unsigned qbp = q0 | (q1 << 16);
-			const pk2 dx = pk_of(tbp[c] ^ qbp);                                        // 0 where equal (codes are 0..4)
-			const unsigned neq = pk_neg_mask(pk_of(u_of(dx) | u_of(k_zero - dx)));     // 0xFFFF where the codes differ
-			unsigned sc = bfi(neq, k_mis, k_mchu);
-			const pk2 nx = pk_of(u_of(pk_max(pk_of(tbp[c]), pk_of(qbp))) ^ k_m1);      // 0 where either code is the wildcard m-1
-			const unsigned isn = ~pk_neg_mask(pk_of(u_of(nx) | u_of(k_zero - nx)));
-			sc = bfi(isn, k_scN, sc);
-			const pk2 sv = pk_of(bfi(half_mask(f0, f1), sc, u_of(s[c])));
-			s[c] = sv;
-			// the five-way max with the reference's priority a > b > a2 > b2 on ties (strict >)
-			pk2 a = xt1 + vt1, b = yy + ut, a2 = x2t1 + vt1, b2 = yy2 + ut;
-			pk2 z = sv, zn;
-			zn = pk_max(z, a);  unsigned d = pk_neg_mask(z - zn) & 0x00010001u;            z = zn;
-			zn = pk_max(z, b);  d = bfi(pk_neg_mask(z - zn), 0x00020002u, d);                z = zn;
-			zn = pk_max(z, a2); d = bfi(pk_neg_mask(z - zn), 0x00030003u, d);                z = zn;
-			zn = pk_max(z, b2); d = bfi(pk_neg_mask(z - zn), 0x00040004u, d);                z = zn;
-			z = pk_min(z, k_mch);
-			const pk2 un = z - vt1, vn = z - ut;
-			pk2 tmp = z - k_q;
-			a = a - tmp, b = b - tmp;
-			tmp = z - k_q2;
-			a2 = a2 - tmp, b2 = b2 - tmp;
-			const pk2 pa = pk_max(a, k_zero), pb = pk_max(b, k_zero), pa2 = pk_max(a2, k_zero), pb2 = pk_max(b2, k_zero);
-			d |= (pk_neg_mask(k_zero - pa) & 0x00080008u) | (pk_neg_mask(k_zero - pb) & 0x00100010u) |
-			     (pk_neg_mask(k_zero - pa2) & 0x00200020u) | (pk_neg_mask(k_zero - pb2) & 0x00400040u);
-			u[c] = act ? un : u[c], v[c] = act ? vn : v[c];
-			x[c] = act ? pa - k_qe : x[c];
-			y[c] = act ? pb - k_qe : y[c];
-			x2[c] = act ? pa2 - k_qe2 : x2[c];
-			y2[c] = act ? pb2 - k_qe2 : y2[c];
-			if (act & (with_cigar != 0)) *(uint16_t *)(prow + t0) = (uint16_t)((d & 0xffu) | ((d >> 8) & 0xff00u));
-			// exact H tracking (:316-351), 32-bit per column
-			const int un0 = (int)un.x, un1 = (int)un.y, vn0 = (int)vn.x, vn1 = (int)vn.y;
-			{
-				const int hold = H0[c];
-				int hn = (t0 == en0) ? (en0 > 0 ? h_prev + un0 : hold + vn0) : (((unsigned)(t0 - st0) < (unsigned)(en0 - st0)) ? hold + vn0 : hold);
-				hn = r == 0 ? (t0 == 0 ? vn0 - P.qe_pre : hold) : hn;
-				hn = act ? hn : hold;
-				H0[c] = hn;
-				const bool valid = (unsigned)(t0 - st0) <= (unsigned)(en0 - st0);
-				const unsigned rank = t0 == en0 ? 0u : (t0 < en1 ? 1u + (unsigned)((t0 - st0) & 3) * 4096u + (unsigned)(t0 - st0) : 1u + 4u * 4096u + (unsigned)(t0 - st0));
-				const bool better = valid & ((hn > bh) | ((hn == bh) & (rank < bk)));
-				bh = better ? hn : bh, bk = better ? rank : bk;
-			}
-			{
-				const int hold = H1[c];
-				int hn = (t1 == en0) ? (en0 > 0 ? h_prev + un1 : hold + vn1) : (((unsigned)(t1 - st0) < (unsigned)(en0 - st0)) ? hold + vn1 : hold);
-				hn = r == 0 ? hold : hn;                                              // t1 >= 1
-				hn = act ? hn : hold;
-				H1[c] = hn;
-				const bool valid = (unsigned)(t1 - st0) <= (unsigned)(en0 - st0);
-				const unsigned rank = t1 == en0 ? 0u : (t1 < en1 ? 1u + (unsigned)((t1 - st0) & 3) * 4096u + (unsigned)(t1 - st0) : 1u + 4u * 4096u + (unsigned)(t1 - st0));
-				const bool better = valid & ((hn > bh) | ((hn == bh) & (rank < bk)));
-				bh = better ? hn : bh, bk = better ? rank : bk;
-			}
-		}
-		const int max_H = wave_max_i32(bh);
-		const unsigned long long top = __ballot(bh == max_H);
-		unsigned rk;
-		if (__popcll(top) == 1) rk = (unsigned)__builtin_amdgcn_readlane((int)bk, __ffsll((unsigned long long)top) - 1);
-		else rk = wave_min_u32(bh == max_H ? bk : 0xffffffffu);
-		const int max_t = rk == 0 ? en0 : st0 + (int)((rk - 1u) & 4095u);
-		int H_en0 = 0, H_st0 = 0;
-#pragma unroll
-		for (int c = 0; c < KP; ++c) {
-			if ((en0 >> 7) == c) H_en0 = __builtin_amdgcn_readlane((en0 & 1) ? H1[c] : H0[c], (en0 >> 1) & 63);
-			if ((st0 >> 7) == c) H_st0 = __builtin_amdgcn_readlane((st0 & 1) ? H1[c] : H0[c], (st0 >> 1) & 63);
-		}
-		if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - en;
-		if (r - st0 == qlen - 1 && H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
-		if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) break;
-		if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H_en0;
-		last_st = st;
-	}
-	int n_cigar = 0;
-	if (with_cigar) {
-		if (PG) __threadfence_block();
-		__builtin_amdgcn_wave_barrier();
-		int i0 = -1, j0 = -1;
-		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
-		else if (!ez.zdropped && (P.flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
-		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
-		if (i0 >= 0 && j0 >= 0) {
-			uint32_t *stage_end = (uint32_t*)(Pm + p_end);
-			n_cigar = traceback(i0, j0, qlen, tlen, w,
-				[&](int r, int k) { return PG ? (int)__builtin_nontemporal_load(Pm + (size_t)r * rowb + k) : (int)Pm[r * rowb + k]; },
-				[&](int k, uint32_t word) { if (lane == 0) stage_end[-1 - k] = word; });
-			if (PG) __threadfence_block();
-			__builtin_amdgcn_wave_barrier();
-			uint32_t *dst = B.cigar + out->cigar_off;
-			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
-			for (int m = lane; m < n_cigar; m += 64) {
-				const uint32_t *src = rev ? stage_end - 1 - m : stage_end - n_cigar + m;
-				dst[m] = PG ? __builtin_nontemporal_load(src) : *src;
-			}
-		}
-	}
-	if (lane == 0) write_ez(out, ez, n_cigar);
-}
-
-template __global__ void extd2_pk_kernel<1, false>(DpBatch, DpParams);
-template __global__ void extd2_pk_kernel<2, false>(DpBatch, DpParams);
-template __global__ void extd2_pk_kernel<3, false>(DpBatch, DpParams);
-template __global__ void extd2_pk_kernel<1, true>(DpBatch, DpParams);
-template __global__ void extd2_pk_kernel<2, true>(DpBatch, DpParams);
-template __global__ void extd2_pk_kernel<3, true>(DpBatch, DpParams);
-
-// ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image
 //   extd2: u|v|x|y|x2|y2|s|sf|qr   (ksw2_extd2_sse.c:100-103)
 //   extz2: u|v|x|y|s|sf|qr         (ksw2_extz2_sse.c:85-87)
