@@ -12,6 +12,12 @@ DATASETS = {
                 reads={"reads150": dict(n_pairs=1500, seed=23, str_frac=0.05, n_frac=0.05),
                        "reads250": dict(n_pairs=600, seed=29, L=250, frag=(500, 700), maxindel=40, str_frac=0.05, n_frac=0.03,
                                         stat=(250, 300, 600, 900))}),
+    # edge cases: a 70 bp element shared by all 620 alleles (one unipath with 620 > POS_N_MAX positions: expand_seed's random_r
+    # sampling), ragged read lengths incl. even ones (the reverse-strand middle-swap quirk), reads with 4-8 N bases
+    "fx3": dict(anchors=dict(n_anchors=620, seed=31, edge=300, allele=(120, 200), repeat_len=70),
+                reads={"ragged": dict(n_pairs=1200, seed=37, lengths=[100, 101, 126, 150, 151, 200, 250], frag=(520, 560), maxindel=8, n_frac=0.03,
+                                      heavy_n_frac=0.03, stat=(150, 300, 500, 800)),
+                       "repeat": dict(n_pairs=300, seed=41, L=150, frag=(300, 420), center_frac=0.9, miss_frac=0.05)}),
 }
 
 

@@ -18,13 +18,14 @@ def rand_dna(rng, n):
     return ACGT[rng.randint(0, 4, size=n)].tobytes()
 
 
-def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, dup_frac=0.0):
+def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, dup_frac=0.0, repeat_len=0):
     """INS anchors named ID_chr_st_len_TYPE_bp1_bp2_end_vcfid (get_anchor_ref.hpp:322-323).
     str_frac: fraction of anchors whose allele is a short tandem repeat; dup_frac: fraction of anchors that
     re-use the previous anchor's left flank (identical flanks => tied chains)."""
     rng = np.random.RandomState(seed)
     out = []
     prev_left = None
+    repeat = rand_dna(rng, repeat_len) if repeat_len else b""    # the same element inside every allele: a high-copy unipath
     for i in range(n_anchors):
         st = 10000 * (i + 1)
         alen = rng.randint(allele[0], allele[1] + 1)
@@ -36,6 +37,8 @@ def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, du
             al = (unit * (alen // len(unit) + 1))[:alen]
         else:
             al = rand_dna(rng, alen)
+        if repeat_len:
+            al = al[:alen // 2] + repeat + al[alen // 2:]
         right = rand_dna(rng, edge)
         seq = left + al + right
         prev_left = left
@@ -66,7 +69,16 @@ def _mutate(rng, s, kind, maxindel=8):
 
 
 def make_reads(anchors, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, miss_frac=0.2, n_frac=0.01,
-               str_frac=0.02, stat=(150, 200, 400, 600), unmapped_frac=0.02, fullscore_frac=0.02):
+               str_frac=0.02, stat=(150, 200, 400, 600), unmapped_frac=0.02, fullscore_frac=0.02, lengths=None, heavy_n_frac=0.0,
+               center_frac=0.0):
+    """lengths: optional list of read lengths drawn per read (ragged batch); heavy_n_frac: reads that get 4-8 N bases;
+    center_frac: fragments centred on the middle of the anchor (where make_anchors puts the shared repeat)."""
+    Lmax = max(lengths) if lengths else L
+    return _make_reads(anchors, n_pairs, seed, Lmax, frag, maxindel, miss_frac, n_frac, str_frac, stat, unmapped_frac, fullscore_frac, lengths, heavy_n_frac,
+                       center_frac)
+
+
+def _make_reads(anchors, n_pairs, seed, L, frag, maxindel, miss_frac, n_frac, str_frac, stat, unmapped_frac, fullscore_frac, lengths, heavy_n_frac, center_frac):
     """Returns a list of (name, comment, seq, qual) FASTQ records, two per pair (interleaved)."""
     rng = np.random.RandomState(seed)
     recs = []
@@ -81,6 +93,8 @@ def make_reads(anchors, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, mi
             name, seq = anchors[a]
             flen = min(rng.randint(frag[0], frag[1] + 1), len(seq) - 2 * maxindel - 2)
             off = rng.randint(0, len(seq) - flen - 2 * maxindel - 1)
+            if center_frac and rng.random_sample() < center_frac:
+                off = max(0, min(len(seq) - flen - 2 * maxindel - 2, len(seq) // 2 - rng.randint(40, L)))
             fragment = seq[off:off + flen + 2 * maxindel + 2]
             st_pos = int(name.split("_")[2])
         ends = []
@@ -90,16 +104,22 @@ def make_reads(anchors, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, mi
                 src = fragment[:L + maxindel]
             else:
                 src = revcomp(fragment[flen - L - maxindel:flen])
-            r = _mutate(rng, src, kind, maxindel)[:L]
+            Lr = int(rng.choice(lengths)) if lengths else L
+            r = _mutate(rng, src, kind, maxindel)[:Lr]
+            if heavy_n_frac and rng.random_sample() < heavy_n_frac:
+                b = bytearray(r)
+                for _ in range(rng.randint(4, 9)):
+                    b[rng.randint(len(b))] = ord("N")
+                r = bytes(b)
             if rng.random_sample() < str_frac:
                 unit = rand_dna(rng, rng.randint(2, 6))
-                k = rng.randint(30, 90)
-                s0 = rng.randint(0, L - k)
+                k = rng.randint(30, min(90, len(r) - 5))
+                s0 = rng.randint(0, len(r) - k)
                 r = r[:s0] + (unit * (k // len(unit) + 1))[:k] + r[s0 + k:]
             if rng.random_sample() < n_frac:
                 b = bytearray(r)
                 for _ in range(rng.randint(1, 3)):
-                    b[rng.randint(L)] = ord("N")
+                    b[rng.randint(len(b))] = ord("N")
                 r = bytes(b)
             ends.append(r)
         swap = rng.random_sample() < 0.5         # which mate is "first in pair"
@@ -113,18 +133,19 @@ def make_reads(anchors, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, mi
             unm = rng.random_sample() < unmapped_frac
             full = (not unm) and rng.random_sample() < fullscore_frac
             tid = 30 if unm else 0                # tid > 24 => treated as unmapped (read_realignment.cpp:413)
+            Lk = len(ends[e])
             softl = 0 if full else 40
-            score = 2 * L if full else 140
+            score = 2 * Lk if full else 140
             pos = pos1 if fwd else pos2
             mpos = pos2 if fwd else pos1
             flag = (0x40 if k == 0 else 0x80) | 0x1 | (0 if fwd else 0x10) | (0x20 if fwd else 0)
-            cigar = "%dM" % L if full else "40S%dM" % (L - 40)
+            cigar = "%dM" % Lk if full else "40S%dM" % (Lk - 40)
             c = "%d_%d_%d_%d_20_20_0_0_%d_%sN%sY_%sNNY_" % (tid, pos, softl, score, isize, "F" if fwd else "R",
                                                            "N", "R" if fwd else "F")
             if p == 0 and k == 0 and stat is not None:
                 c += "STAT_%d_%d_%d_%d_" % stat
             c += "FLAG_%d_20_CIGAR_%s_MATE_0_%d_%d_TAG_NM:i:3_" % (flag, cigar, mpos, isize if fwd else -isize)
-            qual = bytes(33 + rng.randint(20, 41, size=L).astype(np.uint8))
+            qual = bytes(33 + rng.randint(20, 41, size=Lk).astype(np.uint8))
             recs.append((names, c, ends[e].decode(), qual.decode()))
     return recs
 
