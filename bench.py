@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -36,6 +37,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU (configs[1]: 1 M)")
     ap.add_argument("--anchors", type=int, default=10000)
     ap.add_argument("--cpu-pairs", type=int, default=60000, help="pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--check-pairs", type=int, default=50000, help="pairs of the sample whose engine records are compared with the CPU run")
+    ap.add_argument("--no-ref-cpu", action="store_true", help="time only the oracle port even if oracle/_ref/ref_aln is present")
     args = ap.parse_args()
 
     import numpy as np
@@ -65,6 +68,7 @@ def main():
     ix_arrays = bench_data.build_index(anc, dense=True)
     index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
     ix_sparse, ix_small = ix_arrays["hash_sparse"], {k: v for k, v in ix_arrays.items() if k != "hash"}
+    ix_hash = ix_arrays["hash"] if rank == 0 and args.cpu_pairs > 0 else None
     del ix_arrays
     bases, base_off, ori, isize = bench_data.make_reads(anc, args.pairs, seed=13 + rank)
     eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
@@ -119,33 +123,56 @@ def main():
     eng.run(stats=True)
     st = eng.stats()
     dom = max(kern, key=lambda k: kern[k]["ms"])
-    roofline, cpu = None, None
+    roofline, cpu, parity = None, None, None
     if rank == 0:
         # algorithmic bytes per read, counted by the oracle on the CPU sample below
-        tmp = tempfile.mkdtemp(prefix="psvr_bench_")
+        shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (6 << 30)
+        tmp = tempfile.mkdtemp(prefix="psvr_bench_", dir="/dev/shm" if shm_ok else None)
         n_cpu = min(args.cpu_pairs, args.pairs)
         bytes_per_read, seed_bytes_per_read = None, None
         if n_cpu > 0:
+            ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_aln")      # the reference's own aligner objects (oracle/Makefile)
+            have_ref = os.path.exists(ref_exe) and not args.no_ref_cpu and shm_ok     # its loader reads the dense 2 GiB table: RAM-backed tmp only
             ix_small["hash_sparse"] = ix_sparse
-            bench_data.write_index_dir(ix_small, os.path.join(tmp, "idx"))
+            bench_data.write_index_dir(ix_small, os.path.join(tmp, "idx"), dense_hash=ix_hash if have_ref else None)
             bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, n_pairs=n_cpu)
             with open(os.path.join(tmp, "header.sam"), "w") as f:
                 f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")
+            base = [os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam")]
+
+            def timed(cmd, out_path):
+                # the executables report the wall of their per-pair loop on stderr (index load excluded)
+                with open(out_path, "w") as fo:
+                    err = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, check=True).stderr.decode()
+                return max(float([l for l in err.split("\n") if l.startswith("ALIGN_SECONDS")][-1].split()[1]), 1e-9)
+
             exe = os.path.join(ROOT, "oracle", "aln_oracle")
-            tc = time.time()
-            out = subprocess.run([exe, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam"), "--stats"],
-                                 stdout=subprocess.PIPE, check=True).stdout.decode()
-            tc = time.time() - tc
-            # subtract the index/FASTQ load by timing a zero-read run
-            tl = time.time()
-            subprocess.run([exe, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam"), "--stats", "--limit", "0"],
-                           stdout=subprocess.PIPE, check=True)
-            tl = time.time() - tl
-            cs = json.loads(out.strip().split("\n")[-1])
-            cpu = {"value": round(2 * n_cpu / max(tc - tl, 1e-9), 1), "unit": "reads/s", "cores": 1, "kind": "port",
-                   "sample": "first %d pairs of the same workload, oracle/aln_oracle -t 1 equivalent (scalar C++ restatement), index load excluded" % n_cpu}
+            tc = timed([exe] + base + ["--stats", "--print"], os.path.join(tmp, "port.jsonl"))
+            port_lines = open(os.path.join(tmp, "port.jsonl")).read().strip().split("\n")
+            cs = json.loads(port_lines[-1])
             bytes_per_read = cs["bytes"]["total"] / (2.0 * n_cpu)
             seed_bytes_per_read = (cs["bytes"]["probe"] + cs["bytes"]["hit"] + cs["bytes"]["read"]) / (2.0 * n_cpu)
+            port_rate = round(2 * n_cpu / tc, 1)
+            cpu = {"value": port_rate, "unit": "reads/s", "cores": 1, "kind": "port",
+                   "sample": "first %d pairs of the same workload, oracle/aln_oracle (scalar C++ restatement, -t 1 equivalent), index load excluded" % n_cpu}
+            want = [json.loads(l) for l in port_lines[:-1] if l.startswith("{")][:n_cpu]
+            against = "oracle/aln_oracle"
+            if have_ref:
+                tr = timed([ref_exe] + base, os.path.join(tmp, "ref.jsonl"))
+                cpu = {"value": round(2 * n_cpu / tr, 1), "unit": "reads/s", "cores": 1, "kind": "reference", "port_value": port_rate,
+                       "sample": "first %d pairs of the same workload through the reference's own aligner objects (oracle/_ref/ref_aln: read_realignment/deBGA_index/"
+                                 "graph/ksw2_extd2_sse compiled from the reference tree, -t 1 code path, no BAM encode), index load excluded; port_value = oracle/aln_oracle on the same sample" % n_cpu}
+                want = [json.loads(l) for l in open(os.path.join(tmp, "ref.jsonl")) if l.lstrip().startswith("{")][:n_cpu]
+                against = "oracle/_ref/ref_aln (reference objects)"
+            # the batch just timed, checked against the CPU run on that sample (checker only; nothing here is timed)
+            import aln_common as ac
+            n_chk = min(n_cpu, args.check_pairs)
+            reads_o, pairs_o, cig_o = eng.download()
+            lens = np.diff(base_off)
+            got = ac.engine_records(reads_o, pairs_o, cig_o, ori, lens, 0, n_chk)
+            differ = sum(1 for i in range(n_chk) if got[i] != want[i])
+            parity = {"pairs_checked": n_chk, "pairs_differing": differ, "against": against}
+            shutil.rmtree(tmp, ignore_errors=True)
         launches = max(1, kern[dom]["launches"])
         avg_ms = kern[dom]["ms"] / launches
         share = {"k_seed": seed_bytes_per_read}.get(dom, bytes_per_read)
@@ -174,7 +201,7 @@ def main():
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank, %d iteration(s)/step" % (max(exchange_iters) if exchange_iters else 0)),
                                                  "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
-                "roofline": roofline, "cpu_baseline": cpu,
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity,
                 "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include "ksw_oracle.h"
 
@@ -1032,15 +1033,17 @@ bool read_fastq_record(FILE *f, Read *r)
 } // namespace orc
 
 #ifdef ORC_ALN_MAIN
-// aln_oracle <index_dir> <reads.fq> <header.sam> [--trace] [--limit N] [--stats]
+// aln_oracle <index_dir> <reads.fq> <header.sam> [--trace] [--limit N] [--stats [--print]]
+// stderr: "ALIGN_SECONDS <s>" = wall of the per-pair loop alone (index load excluded), which bench.py reports.
 int main(int argc, char **argv)
 {
 	if (argc < 4) { fprintf(stderr, "usage: aln_oracle <index_dir> <reads.fq> <header.sam> [--trace] [--limit N] [--stats]\n"); return 1; }
-	bool trace = false, stats = false;
+	bool trace = false, stats = false, print = false;
 	long limit = -1;
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
 		else if (!strcmp(argv[i], "--stats")) stats = true;
+		else if (!strcmp(argv[i], "--print")) print = true;
 		else if (!strcmp(argv[i], "--limit") && i + 1 < argc) limit = atol(argv[++i]);
 	}
 	std::vector<std::string> names;
@@ -1053,11 +1056,15 @@ int main(int argc, char **argv)
 	if (!fq) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
 	orc::Read r1, r2;
 	long i = 0;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
 	while ((limit < 0 || i < limit) && orc::read_fastq_record(fq, &r1) && orc::read_fastq_record(fq, &r2)) {
 		std::string line = orc::aligner_pair(a, r1, r2, i, trace);
-		if (!stats) puts(line.c_str());
+		if (!stats || print) puts(line.c_str());
 		++i;
 	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	fprintf(stderr, "ALIGN_SECONDS %.6f\n", (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
 	if (stats) {
 		const orc::Counters &c = orc::aligner_counters(a);
 		printf("{\"pairs\":%ld,\"reads_aligned\":%llu,\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_calls\":%llu,\"simple_calls\":%llu,\"dp_cells\":%llu,"

@@ -64,10 +64,13 @@ def build_index(anc, dense=True):
                 posp=np.arange(U + 1, dtype=np.uint64), hash=h, hash_sparse=sparse, kmer=(v & np.uint64(0xffff)).astype(np.uint32), off=offs, chr=chr_text)
 
 
-def write_index_dir(ix, path):
-    """On-disk form for the oracle executable (sparse first level, see tests/index_fixture.py)."""
+def write_index_dir(ix, path, dense_hash=None):
+    """On-disk form for the oracle executable (sparse first level, see tests/index_fixture.py).  dense_hash: also write the
+    2 GiB prefix-sum table unipath_g.hash, which the reference's own loader (oracle/_ref/ref_aln) reads."""
     import os
     os.makedirs(path, exist_ok=True)
+    if dense_hash is not None:
+        dense_hash.tofile(os.path.join(path, "unipath_g.hash"))
     for f, k in (("ref.seq", "ref_seq"), ("unipath.seqb", "seq"), ("unipath.seqfb", "seqf"), ("unipath.pos", "pos"), ("unipath.posp", "posp"),
                  ("unipath_g.kmer", "kmer"), ("unipath_g.offset", "off")):
         ix[k].tofile(os.path.join(path, f))

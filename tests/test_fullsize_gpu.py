@@ -26,30 +26,7 @@ N_PAIRS = int(os.environ.get("PSVR_FULLSIZE_PAIRS", "1000000"))
 N_ORACLE = 20000
 
 
-def records(reads, pairs, cig, ori, lens, lo, hi):
-    out = []
-    for p in range(lo, hi):
-        rr = []
-        for k in range(2):
-            r = reads[2 * p + k]
-            res = []
-            for i in range(int(r["n_result"])):
-                c = r["cand"][i]
-                ops = cig[int(c["cigar_off"]):int(c["cigar_off"]) + int(c["n_cigar"])]
-                cg = "".join("%d%s" % (int(np.int16(int(w) >> 4)), "MIDNSHP=XB"[int(w) & 0xf]) for w in ops)
-                res.append([int(c["align_score"]), int(c["chain_score"]), int(c["chr_id"]), int(c["ref_bg"]), int(c["read_bg"]), int(c["direction"]), int(c["mapq"]), cg])
-            o = ori[2 * p + k]
-            oc = ("%dS" % o["read_bg"] if o["read_bg"] > 0 else "") + "%dM" % (lens[2 * p + k] - int(o["read_bg"]))
-            d = {"n": int(r["n_result"]), "unmapped": int(r["unmapped"]), "res": res,
-                 "ori": [int(o["align_score"]), 0, int(o["chr_id"]), int(o["ref_bg"]), int(o["read_bg"]), int(o["direction"]), int(o["mapq"]), oc]}
-            if pairs[p]["gain"]:
-                d["prim"], d["sec"] = int(r["primary"]), int(r["secondary"])
-                if r["primary"] != -1:
-                    d["mate"] = [int(r["has_mate"]), int(r["mate_chr_id"]) if r["has_mate"] else 0, int(r["mate_ref_bg"]) if r["has_mate"] else 0]
-            rr.append(d)
-        q = pairs[p]
-        out.append({"i": p, "reads": rr, "pe": [int(q["max_score"]), int(q["cur_isize"]), int(q["proper"]), int(q["gain"]), int(q["max1"]), int(q["max2"])]})
-    return out
+records = ac.engine_records
 
 
 def canon(reads, cig):
