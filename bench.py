@@ -123,6 +123,18 @@ def main():
     eng.run(stats=True)
     st = eng.stats()
     dom = max(kern, key=lambda k: kern[k]["ms"])
+    # the boundary hands over host buffers: one extra, separately reported pass incl. H2D of the batch and D2H of the results
+    torch.cuda.synchronize()
+    tp = time.time()
+    eng.upload(bases, base_off, ori)
+    eng.set_stream_pos([2, 0, 0])      # a new upload continues the reference's rand() streams; this is the same first batch again
+    eng.run()
+    out_host = eng.download()
+    tp = time.time() - tp
+    pcie = {"reads_per_s": round(2 * args.pairs / tp, 1), "ms": round(tp * 1e3, 2),
+            "h2d_bytes": int(bases.nbytes + base_off.nbytes + ori.nbytes), "d2h_bytes": int(sum(a.nbytes for a in out_host)),
+            "note": "upload (pageable host memory) + run + download of one batch through psvr_engine_upload/run/download; not `value`"}
+    del out_host
     roofline, cpu, parity = None, None, None
     if rank == 0:
         # algorithmic bytes per read, counted by the oracle on the CPU sample below
@@ -201,7 +213,7 @@ def main():
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank, %d iteration(s)/step" % (max(exchange_iters) if exchange_iters else 0)),
                                                  "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
-                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity,
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "pcie_inclusive": pcie,
                 "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)

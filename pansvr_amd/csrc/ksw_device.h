@@ -107,6 +107,14 @@ __host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_
 
 __device__ __forceinline__ int s8(int v) { return (int)(int8_t)v; }
 
+// mark a value the code knows to be identical in all lanes of the wavefront as uniform (-> SGPR, scalar control flow)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v)
+{
+	const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+	return (long long)((unsigned long long)hi << 32 | lo);
+}
+
 // DPP controls (GFX9): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
 __device__ __forceinline__ int dpp_wave_shr1(int v, int carry_in)
 {

@@ -140,19 +140,167 @@ __device__ __forceinline__ void dp_main_loop(const DpParams &P, const uint8_t *t
 #undef W8
 }
 
+// The sweep for problems whose band never clips the matrix and whose in-band values fit int8 (P.nowrap_ok &&
+// dp_band_never_binds): the common case on the `aln` path (qlen <= 200, tlen <= 201).  Same results as dp_main_loop, far
+// fewer instructions per anti-diagonal:
+//   * an in-band cell only ever reads in-band cells of the previous diagonal or one of the explicit boundary values
+//     (:142-156), so the lanes outside [st0,en0] may hold anything: no select keeps their state, the 16-lane block
+//     rounding, the stale-score lanes and the 8-bit wrap are not modelled at all;
+//   * the left boundary of the band is simply the carry shifted into lane 0 of chunk 0; the first-row boundary is written
+//     into lane r before the sweep of the diagonal;
+//   * all band / z-drop / end-score bookkeeping is wave-uniform (SGPRs, scalar branches);
+//   * the arg-max lane is found with a ballot; the reference's 4-lane tie order is only evaluated when two lanes tie.
+template <int K>
+__device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *target, int lane, int qlen, int tlen, int rowb, int n_rows,
+                                             const uint8_t *QR, uint8_t *Pm, EzAcc &ez_out)
+{
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
+	int u[K], v[K], x[K], y[K], x2[K], y2[K], H[K], tb[K], mis[K];
+#pragma unroll
+	for (int c = 0; c < K; ++c) {
+		const int t = c * 64 + lane;
+		u[c] = v[c] = x[c] = y[c] = neg_qe;
+		x2[c] = y2[c] = neg_qe2;
+		H[c] = -P.qe_pre;                 // H[0] = v - qe on the first diagonal (:351); every other lane is set before it is read
+		const int tc = t < tlen ? target[t] : 0;
+		tb[c] = tc == P.m1 ? 0x100 : tc;  // an N never equals a query code
+		mis[c] = tc == P.m1 ? P.sc_N : P.sc_mis;
+	}
+	__builtin_amdgcn_wave_barrier();
+	int e_max = 0, e_max_t = -1, e_max_q = -1, e_mqe = PSVR_KSW_NEG_INF, e_mqe_t = -1, e_mte = PSVR_KSW_NEG_INF, e_mte_q = -1;
+	int e_score = PSVR_KSW_NEG_INF, e_zd = 0;
+	for (int r = 0; r < n_rows; ++r) {
+		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
+		const int ur = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
+		const int c_first = st0 >> 6, c_last = en0 >> 6;
+		const int qbase = qlen - 1 - r;
+		const unsigned prow = (unsigned)(r * rowb - (st0 & ~15));
+		int h_prev = 0;
+#pragma unroll
+		for (int c = 0; c < K; ++c) {
+			if (en0 > 0 && ((en0 - 1) >> 6) == c) h_prev = __builtin_amdgcn_readlane(H[c], (en0 - 1) & 63);
+			if (en0 == r && (r >> 6) == c) {      // first cell of column r (:153-156)
+				const bool first = lane == (r & 63);
+				u[c] = first ? ur : u[c], y[c] = first ? neg_qe : y[c], y2[c] = first ? neg_qe2 : y2[c];
+			}
+		}
+		const int sel_t = en0 > 0 ? en0 : -1;
+		int bh = (int)0x80000000;
+		unsigned long long amask[K];
+#pragma unroll
+		for (int c = K - 1; c >= 0; --c) {
+			amask[c] = 0;
+			if (c < c_first || c > c_last) continue;
+			const int t = c * 64 + lane;
+			// (r-1,t-1): lane 0 of chunk 0 receives the boundary values of column -1 (:142-152), other chunks the old lane 63
+			int cx = neg_qe, cv = ur, cx2 = neg_qe2;
+			if (c > 0) {
+				cx = __builtin_amdgcn_readlane(x[c - 1], 63);
+				cv = __builtin_amdgcn_readlane(v[c - 1], 63);
+				cx2 = __builtin_amdgcn_readlane(x2[c - 1], 63);
+			}
+			const int xt1 = dpp_wave_shr1(x[c], cx), vt1 = dpp_wave_shr1(v[c], cv), x2t1 = dpp_wave_shr1(x2[c], cx2);
+			const int qb = QR[(unsigned)(qbase + t)];
+			int sc = tb[c] == qb ? P.sc_mch : mis[c];
+			sc = qb == P.m1 ? P.sc_N : sc;
+			const int ut = u[c];
+			int a = xt1 + vt1, b = y[c] + ut, a2 = x2t1 + vt1, b2 = y2[c] + ut;
+			int z = max(max(sc, a), b);
+			z = max(max(z, a2), b2);
+			int d = 4;                                     // first of {sc,a,b,a2,b2} that reaches the maximum (:176-213)
+			d = a2 == z ? 3 : d;
+			d = b == z ? 2 : d;
+			d = a == z ? 1 : d;
+			d = sc == z ? 0 : d;
+			z = min(z, P.sc_mch);
+			const int un = z - vt1, vn = z - ut;
+			const int zq = z - P.q, zq2 = z - P.q2;
+			a -= zq, b -= zq, a2 -= zq2, b2 -= zq2;
+			d |= (a > 0 ? 0x08 : 0) | (b > 0 ? 0x10 : 0) | (a2 > 0 ? 0x20 : 0) | (b2 > 0 ? 0x40 : 0);
+			u[c] = un, v[c] = vn;
+			x[c] = max(a, 0) - qe8, y[c] = max(b, 0) - qe8;
+			x2[c] = max(a2, 0) - qe28, y2[c] = max(b2, 0) - qe28;
+			// exact H (:316-351): the last in-band lane continues from its left neighbour, the others from themselves
+			const int hn = t == sel_t ? h_prev + un : H[c] + vn;
+			H[c] = hn;
+			const bool act = (t >= st0) & (t <= en0);
+			amask[c] = __ballot(act);
+			if (act) {
+				if (with_cigar) Pm[prow + (unsigned)t] = (uint8_t)d;
+				bh = max(bh, hn);
+			}
+		}
+		const int max_H = wave_max_i32(bh);
+		// arg-max: usually a single lane holds the maximum
+		int n_top = 0, max_t = 0;
+		unsigned long long top[K];
+#pragma unroll
+		for (int c = 0; c < K; ++c) {
+			top[c] = 0;
+			if (c < c_first || c > c_last) continue;
+			top[c] = __ballot(H[c] == max_H) & amask[c];
+			n_top += __popcll(top[c]);
+			if (top[c]) max_t = c * 64 + __ffsll((unsigned long long)top[c]) - 1;
+		}
+		if (n_top != 1) {                                  // the reference's order among equal lanes (:322-349)
+			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			unsigned bk = 0xffffffffu;
+#pragma unroll
+			for (int c = 0; c < K; ++c) {
+				const int t = c * 64 + lane;
+				const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
+				                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
+				if ((top[c] >> lane) & 1) bk = min(bk, rank);
+			}
+			const unsigned rk = wave_min_u32(bk);
+			max_t = rk == 0 ? en0 : st0 + (int)((rk - 1u) & 4095u);
+		}
+		if (en0 == tlen - 1) {
+			int H_en0 = 0;
+#pragma unroll
+			for (int c = 0; c < K; ++c)
+				if ((en0 >> 6) == c) H_en0 = __builtin_amdgcn_readlane(H[c], en0 & 63);
+			if (H_en0 > e_mte) e_mte = H_en0, e_mte_q = r - (((en0 + 16) & ~15) - 1);
+			if (r == n_rows - 1) e_score = H_en0;
+		}
+		if (r - st0 == qlen - 1) {
+			int H_st0 = 0;
+#pragma unroll
+			for (int c = 0; c < K; ++c)
+				if ((st0 >> 6) == c) H_st0 = __builtin_amdgcn_readlane(H[c], st0 & 63);
+			if (H_st0 > e_mqe) e_mqe = H_st0, e_mqe_t = st0;
+		}
+		// ksw_apply_zdrop, is_rot = 1 (ksw2.h:245-261)
+		if (max_H > e_max) {
+			e_max = max_H, e_max_t = max_t, e_max_q = r - max_t;
+		} else if (max_t >= e_max_t && r - max_t >= e_max_q) {
+			const int tl = max_t - e_max_t, ql = (r - max_t) - e_max_q;
+			const int l = tl > ql ? tl - ql : ql - tl;
+			if (P.zdrop >= 0 && e_max - max_H > P.zdrop + l * P.e2) { e_zd = 1; break; }
+		}
+	}
+	ez_out.max = e_max, ez_out.max_t = e_max_t, ez_out.max_q = e_max_q;
+	ez_out.mqe = e_mqe, ez_out.mqe_t = e_mqe_t, ez_out.mte = e_mte, ez_out.mte_q = e_mte_q;
+	ez_out.score = e_score, ez_out.zdropped = e_zd;
+}
+
 // kDpWaves independent alignments per workgroup (one per wavefront, no inter-wave communication): single-wave workgroups
 // run into the workgroups-per-CU limit long before the wave slots are full
 template <int K, bool PG>
 __global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpParams P)
 {
 	extern __shared__ __align__(16) uint8_t lds_all[];
-	const int wave = threadIdx.x >> 6;
+	// everything per-alignment is wave-uniform; threadIdx.x >> 6 is not provably so for the compiler, and without the
+	// readfirstlane all band / z-drop bookkeeping of the sweep is done per lane in VALU with exec-mask control flow
+	const int wave = uni(threadIdx.x >> 6);
 	const long long slot = (long long)blockIdx.x * kDpWaves + wave;
 	if (slot >= B.n) return;
 	uint8_t *lds = lds_all + (size_t)wave * B.lds_per_wave;
-	const int pid = B.idx[slot];
+	const int pid = uni(B.idx[slot]);
 	const int lane = threadIdx.x & 63;
-	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
+	const int qlen = uni(B.qlen[pid]), tlen = uni(B.tlen[pid]);
 	psvr_extz_t *out = B.ez + pid;
 	EzAcc ez;
 	ez.reset();
@@ -160,7 +308,7 @@ __global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpP
 		if (lane == 0) write_ez(out, ez, 0);
 		return;
 	}
-	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
+	const uint8_t *query = B.qseq + uni64(B.q_off[pid]), *target = B.tseq + uni64(B.t_off[pid]);
 	const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
 	int n_col = qlen < tlen ? qlen : tlen;
 	n_col = ((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1;
@@ -169,13 +317,13 @@ __global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpP
 	const int qimg = (qlen + 16 + 15) & ~15;
 	uint8_t *QR = lds;                 // reversed query + >=16 zero bytes (the calloc'ed tail of `qr`, :100,121)
 	// direction bytes, row pitch rowb (:115): behind the query image in LDS, or (PG) in this problem's slice of the HBM slab
-	uint8_t *Pm = PG ? B.pslab + (B.p_off[pid] << B.p_unit_shift) : lds + qimg;
+	uint8_t *Pm = PG ? B.pslab + (uni64(B.p_off[pid]) << B.p_unit_shift) : lds + qimg;
 	const int p_end = n_rows * rowb + 16;
 	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
 	// 8-bit wrap-around only has to be emulated when it can be observed: if the band never clips the matrix, in-band cells
 	// never read a lane outside the band (dp_band_never_binds) and all in-band values fit int8 for these scoring parameters
 	// (P.nowrap_ok, make_dp_params), so the sign-extension after every add/sub is dropped
-	if (P.nowrap_ok && dp_band_never_binds(qlen, tlen, w)) dp_main_loop<K, false>(P, target, lane, qlen, tlen, w, rowb, n_rows, QR, Pm, ez);
+	if (P.nowrap_ok && dp_band_never_binds(qlen, tlen, w)) dp_lean_loop<K>(P, target, lane, qlen, tlen, rowb, n_rows, QR, Pm, ez);
 	else dp_main_loop<K, true>(P, target, lane, qlen, tlen, w, rowb, n_rows, QR, Pm, ez);
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	int n_cigar = 0;
@@ -194,7 +342,7 @@ __global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpP
 				[&](int k, uint32_t word) { if (lane == 0) stage_end[-1 - k] = word; });
 			if (PG) __threadfence_block();
 			__builtin_amdgcn_wave_barrier();
-			uint32_t *dst = B.cigar + out->cigar_off;
+			uint32_t *dst = B.cigar + uni64(out->cigar_off);
 			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
 			for (int m = lane; m < n_cigar; m += 64) {
 				const uint32_t *src = rev ? stage_end - 1 - m : stage_end - n_cigar + m;
@@ -457,7 +605,7 @@ __global__ __launch_bounds__(64) void extd2_lds_kernel(DpBatch B, DpParams P)
 		else if (!ez.zdropped && (flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
 		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
 		if (i0 >= 0 && j0 >= 0) {
-			uint32_t *dst = B.cigar + out->cigar_off;
+			uint32_t *dst = B.cigar + uni64(out->cigar_off);
 			n_cigar = traceback(i0, j0, qlen, tlen, w,
 				[&](int r, int k) { return (int)__builtin_nontemporal_load(Pm + (size_t)r * rowb + k); },
 				[&](int k, uint32_t word) { if (lane == 0) dst[k] = word; });
