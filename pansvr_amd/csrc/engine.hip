@@ -23,25 +23,15 @@ __device__ __forceinline__ long long pair_of(const int32_t *work, long long i) {
 
 // ---- stage kernels: one thread per item; the read-level stages run per mate ------------------------
 // prep (prep_read in aln_device.h), one wavefront per read: coalesced base loads, N draws ordered by a ballot
-// prefix, 2-bit codes staged in LDS, packed words built from wave ballots (no per-base read-modify-write).
-__device__ __forceinline__ uint64_t spread_bits(uint32_t x)
-{
-	uint64_t v = x;
-	v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-	v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-	v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-	v = (v | (v << 2)) & 0x3333333333333333ull;
-	v = (v | (v << 1)) & 0x5555555555555555ull;
-	return v;
-}
+// prefix, codes of both strands staged in LDS, then one lane per packed 32-base word (no per-base read-modify-write).
 __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate)
 {
 	extern __shared__ __align__(16) uint8_t prep_lds[];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
 	if (wi >= n) return;
 	const long long read = pair_of(work, wi) * 2 + mate;
-	uint8_t *codes = prep_lds + (size_t)wave * c.lmax;
+	uint8_t *fw = prep_lds + (size_t)wave * 2 * c.lmax, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
 	const long long sr = src_read(c, read);
 	const psvr_ori_t o = c.ori[sr];
 	const int L = (int)(c.base_off[sr + 1] - c.base_off[sr]);
@@ -60,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	const long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0);
 	int draws = 0;
 	bool any4 = false;
-	for (int i0 = 0; i0 < L; i0 += 64) {
+	for (int i0 = 0; i0 < c.lmax; i0 += 64) {
 		const int i = i0 + lane;
 		char ch = i < L ? s[i] : 'A';
 		const bool isn = i < L && ch == 'N';
@@ -75,28 +65,30 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 		}
 		draws += __popcll(m);
 		const uint8_t code = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0;
-		if (i < L) codes[i] = code, b0[i] = code, b1[L - 1 - i] = code ^ 3;
+		if (i < L) fw[i] = code, rv[L - 1 - i] = code ^ 3, b0[i] = code, b1[L - 1 - i] = code ^ 3;
+		else if (i < c.lmax) fw[i] = 0, rv[i] = 0;
 		any4 |= __ballot(i < L && code > 3) != 0;
 	}
 	if (lane == 0) c.has_n4[read] = any4;
-	// packed words of both strands (binary_read_64_bit, rr.cpp:295-300): word = OR of code << 2*(31 - (i & 31)); a code of 4
-	// (lower-case n) spills its third bit into the neighbouring base exactly as the reference's shift does
-	for (int s2 = 0; s2 < 2; ++s2) {
-		uint64_t *wout = s2 ? w1 : w0;
-		for (int i0 = 0; i0 < c.wmax * 32; i0 += 64) {
-			const int i = i0 + lane;
-			const unsigned code = i < L ? (s2 ? (unsigned)(codes[L - 1 - i] ^ 3) : (unsigned)codes[i]) : 0u;
-			const unsigned long long m0 = __ballot(code & 1), m1 = __ballot(code & 2), m2 = __ballot(code & 4);
-			if (lane < 2) {
-				const int w = (i0 >> 5) + lane;
-				if (w < c.wmax) {
-					const uint32_t l0 = (uint32_t)(m0 >> (32 * lane)), l1 = (uint32_t)(m1 >> (32 * lane)), l2 = (uint32_t)(m2 >> (32 * lane));
-					uint64_t word = spread_bits(__brev(l0)) | (spread_bits(__brev(l1)) << 1);
-					word |= (spread_bits(__brev(l2)) << 2);          // bit 2 of base i lands on bit 0 of base i-1; the top base's is shifted out
-					wout[w] = word;
-				}
+	__builtin_amdgcn_wave_barrier();
+	// packed words of both strands (binary_read_64_bit, rr.cpp:295-300): word = OR of code << 2*(31 - (i & 31)).  One lane per
+	// word: four codes (one per byte of a 32-bit LDS word) are gathered MSB-first into eight bits by one multiply.
+	for (int j = lane; j < 2 * c.wmax; j += 64) {
+		const int s2 = j >= c.wmax, w = j - s2 * c.wmax;
+		uint64_t word = 0;
+		if (w * 32 < c.lmax) {
+			const uint8_t *src = (s2 ? rv : fw) + w * 32;
+			if (!any4) {
+				const uint4 lo = *(const uint4 *)src, hi = *(const uint4 *)(src + 16);
+				const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+				for (int g = 0; g < 8; ++g) word |= (uint64_t)((x[g] * 0x40100401u) >> 24) << (56 - 8 * g);
+			} else {
+				// a code of 4 (lower-case n) spills its third bit into the neighbouring base exactly as the reference's shift does
+				for (int k = 0; k < 32; ++k) word |= ((uint64_t)src[k]) << ((31 - k) << 1);
 			}
 		}
+		(s2 ? w1 : w0)[w] = word;
 	}
 	if (lane == 0) { c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1); }
 }
@@ -107,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *work, long long n, int mate, int tsize, int per_wave)
 {
 	extern __shared__ __align__(16) uint8_t str_lds[];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
 	if (wi >= n) return;
 	const long long read = pair_of(work, wi) * 2 + mate;
@@ -465,7 +457,7 @@ struct GpuBE {
 	{
 		if (n <= 0) return;
 		t0("k_prep");
-		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * c.lmax, stream, c, w, n, mate);
+		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * 2 * c.lmax, stream, c, w, n, mate);
 		t1();
 		note(hipGetLastError());
 	}

@@ -17,7 +17,8 @@ DATASETS = {
     "fx3": dict(anchors=dict(n_anchors=620, seed=31, edge=300, allele=(120, 200), repeat_len=70),
                 reads={"ragged": dict(n_pairs=1200, seed=37, lengths=[100, 101, 126, 150, 151, 200, 250], frag=(520, 560), maxindel=8, n_frac=0.03,
                                       heavy_n_frac=0.03, stat=(150, 300, 500, 800)),
-                       "repeat": dict(n_pairs=300, seed=41, L=150, frag=(300, 420), center_frac=0.9, miss_frac=0.05)}),
+                       "repeat": dict(n_pairs=300, seed=41, L=150, frag=(300, 420), center_frac=0.9, miss_frac=0.05),
+                       "lower": dict(n_pairs=300, seed=43, L=150, frag=(520, 560), lower_frac=0.5, stat=(150, 300, 500, 800))}),
 }
 
 

@@ -42,8 +42,8 @@ def main(names):
             res = subprocess.run([os.path.join(REF, "ref_aln"), idx, os.path.join(work, rname + ".fq"), os.path.join(work, "header.sam"), "--trace"],
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
             lines = [l for l in res.stdout.decode().split("\n") if l.startswith("{") or l.startswith(" {")]
-            with gzip.open(os.path.join(out, rname + ".jsonl.gz"), "wt") as f:
-                f.write("\n".join(l.strip() for l in lines) + "\n")
+            with open(os.path.join(out, rname + ".jsonl.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:   # mtime=0: reproducible bytes
+                f.write(("\n".join(l.strip() for l in lines) + "\n").encode())
             print(name, rname, len(lines), "pairs")
 
 

@@ -70,15 +70,17 @@ def _mutate(rng, s, kind, maxindel=8):
 
 def make_reads(anchors, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, miss_frac=0.2, n_frac=0.01,
                str_frac=0.02, stat=(150, 200, 400, 600), unmapped_frac=0.02, fullscore_frac=0.02, lengths=None, heavy_n_frac=0.0,
-               center_frac=0.0):
+               center_frac=0.0, lower_frac=0.0):
     """lengths: optional list of read lengths drawn per read (ragged batch); heavy_n_frac: reads that get 4-8 N bases;
-    center_frac: fragments centred on the middle of the anchor (where make_anchors puts the shared repeat)."""
+    center_frac: fragments centred on the middle of the anchor (where make_anchors puts the shared repeat);
+    lower_frac: reads with a few lower-case bases and lower-case n (charToDna5n maps n to code 4, which spills a bit into the
+    neighbouring base of the packed read words)."""
     Lmax = max(lengths) if lengths else L
     return _make_reads(anchors, n_pairs, seed, Lmax, frag, maxindel, miss_frac, n_frac, str_frac, stat, unmapped_frac, fullscore_frac, lengths, heavy_n_frac,
-                       center_frac)
+                       center_frac, lower_frac)
 
 
-def _make_reads(anchors, n_pairs, seed, L, frag, maxindel, miss_frac, n_frac, str_frac, stat, unmapped_frac, fullscore_frac, lengths, heavy_n_frac, center_frac):
+def _make_reads(anchors, n_pairs, seed, L, frag, maxindel, miss_frac, n_frac, str_frac, stat, unmapped_frac, fullscore_frac, lengths, heavy_n_frac, center_frac, lower_frac=0.0):
     """Returns a list of (name, comment, seq, qual) FASTQ records, two per pair (interleaved)."""
     rng = np.random.RandomState(seed)
     recs = []
@@ -110,6 +112,14 @@ def _make_reads(anchors, n_pairs, seed, L, frag, maxindel, miss_frac, n_frac, st
                 b = bytearray(r)
                 for _ in range(rng.randint(4, 9)):
                     b[rng.randint(len(b))] = ord("N")
+                r = bytes(b)
+            if lower_frac and rng.random_sample() < lower_frac:
+                b = bytearray(r)
+                for _ in range(rng.randint(1, 6)):
+                    k = rng.randint(len(b))
+                    b[k] = ord(chr(b[k]).lower())
+                for _ in range(rng.randint(0, 3)):
+                    b[rng.randint(len(b))] = ord("n")
                 r = bytes(b)
             if rng.random_sample() < str_frac:
                 unit = rand_dna(rng, rng.randint(2, 6))
