@@ -348,6 +348,7 @@ struct Ksw {
 				cig.resize(qlen + tlen + 2);
 				orc_extd2(qlen, qseq, tlen, tseq, 5, mat, P->gap_open, P->gap_ex, P->gap_open2, P->gap_ex2, 200, P->zdrop, -1, 0, &ez, cig.data(), (int)cig.size());
 				C->dp_calls++, C->dp_cells += (uint64_t)qlen * tlen, C->dp_out_bytes += 4 * ez.n_cigar + 40;
+				if (getenv("ORC_DP_SHAPES")) fprintf(stderr, "DP %d %d %d\n", qlen, tlen, (int)type);
 			}
 		} else C->simple_calls++;
 		if (is_simple_aln) {
