@@ -191,6 +191,17 @@ PSVR_HD uint64_t fnv1a(uint64_t h, uint64_t v)
 	return h;
 }
 
+// false: first-level bucket h is certainly empty (1-bit probe of the occupancy bitmap)
+PSVR_HD bool bucket_occupied(const DevIndex &ix, uint64_t h)
+{
+#ifdef PSVR_EMU_SPARSE_HASH
+	(void)ix, (void)h;
+	return true;
+#else
+	return !ix.occ || ((ix.occ[h >> 5] >> (h & 31)) & 1u);
+#endif
+}
+
 PSVR_HD void hash_pair(const DevIndex &ix, uint64_t h, uint64_t &lo, uint64_t &hi)
 {
 #ifdef PSVR_EMU_SPARSE_HASH
@@ -201,7 +212,6 @@ PSVR_HD void hash_pair(const DevIndex &ix, uint64_t h, uint64_t &lo, uint64_t &h
 	};
 	lo = at(h), hi = at(h + 1);
 #else
-	if (ix.occ && !((ix.occ[h >> 5] >> (h & 31)) & 1u)) { lo = hi = 0; return; }
 	lo = ix.hash[h], hi = ix.hash[h + 1];
 #endif
 }
@@ -433,13 +443,19 @@ PSVR_HD uint32_t mem_for_hit(const DevIndex &ix, uint64_t hit, const uint64_t *r
 
 // seed loop of chainning_one_read (rr.cpp:614-635) for one strand: search_kmer + binsearch_range
 // (deBGA_index.cpp:84-101, binarys_qsort.c:25-100) and UNITIG_MEM_search (deBGA_index.cpp:105-146)
-PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
+// The loop is written as a three-stage state machine so that the lanes of a wavefront regroup: all lanes first run the cheap
+// stage (skip rules + occupancy bit) until each has a k-mer whose bucket is non-empty or is done; then all of them do the
+// hash gather + bucket bisection together; that repeats until every lane holds a hit or is done, and only then the hits
+// are extended.  Written as `for off: probe; if hit: extend` the rare stages run on nearly every iteration with a handful
+// of lanes active.  Per strand the order of operations -- and every result -- is unchanged.
+// `rb_local`: optional copy of this strand's packed words in fast memory (the GPU kernel stages them in LDS).
+template <bool LOCAL> PSVR_HD void seed_strand_t(const Ctx &c, long long rs, const uint64_t *rb_local)
 {
 	const long long read = rs >> 1;
 	const int rev = (int)(rs & 1);
 	if (!c.active[read]) return;
 	const int L = c.read_l[read];
-	const uint64_t *rb = c.rb + rs * (long long)c.wmax;
+	const uint64_t *rb = LOCAL ? rb_local : c.rb + rs * (long long)c.wmax;
 	const uint8_t *sl = c.seed_list + read * (long long)c.lmax;
 	const bool is_str = c.is_str[read] != 0;
 	const uint32_t kn = L - kLenKmer + 1;
@@ -450,17 +466,25 @@ PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
 	uint32_t total = 0, probes = 0;
 	for (int pass = 0; pass < 3; ++pass) {            // 0: write into slot (counting), 1: count only (skipped), 2: fill arena slice
 		if (pass == 1) continue;
-		uint32_t n = 0, msr = 0;
-		for (uint32_t off = 0; off < kn; off += kSeedStep) {
-			if (off + kLenKmer - 1 <= msr) continue;
-			if (is_str && seed_list_at(sl, (int)kn, rev, off) == 0) continue;
-			uint64_t kmer = get_kmer(off, rb);
-			if (pass == 0) ++probes;
-			uint64_t first_hit = 0;
-			const uint32_t nh = probe_kmer(ix, kmer, first_hit);
-			if (nh == 0) continue;
-			if (nh > (uint32_t)kUniPosNMax) continue;
-			uint32_t mri = 1;
+		uint32_t n = 0, msr = 0, off = 0, nh = 0;
+		uint64_t kmer = 0, first_hit = 0;
+		int stage = 0;                                // 0: scanning, 1: bucket non-empty, 2: hits to extend
+		for (;;) {
+			while (stage != 2 && off < kn) {
+				while (off < kn) {                        // stage 0
+					if (off + kLenKmer - 1 <= msr || (is_str && seed_list_at(sl, (int)kn, rev, off) == 0)) { off += kSeedStep; continue; }
+					kmer = get_kmer(off, rb);
+					if (pass == 0) ++probes;
+					if (bucket_occupied(ix, kmer >> 12)) { stage = 1; break; }
+					off += kSeedStep;
+				}
+				if (stage != 1) break;
+				nh = probe_kmer(ix, kmer, first_hit);     // stage 1
+				if (nh == 0 || nh > (uint32_t)kUniPosNMax) { off += kSeedStep; stage = 0; }
+				else stage = 2;
+			}
+			if (stage != 2) break;
+			uint32_t mri = 1;                             // stage 2
 			for (uint64_t hit = first_hit; hit < first_hit + nh; ++hit) {
 				VMem m;
 				const uint32_t ri = mem_for_hit(ix, hit, rb, off, L, m);
@@ -470,6 +494,8 @@ PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
 				if (ri > mri) mri = ri;
 			}
 			msr = off + kLenKmer + mri - 1;
+			off += kSeedStep;
+			stage = 0;
 		}
 		if (pass == 0) {
 			total = n;
@@ -482,6 +508,7 @@ PSVR_HDN inline void seed_strand(const Ctx &c, long long rs)
 	st.mem_off = base, st.mem_n = total;
 	if (c.stats) { stat_add(c, ST_PROBES, probes); stat_add(c, ST_HITS, total); }
 }
+PSVR_HDN inline void seed_strand(const Ctx &c, long long rs) { seed_strand_t<false>(c, rs, nullptr); }
 
 // stable bottom-up merge sort of idx[0..n) by less(a,b); tmp has n entries
 template <class T, class Less> PSVR_HD void stable_sort(T *a, T *tmp, uint32_t n, Less less)

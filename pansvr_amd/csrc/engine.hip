@@ -156,10 +156,23 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 	for (int i = lane; i < kn; i += 64) out[i] = sl[i];
 }
 // K1 seed_probe + K2 mem_extend: hash gather, bucket search, unipath lookup, MEM extension
-__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n, int mate)
+// Each thread first copies its strand's packed words (wmax x 8 B) into LDS -- row pitch an odd number of 8-byte words, so the
+// lanes of a wavefront spread over the banks -- because every probe and every MEM extension re-reads them; lds_pitch == 0
+// (reads too long for the LDS budget) keeps them in global memory.
+__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n, int mate, int lds_pitch)
 {
+	extern __shared__ __align__(16) uint64_t seed_lds[];
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < 2 * n) seed_strand(c, (pair_of(work, i >> 1) * 2 + mate) * 2 + (i & 1));
+	if (i >= 2 * n) return;
+	const long long rs = (pair_of(work, i >> 1) * 2 + mate) * 2 + (i & 1);
+	if (lds_pitch) {
+		uint64_t *mine = seed_lds + (size_t)threadIdx.x * lds_pitch;
+		if (c.active[rs >> 1]) {
+			const uint64_t *src = c.rb + rs * (long long)c.wmax;
+			for (int k = 0; k < c.wmax; ++k) mine[k] = src[k];
+		}
+		seed_strand_t<true>(c, rs, mine);
+	} else seed_strand_t<false>(c, rs, nullptr);
 }
 // K3 chain: merge, expand, sort, sparse chaining DP
 __global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *work, long long n, int mate)
@@ -449,7 +462,17 @@ struct GpuBE {
 		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n)), dim3(kBlock), 0, stream, c, w, n, mate); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
-	PSVR_STAGE_M(st_seed, k_seed, 2)
+	void st_seed(const Ctx &c, const int32_t *w, long long n, int mate)
+	{
+		if (n > 0) {
+			int pitch = c.wmax | 1;
+			if ((size_t)pitch * 8 * kBlock > 64 * 1024) pitch = 0;
+			t0("k_seed");
+			hipLaunchKernelGGL(k_seed, dim3(grid_for(2 * n)), dim3(kBlock), (size_t)pitch * 8 * kBlock, stream, c, w, n, mate, pitch);
+			t1();
+		}
+		note(hipGetLastError());
+	}
 	PSVR_STAGE_M(st_chain, k_chain, 1)
 	PSVR_STAGE_M(st_select, k_select, 1)
 #undef PSVR_STAGE_M
