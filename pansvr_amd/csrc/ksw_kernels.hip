@@ -144,10 +144,10 @@ __device__ __forceinline__ void dp_main_loop(const DpParams &P, const uint8_t *t
 // dp_band_never_binds): the common case on the `aln` path (qlen <= 200, tlen <= 201).  Same results as dp_main_loop, far
 // fewer instructions per anti-diagonal:
 //   * an in-band cell only ever reads in-band cells of the previous diagonal or one of the explicit boundary values
-//     (:142-156), so the lanes outside [st0,en0] may hold anything: no select keeps their state, the 16-lane block
-//     rounding, the stale-score lanes and the 8-bit wrap are not modelled at all;
-//   * the left boundary of the band is simply the carry shifted into lane 0 of chunk 0; the first-row boundary is written
-//     into lane r before the sweep of the diagonal;
+//     (:142-156): the 16-lane block rounding, the stale-score lanes and the 8-bit wrap are not modelled at all, and lanes
+//     below the band may hold anything;
+//   * the left boundary of the band is simply the carry shifted into lane 0 of chunk 0; the first-row boundary is the
+//     initial state of a lane, which it keeps until its column enters the band (updates run under the band's exec mask);
 //   * all band / z-drop / end-score bookkeeping is wave-uniform (SGPRs, scalar branches);
 //   * the arg-max lane is found with a ballot; the reference's 4-lane tie order is only evaluated when two lanes tie.
 template <int K>
@@ -161,8 +161,10 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 #pragma unroll
 	for (int c = 0; c < K; ++c) {
 		const int t = c * 64 + lane;
-		u[c] = v[c] = x[c] = y[c] = neg_qe;
+		v[c] = x[c] = y[c] = neg_qe;
 		x2[c] = y2[c] = neg_qe2;
+		// lanes keep these values until their column enters the band at r == t: u/y/y2 of the first cell of column t (:153-156)
+		u[c] = t == 0 ? neg_qe : t < P.long_thres ? s8(-P.e) : t == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
 		H[c] = -P.qe_pre;                 // H[0] = v - qe on the first diagonal (:351); every other lane is set before it is read
 		const int tc = t < tlen ? target[t] : 0;
 		tb[c] = tc == P.m1 ? 0x100 : tc;  // an N never equals a query code
@@ -173,7 +175,8 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 	int e_score = PSVR_KSW_NEG_INF, e_zd = 0;
 	for (int r = 0; r < n_rows; ++r) {
 		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
-		const int ur = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
+		int ur = s8(-P.e2);                // v of column -1 (:142-152); only the first long_thres + 1 diagonals differ
+		if (r <= P.long_thres) ur = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : s8(P.long_diff);
 		const int c_first = st0 >> 6, c_last = en0 >> 6;
 		const int qbase = qlen - 1 - r;
 		const unsigned prow = (unsigned)(r * rowb - (st0 & ~15));
@@ -181,10 +184,6 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 #pragma unroll
 		for (int c = 0; c < K; ++c) {
 			if (en0 > 0 && ((en0 - 1) >> 6) == c) h_prev = __builtin_amdgcn_readlane(H[c], (en0 - 1) & 63);
-			if (en0 == r && (r >> 6) == c) {      // first cell of column r (:153-156)
-				const bool first = lane == (r & 63);
-				u[c] = first ? ur : u[c], y[c] = first ? neg_qe : y[c], y2[c] = first ? neg_qe2 : y2[c];
-			}
 		}
 		const int sel_t = en0 > 0 ? en0 : -1;
 		int bh = (int)0x80000000;
@@ -219,15 +218,15 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 			const int zq = z - P.q, zq2 = z - P.q2;
 			a -= zq, b -= zq, a2 -= zq2, b2 -= zq2;
 			d |= (a > 0 ? 0x08 : 0) | (b > 0 ? 0x10 : 0) | (a2 > 0 ? 0x20 : 0) | (b2 > 0 ? 0x40 : 0);
-			u[c] = un, v[c] = vn;
-			x[c] = max(a, 0) - qe8, y[c] = max(b, 0) - qe8;
-			x2[c] = max(a2, 0) - qe28, y2[c] = max(b2, 0) - qe28;
 			// exact H (:316-351): the last in-band lane continues from its left neighbour, the others from themselves
 			const int hn = t == sel_t ? h_prev + un : H[c] + vn;
-			H[c] = hn;
 			const bool act = (t >= st0) & (t <= en0);
 			amask[c] = __ballot(act);
-			if (act) {
+			if (act) {   // lanes above the band must keep their initial u/y/y2; what lanes below it hold no longer matters
+				u[c] = un, v[c] = vn;
+				x[c] = max(a, 0) - qe8, y[c] = max(b, 0) - qe8;
+				x2[c] = max(a2, 0) - qe28, y2[c] = max(b2, 0) - qe28;
+				H[c] = hn;
 				if (with_cigar) Pm[prow + (unsigned)t] = (uint8_t)d;
 				bh = max(bh, hn);
 			}
