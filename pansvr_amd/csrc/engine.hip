@@ -242,15 +242,13 @@ __global__ void k_iota(int32_t *w, long long at, long long start, long long n)
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) w[at + i] = (int32_t)(start + i);
 }
-__global__ void k_gather_i64(const long long *a, const int32_t *idx, long long n, long long *out)
+// the three per-pair values the host's offset walk needs, for the listed pairs, in one pass: out = [n x i64 | n x i64 | n x i32]
+__global__ void k_gather_listed(const long long *a, const long long *b, const int32_t *c, const int32_t *idx, long long n, long long *out)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < n) out[i] = a[idx[i]];
-}
-__global__ void k_gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out)
-{
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < n) out[i] = a[idx[i]];
+	if (i >= n) return;
+	const int32_t j = idx[i];
+	out[i] = a[j], out[n + i] = b[j], ((int32_t *)(out + 2 * n))[i] = c[j];
 }
 __global__ void k_scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n)
 {
@@ -510,27 +508,23 @@ struct GpuBE {
 	DevBuf tmp_idx, tmp_val, tmp_out;
 	void fill_iota(int32_t *p, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, 0ll, 0ll, n); }
 	void append_iota(int32_t *w, long long at, long long start, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, start, n); }
-	void gather_i64(const long long *a, const int32_t *idx, long long n, long long *out)
+	// one index upload, one kernel, one synchronisation; the indices stay on the device for scatter_listed_i32
+	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc)
 	{
 		if (!n) return;
-		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 8));
-		h2d(tmp_idx.p, idx, n * 4);
-		hipLaunchKernelGGL(k_gather_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
-		d2h(out, tmp_out.p, n * 8);
+		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 20 + 16));
+		note(hipMemcpyAsync(tmp_idx.p, idx, n * 4, hipMemcpyHostToDevice, stream));
+		hipLaunchKernelGGL(k_gather_listed, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, b, cc, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
+		note(hipMemcpyAsync(oa, tmp_out.p, n * 8, hipMemcpyDeviceToHost, stream));
+		note(hipMemcpyAsync(ob, (char *)tmp_out.p + n * 8, n * 8, hipMemcpyDeviceToHost, stream));
+		note(hipMemcpyAsync(oc, (char *)tmp_out.p + n * 16, n * 4, hipMemcpyDeviceToHost, stream));
+		note(hipStreamSynchronize(stream));
 	}
-	void gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out)
+	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n)
 	{
 		if (!n) return;
-		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 8));
-		h2d(tmp_idx.p, idx, n * 4);
-		hipLaunchKernelGGL(k_gather_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, (int32_t *)tmp_out.p);
-		d2h(out, tmp_out.p, n * 4);
-	}
-	void scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n)
-	{
-		if (!n) return;
-		note(tmp_idx.ensure(n * 4)), note(tmp_val.ensure(n * 4));
-		h2d(tmp_idx.p, idx, n * 4), h2d(tmp_val.p, val, n * 4);
+		note(tmp_val.ensure(n * 4));
+		h2d(tmp_val.p, val, n * 4);
 		hipLaunchKernelGGL(k_scatter_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n);
 	}
 	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n) { if (n) hipLaunchKernelGGL(k_hoff_shadows, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, P, n); }

@@ -249,6 +249,29 @@ template <class BE> struct EngineCore {
 		be.h2d(d_off, base_off, (R + 1) * 8);
 		be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
 		c.bases = d_bases, c.base_off = d_off, c.ori = d_ori;
+		// variant slots: pair s at every combination of its N-substitution residues.  Only those slots force draws, so the
+		// table is zeroed on the device and just their rows are uploaded, once per batch.
+		{
+			std::vector<uint8_t> force((size_t)8 * V, 0);
+			h_vsrc.assign(V, 0), h_sp_idx.assign(special.size(), 0);
+			for (size_t i = 0; i < special.size(); ++i) {
+				const Special &sp = special[i];
+				h_sp_idx[i] = sp.pair;
+				for (int v = 0; v < sp.nvar; ++v) {
+					long long slot = sp.vslot + v;
+					h_vsrc[slot - P] = sp.pair;
+					int code = v;
+					for (int k = 0; k < 2; ++k) {
+						int n = k == 0 ? sp.n1 : sp.n2;
+						uint8_t *f = &force[4 * (2 * (slot - P) + k)];
+						f[0] = (uint8_t)n;
+						for (int j = 0; j < n; ++j) f[1 + j] = (uint8_t)(code & 3), code >>= 2;
+					}
+				}
+			}
+			be.dzero(d_force, (size_t)8 * S);
+			if (V) be.h2d(d_force + (size_t)8 * P, force.data(), force.size());
+		}
 		return PSVR_OK;
 	}
 
@@ -339,6 +362,7 @@ template <class BE> struct EngineCore {
 	// ---- one full run of the uploaded batch (rand state is NOT advanced: call commit() for that)
 	struct Win { int32_t pair; long long eval_off; int32_t eval_tot; std::vector<long long> off; std::vector<int32_t> tot; };   // window-resolved pair
 	// state of the current batch's resolution, kept so that rebase() can continue from it
+	std::vector<int32_t> h_vsrc, h_sp_idx;            // variant slot -> pair; pairs with variant slots (built by upload())
 	std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
 	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
 	std::vector<char> is_special;                     // a special pair whose prediction failed falls back to the window method
@@ -363,30 +387,9 @@ template <class BE> struct EngineCore {
 		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_sens, P), be.dzero(d_mask, P);
 		be.fill_iota(d_src, S);
 		c.src = d_src, c.force = d_force;
-		// variant slots: pair s at every combination of its N-substitution residues
-		{
-			std::vector<uint8_t> force((size_t)8 * S, 0);
-			std::vector<int32_t> vsrc(V);
-			std::vector<int32_t> sp_idx(special.size());
-			for (size_t i = 0; i < special.size(); ++i) {
-				const Special &sp = special[i];
-				sp_idx[i] = sp.pair;
-				for (int v = 0; v < sp.nvar; ++v) {
-					long long slot = sp.vslot + v;
-					vsrc[slot - P] = sp.pair;
-					int code = v;
-					for (int k = 0; k < 2; ++k) {
-						int n = k == 0 ? sp.n1 : sp.n2;
-						uint8_t *f = &force[4 * (2 * slot + k)];
-						f[0] = (uint8_t)n;
-						for (int j = 0; j < n; ++j) f[1 + j] = (uint8_t)(code & 3), code >>= 2;
-					}
-				}
-			}
-			be.h2d(d_force, force.data(), force.size());
-			if (V) be.h2d(d_src + P, vsrc.data(), V * 4);
-			if (!special.empty()) { std::vector<int32_t> ones(special.size(), 1); be.scatter_u8(d_mask, sp_idx.data(), (long long)sp_idx.size(), 1); }
-		}
+		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
+		if (V) be.h2d(d_src + P, h_vsrc.data(), V * 4);
+		if (!h_sp_idx.empty()) be.scatter_u8(d_mask, h_sp_idx.data(), (long long)h_sp_idx.size(), 1);
 		dp_done = 0, cw_done = 0;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
 		have_run = true;
@@ -471,9 +474,7 @@ template <class BE> struct EngineCore {
 			be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
 			be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
 			if (!listed.empty()) {
-				be.gather_i64(d_noff, listed.data(), (long long)listed.size(), pre.data());
-				be.gather_i64(c.poff, listed.data(), (long long)listed.size(), cur_off.data());
-				be.gather_i32(d_ctot, listed.data(), (long long)listed.size(), cur_tot.data());
+				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data());
 			}
 			// walk O_{s+1} = O_s + D_s through the tables
 			{
@@ -508,7 +509,7 @@ template <class BE> struct EngineCore {
 					cur_off[i] = t;                                  // where the pair must be evaluated next
 				}
 			}
-			if (!listed.empty()) be.scatter_i32(d_ctot, listed.data(), res.data(), (long long)listed.size());
+			if (!listed.empty()) be.scatter_listed_i32(d_ctot, res.data(), (long long)listed.size());   // same indices as gather_listed
 			// new offsets from the totals; which pairs drew from a stale offset?
 			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
 			be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);

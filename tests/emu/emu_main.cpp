@@ -28,11 +28,15 @@ struct CpuBE {
 	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
 	void fill_iota(int32_t *p, long long n) { for (long long i = 0; i < n; ++i) p[i] = (int32_t)i; }
 	void append_iota(int32_t *w, long long at, long long start, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = (int32_t)(start + i); }
-	void gather_i64(const long long *a, const int32_t *idx, long long n, long long *out) { for (long long i = 0; i < n; ++i) out[i] = a[idx[i]]; }
-	void gather_i32(const int32_t *a, const int32_t *idx, long long n, int32_t *out) { for (long long i = 0; i < n; ++i) out[i] = a[idx[i]]; }
+	std::vector<int32_t> listed_idx;
+	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc)
+	{
+		listed_idx.assign(idx, idx + n);
+		for (long long i = 0; i < n; ++i) oa[i] = a[idx[i]], ob[i] = b[idx[i]], oc[i] = cc[idx[i]];
+	}
+	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n) { for (long long i = 0; i < n; ++i) a[listed_idx[i]] = val[i]; }
 	void scatter_u8(uint8_t *a, const int32_t *idx, long long n, uint8_t v) { for (long long i = 0; i < n; ++i) a[idx[i]] = v; }
 	void st_mask_totals(const int32_t *ctot, const uint8_t *mask, long long n, int32_t *out) { for (long long i = 0; i < n; ++i) out[i] = mask[i] ? 0 : ctot[i]; }
-	void scatter_i32(int32_t *a, const int32_t *idx, const int32_t *val, long long n) { for (long long i = 0; i < n; ++i) a[idx[i]] = val[i]; }
 	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n)
 	{
 		for (long long j = 0; j < n; ++j) for (int k = 0; k < 2; ++k) c.hoff[2 * (P + j) + k] = c.hoff[2 * (long long)c.src[P + j] + k];
