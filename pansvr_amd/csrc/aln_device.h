@@ -903,7 +903,17 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 }
 
 // get_ksw_score (rr.cpp:308-400) for candidate k of `read`
-PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
+// CIGAR pieces a candidate may need: per chain node at most 'M' + alignment (+ negative D); + tail M + left extension.  A chain
+// has at most us_n nodes (sizing by that bound avoids walking the chain twice).
+PSVR_HD int walk_seg_cap(const Ctx &c, long long read, int k)
+{
+	const int is_rev = c.ccand[read * 12 + k].direction == kRev;
+	const int cap = 3 * (int)c.strand[read * 2 + is_rev].us_n + 4;
+	return cap > kSegMax ? kSegMax : cap;
+}
+
+// candidate k of `read`; its CandWork slot and its slice of the piece arena were reserved by walk_read
+PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap)
 {
 	const ChainCand &cc = c.ccand[read * 12 + k];
 	const int is_rev = cc.direction == kRev;
@@ -911,14 +921,6 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
 	const USeed *va = c.us.base + st.us_off;
 	const PathN *dp = c.path + st.us_off;
 	const int read_l = c.read_l[read];
-	long long cwi = arena_alloc(c.cw, 1);
-	if (cwi < 0) return;
-	int n_nodes = 0;
-	for (int node = (int)cc.max_index; node != -1; node = dp[node].pre_node) ++n_nodes;
-	int seg_cap = 3 * n_nodes + 4;                        // per chain node: at most 'M' + alignment (+ negative D); + tail M + left extension
-	if (seg_cap > kSegMax) seg_cap = kSegMax;
-	long long so = arena_alloc(c.seg, (unsigned long long)seg_cap);
-	if (so < 0) return;
 	WalkState w;
 	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
 	w.read_w = c.rb + (read * 2 + is_rev) * (long long)c.wmax, w.packed_ok = c.has_n4[read] == 0;
@@ -973,6 +975,25 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k)
 	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = rba, cw.bad = w.bad, cw.seg_off = so;
 	if (w.bad) *c.err = 10 + w.bad;
 	stat_add(c, ST_CAND, 1);
+}
+
+// all candidates of one read.  The arenas are bump allocators on one counter each: reserving per read instead of per
+// candidate keeps the number of same-address atomics (the limit of this stage) down.
+PSVR_HDN inline void walk_read(const Ctx &c, long long read)
+{
+	if (!c.active[read]) return;
+	const int nc = c.n_ccand[read];
+	if (nc <= 0) return;
+	int total = 0;
+	for (int k = 0; k < nc; ++k) total += walk_seg_cap(c, read, k);
+	const long long cw0 = arena_alloc(c.cw, (unsigned long long)nc);
+	long long so = arena_alloc(c.seg, (unsigned long long)total);
+	if (cw0 < 0 || so < 0) return;
+	for (int k = 0; k < nc; ++k) {
+		const int cap = walk_seg_cap(c, read, k);
+		walk_candidate(c, read, k, cw0 + k, so, cap);
+		so += cap;
+	}
 }
 
 struct CigOp { uint8_t type; int16_t size; };

@@ -189,10 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *work, lon
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
 	if (i >= 2 * n) return;
-	long long r = pair_of(work, i >> 1) * 2 + (i & 1);
-	if (!c.active[r]) return;
-	const int nc = c.n_ccand[r];
-	for (int k = 0; k < nc; ++k) walk_candidate(c, r, k);
+	walk_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
 }
 __global__ __launch_bounds__(64) void k_assemble(Ctx c, long long begin, long long end)
 {

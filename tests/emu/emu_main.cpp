@@ -48,11 +48,7 @@ struct CpuBE {
 	void st_select(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) select_read(c, pr(w, i) * 2 + mate); }
 	void st_walk(const Ctx &c, const int32_t *w, long long n)
 	{
-		for (long long i = 0; i < 2 * n; ++i) {
-			long long r = pr(w, i >> 1) * 2 + (i & 1);
-			if (!c.active[r]) continue;
-			for (int k = 0; k < c.n_ccand[r]; ++k) walk_candidate(c, r, k);
-		}
+		for (long long i = 0; i < 2 * n; ++i) walk_read(c, pr(w, i >> 1) * 2 + (i & 1));
 	}
 	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
 	{
