@@ -24,14 +24,16 @@ __device__ __forceinline__ long long pair_of(const int32_t *work, long long i) {
 // ---- stage kernels: one thread per item; the read-level stages run per mate ------------------------
 // prep (prep_read in aln_device.h), one wavefront per read: coalesced base loads, N draws ordered by a ballot
 // prefix, codes of both strands staged in LDS, then one lane per packed 32-base word (no per-base read-modify-write).
-__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate)
+__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate, int tsize, int per_wave)
 {
 	extern __shared__ __align__(16) uint8_t prep_lds[];
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
 	if (wi >= n) return;
 	const long long read = pair_of(work, wi) * 2 + mate;
-	uint8_t *fw = prep_lds + (size_t)wave * 2 * c.lmax, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
+	uint8_t *fw = prep_lds + (size_t)wave * per_wave, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
+	uint64_t *pw = (uint64_t *)(rv + c.lmax);                            // forward strand's packed words (for the STR screen)
+	unsigned int *bits = (unsigned int *)(pw + c.wmax);                  // tsize words: hashed 20-mer set
 	const long long sr = src_read(c, read);
 	const psvr_ori_t o = c.ori[sr];
 	const int L = (int)(c.base_off[sr + 1] - c.base_off[sr]);
@@ -89,8 +91,30 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 			}
 		}
 		(s2 ? w1 : w0)[w] = word;
+		if (!s2) pw[w] = word;
 	}
-	if (lane == 0) { c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1); }
+	// STR screen (rr.cpp:549-598 decides STR when fewer than kn - 15 of the kn 20-mers are distinct, i.e. at least 16 repeats):
+	// hash every 20-mer into a 32*tsize-bit set; a k-mer that finds its bit taken is a repeat or a collision, so fewer than 16
+	// such events prove the read is not STR.  The few reads left (is_str = 2) get the exact count in k_str_detect.
+	const int kn = L - kLenKmer + 1;
+	int verdict = 2;
+	if (kn >= 15) {
+		const unsigned bmask = (unsigned)tsize * 32u - 1u;
+		for (int i = lane; i < tsize; i += 64) bits[i] = 0;
+		__builtin_amdgcn_wave_barrier();
+		int taken = 0;
+		for (int i0 = 0; i0 < kn; i0 += 64) {
+			const int i = i0 + lane;
+			bool hit = false;
+			if (i < kn) {
+				const unsigned h = (unsigned)((get_kmer((uint32_t)i, pw) * 0x9E3779B97F4A7C15ull) >> 40) & bmask;
+				hit = (atomicOr(&bits[h >> 5], 1u << (h & 31)) >> (h & 31)) & 1u;
+			}
+			taken += __popcll(__ballot(hit));
+		}
+		if (taken < 16) verdict = 0;
+	}
+	if (lane == 0) { c.is_str[read] = (uint8_t)verdict; c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1); }
 }
 
 // STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are counted in an open-addressing hash
@@ -103,15 +127,15 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
 	if (wi >= n) return;
 	const long long read = pair_of(work, wi) * 2 + mate;
-	if (!c.active[read]) return;
+	if (!c.active[read] || c.is_str[read] != 2) return;      // k_prep's screen has cleared all but a few percent of the reads
 	unsigned long long *key = (unsigned long long *)(str_lds + (size_t)wave * (size_t)per_wave);   // keys | counts | seed_list staging
 	unsigned int *cnt = (unsigned int *)(key + tsize);
 	const unsigned long long EMPTY = ~0ull;               // a 20-mer has 40 significant bits
 	const unsigned mask = (unsigned)tsize - 1;
-	for (int i = lane; i < tsize; i += 64) key[i] = EMPTY, cnt[i] = 0;
 	const int L = c.read_l[read];
 	const uint64_t *rb = c.rb + (read * 2) * (long long)c.wmax;
 	const int kn = L - kLenKmer + 1;
+	for (int i = lane; i < tsize; i += 64) key[i] = EMPTY, cnt[i] = 0;
 	int distinct = 0;
 	for (int i0 = 0; i0 < kn; i0 += 64) {
 		const int i = i0 + lane;
@@ -471,19 +495,26 @@ struct GpuBE {
 	PSVR_STAGE_M(st_chain, k_chain, 1)
 	PSVR_STAGE_M(st_select, k_select, 1)
 #undef PSVR_STAGE_M
+	static int str_tsize(const Ctx &c)
+	{
+		int tsize = 256;                                          // >= 2 x (L - 19) k-mers, power of two
+		while (tsize < 2 * c.lmax) tsize <<= 1;
+		return tsize;
+	}
 	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n <= 0) return;
 		t0("k_prep");
-		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * 2 * c.lmax, stream, c, w, n, mate);
+		const int tsize = str_tsize(c);
+		const size_t per_wave = ((size_t)2 * c.lmax + (size_t)c.wmax * 8 + (size_t)tsize * 4 + 15) & ~(size_t)15;
+		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * per_wave, stream, c, w, n, mate, tsize, (int)per_wave);
 		t1();
 		note(hipGetLastError());
 	}
 	void st_str(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n <= 0) return;
-		int tsize = 256;                                          // >= 2 x (L - 19) k-mers, power of two
-		while (tsize < 2 * c.lmax) tsize <<= 1;
+		const int tsize = str_tsize(c);
 		// per wave: tsize keys (8 B) + tsize counts (4 B); the seed_list staging (<= lmax bytes) reuses the space behind them
 		const size_t per_wave = (size_t)tsize * 12 + (((size_t)c.lmax + 15) & ~(size_t)15);
 		const size_t lds = (size_t)(kBlock / 64) * per_wave;
