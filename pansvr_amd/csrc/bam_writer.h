@@ -1,0 +1,209 @@
+// bam_writer.h -- BGZF + BAM record encoder for the CLI's two output files.
+//
+// Replaces the reference's text -> sam_parse1 -> sam_write1 route when the output is BAM (`output_BAM`,
+// `output_ori_bam` rr.cpp:479-536,656-719 write through htslib; `init_run` opens the files "wb" unless -S).
+// The vendored htslib cannot be built in this image, so this encoder follows the published
+// format (SAM/BAM specification v1, sections 4.1 BGZF and 4.2 BAM) and the typing rules of htslib's sam_parse1:
+//   * integer tags take the smallest type that holds the value (c/C/s/S/i/I),
+//   * bin = reg2bin(pos, pos + reference length of the CIGAR, or +1 without one),
+//   * sequence as 4-bit codes of "=ACMGRSVTWYHKDBN", qualities as phred (text - 33), '*' -> 0xff.
+// Byte-identity with htslib's BGZF blocks is not claimed (block boundaries and deflate output depend on the
+// zlib build); the records inside are what the specification prescribes.  tests/test_aln_gpu.py decodes the
+// BAM with an independent reader and compares it with the SAM text of the same run.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+#include <string>
+#include <vector>
+
+namespace psvr {
+
+class BgzfWriter {
+	FILE *f_ = nullptr;
+	std::vector<uint8_t> buf_;
+	static const size_t kBlock = 0xff00;      // uncompressed bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
+	bool ok_ = true;
+	void flush_block(const uint8_t *p, size_t n)
+	{
+		uint8_t out[0x10000 + 64];
+		z_stream zs;
+		memset(&zs, 0, sizeof zs);
+		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok_ = false; return; }
+		zs.next_in = (Bytef *)p, zs.avail_in = (uInt)n;
+		zs.next_out = out + 18, zs.avail_out = sizeof out - 18 - 8;
+		int rc = deflate(&zs, Z_FINISH);
+		deflateEnd(&zs);
+		if (rc != Z_STREAM_END) { ok_ = false; return; }
+		const size_t clen = zs.total_out, bsize = clen + 18 + 8 - 1;
+		static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+		memcpy(out, hdr, 16);
+		out[16] = (uint8_t)(bsize & 0xff), out[17] = (uint8_t)(bsize >> 8);
+		const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+		uint8_t *t = out + 18 + clen;
+		for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+		if (fwrite(out, 1, clen + 26, f_) != clen + 26) ok_ = false;
+	}
+public:
+	bool open(const char *fn) { f_ = fopen(fn, "wb"); buf_.reserve(kBlock * 2); return f_ != nullptr; }
+	void write(const void *p, size_t n)
+	{
+		const uint8_t *b = (const uint8_t *)p;
+		buf_.insert(buf_.end(), b, b + n);
+		size_t off = 0;
+		while (buf_.size() - off >= kBlock) { flush_block(buf_.data() + off, kBlock); off += kBlock; }
+		if (off) buf_.erase(buf_.begin(), buf_.begin() + off);
+	}
+	bool close()
+	{
+		if (!f_) return false;
+		if (!buf_.empty()) flush_block(buf_.data(), buf_.size());
+		static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		if (fwrite(eof, 1, 28, f_) != 28) ok_ = false;
+		if (fclose(f_) != 0) ok_ = false;
+		f_ = nullptr;
+		return ok_;
+	}
+};
+
+struct BamRef { std::string name; uint32_t len; };
+
+// one alignment record in SAM terms (what the CLI's emit_record prints)
+struct SamFields {
+	std::string qname, cigar, seq, qual, tags;   // tags: "\tXX:t:value..." as in the SAM line; cigar/seq/qual may be "*"
+	int flag = 0, tid = -1, mapq = 0, mtid = -1, isize = 0;
+	int64_t pos1 = 0, mpos1 = 0;                 // 1-based; 0 = unset
+};
+
+class BamWriter {
+	BgzfWriter z_;
+	std::vector<uint8_t> rec_;
+	static void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+	static void put16(std::vector<uint8_t> &v, uint16_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }
+	static int reg2bin(int64_t beg, int64_t end)             // SAMv1 section 5.3
+	{
+		--end;
+		if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+		if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+		if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+		if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+		if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+		return 0;
+	}
+	static void put_int_tag(std::vector<uint8_t> &v, long long x)   // smallest type, as sam_parse1 chooses
+	{
+		if (x < 0) {
+			if (x >= -128) v.push_back('c'), v.push_back((uint8_t)(int8_t)x);
+			else if (x >= -32768) v.push_back('s'), put16(v, (uint16_t)(int16_t)x);
+			else v.push_back('i'), put32(v, (uint32_t)(int32_t)x);
+		} else {
+			if (x <= 255) v.push_back('C'), v.push_back((uint8_t)x);
+			else if (x <= 65535) v.push_back('S'), put16(v, (uint16_t)x);
+			else v.push_back('I'), put32(v, (uint32_t)x);
+		}
+	}
+	static bool put_tags(std::vector<uint8_t> &v, const std::string &tags)
+	{
+		size_t i = 0;
+		while (i < tags.size()) {
+			if (tags[i] == '\t') { ++i; continue; }
+			size_t e = tags.find('\t', i);
+			if (e == std::string::npos) e = tags.size();
+			if (e - i < 5 || tags[i + 2] != ':' || tags[i + 4] != ':') return false;
+			v.push_back((uint8_t)tags[i]), v.push_back((uint8_t)tags[i + 1]);
+			const char ty = tags[i + 3];
+			const std::string val = tags.substr(i + 5, e - (i + 5));
+			if (ty == 'i') put_int_tag(v, strtoll(val.c_str(), nullptr, 10));
+			else if (ty == 'A') { v.push_back('A'); v.push_back(val.empty() ? ' ' : (uint8_t)val[0]); }
+			else if (ty == 'f') { v.push_back('f'); float fl = strtof(val.c_str(), nullptr); uint32_t u; memcpy(&u, &fl, 4); put32(v, u); }
+			else if (ty == 'Z' || ty == 'H') { v.push_back((uint8_t)ty); v.insert(v.end(), val.begin(), val.end()); v.push_back(0); }
+			else if (ty == 'B') {
+				if (val.empty()) return false;
+				const char st = val[0];
+				std::vector<std::string> items;
+				size_t p = 1;
+				while (p < val.size()) { size_t q = val.find(',', p + 1); if (q == std::string::npos) q = val.size(); items.push_back(val.substr(p + 1, q - p - 1)); p = q; }
+				v.push_back('B'), v.push_back((uint8_t)st), put32(v, (uint32_t)items.size());
+				for (const std::string &it : items) {
+					if (st == 'f') { float fl = strtof(it.c_str(), nullptr); uint32_t u; memcpy(&u, &fl, 4); put32(v, u); }
+					else {
+						long long x = strtoll(it.c_str(), nullptr, 10);
+						if (st == 'c' || st == 'C') v.push_back((uint8_t)x);
+						else if (st == 's' || st == 'S') put16(v, (uint16_t)x);
+						else put32(v, (uint32_t)x);
+					}
+				}
+			} else return false;
+			i = e;
+		}
+		return true;
+	}
+public:
+	bool open(const char *fn, const std::string &header_text, const std::vector<BamRef> &refs)
+	{
+		if (!z_.open(fn)) return false;
+		std::vector<uint8_t> h = {'B', 'A', 'M', 1};
+		put32(h, (uint32_t)header_text.size());
+		h.insert(h.end(), header_text.begin(), header_text.end());
+		put32(h, (uint32_t)refs.size());
+		for (const BamRef &r : refs) {
+			put32(h, (uint32_t)r.name.size() + 1);
+			h.insert(h.end(), r.name.begin(), r.name.end());
+			h.push_back(0);
+			put32(h, r.len);
+		}
+		z_.write(h.data(), h.size());
+		return true;
+	}
+	bool write(const SamFields &s)
+	{
+		std::vector<uint32_t> cig;
+		int64_t rlen = 0;
+		if (!s.cigar.empty() && s.cigar != "*") {
+			long long n = 0;
+			bool neg = false;
+			for (char ch : s.cigar) {
+				if (ch == '-') { neg = true; continue; }
+				if (ch >= '0' && ch <= '9') { n = n * 10 + (ch - '0'); continue; }
+				const char *ops = "MIDNSHP=X", *q = strchr(ops, ch);
+				if (!q) return false;
+				if (neg) n = -n;
+				const int op = (int)(q - ops);
+				cig.push_back((uint32_t)n << 4 | (uint32_t)op);
+				if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (uint32_t)n & 0xfffffff;
+				n = 0, neg = false;
+			}
+		}
+		const bool no_seq = s.seq.empty() || s.seq == "*";
+		const uint32_t l_seq = no_seq ? 0 : (uint32_t)s.seq.size();
+		const int64_t pos0 = s.pos1 - 1;
+		rec_.clear();
+		put32(rec_, 0);                                             // block_size, patched below
+		put32(rec_, (uint32_t)s.tid), put32(rec_, (uint32_t)(int32_t)pos0);
+		rec_.push_back((uint8_t)(s.qname.size() + 1)), rec_.push_back((uint8_t)s.mapq);
+		put16(rec_, (uint16_t)reg2bin(pos0 < 0 ? 0 : pos0, (pos0 < 0 ? 0 : pos0) + (rlen > 0 ? rlen : 1)));
+		put16(rec_, (uint16_t)cig.size()), put16(rec_, (uint16_t)s.flag);
+		put32(rec_, l_seq);
+		put32(rec_, (uint32_t)s.mtid), put32(rec_, (uint32_t)(int32_t)(s.mpos1 - 1)), put32(rec_, (uint32_t)s.isize);
+		rec_.insert(rec_.end(), s.qname.begin(), s.qname.end());
+		rec_.push_back(0);
+		for (uint32_t c : cig) put32(rec_, c);
+		static const char *nt16 = "=ACMGRSVTWYHKDBN";
+		for (uint32_t i = 0; i < l_seq; i += 2) {
+			auto code = [&](char ch) { const char *q = strchr(nt16, ch >= 'a' && ch <= 'z' ? ch - 32 : ch); return q && ch ? (int)(q - nt16) : 15; };
+			const int hi = code(s.seq[i]), lo = i + 1 < l_seq ? code(s.seq[i + 1]) : 0;
+			rec_.push_back((uint8_t)(hi << 4 | lo));
+		}
+		if (s.qual.empty() || s.qual == "*" || s.qual.size() != l_seq) rec_.insert(rec_.end(), l_seq, 0xff);
+		else for (char ch : s.qual) rec_.push_back((uint8_t)(ch - 33));
+		if (!put_tags(rec_, s.tags)) return false;
+		const uint32_t bs = (uint32_t)rec_.size() - 4;
+		for (int i = 0; i < 4; ++i) rec_[i] = (uint8_t)(bs >> (8 * i));
+		z_.write(rec_.data(), rec_.size());
+		return true;
+	}
+	bool close() { return z_.close(); }
+};
+
+} // namespace psvr

@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../include/psvr_engine.h"
 #include "host_io.h"
+#include "bam_writer.h"
 
 using namespace psvr;
 
@@ -52,7 +53,7 @@ static int usage()
 	        "    -o, --output            STR  Output file [./output.bam]\n"
 	        "    -p, --output_signal_ori STR  Reads not fully aligned by aligner nor re-aligner [./output_ori.bam]\n"
 	        "    -Q, --not-ori                NOT output original result when score of ORI is bigger\n"
-	        "    -S, --SAM                    Output as SAM (the only format this build writes; without -S a .sam is still written and a note printed)\n"
+	        "    -S, --SAM                    Output as SAM, default is BAM\n"
 	        "    -R, --max_use_read      INT  Max number of read pairs to align\n"
 	        "        --device            INT  HIP device [0]\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
@@ -90,6 +91,7 @@ static void rev_qual(std::string &q)  // getReverseStr_qual_char, clib/bam_file.
 struct HeaderInfo {
 	std::string text;
 	std::vector<std::string> names;
+	std::vector<uint32_t> lens;
 	const char *name(int id) const { return id >= 0 && id < (int)names.size() ? names[id].c_str() : "*"; }
 };
 
@@ -108,14 +110,32 @@ static bool load_header(const std::string &fn, HeaderInfo *h)
 		char *e = p;
 		while (*e && *e != '\t' && *e != '\n') ++e;
 		h->names.emplace_back(p, e - p);
+		const char *ln = strstr(buf, "LN:");
+		h->lens.push_back(ln ? (uint32_t)strtoul(ln + 3, nullptr, 10) : 0u);
 	}
 	fclose(f);
 	return true;
 }
 
+// one output file: SAM text (-S) or BAM (default, like the reference's init_run)
+struct OutFile {
+	FILE *sam = nullptr;
+	psvr::BamWriter bam;
+	bool is_bam = false;
+	bool open(const std::string &fn, bool as_bam, const HeaderInfo &H)
+	{
+		is_bam = as_bam;
+		if (!as_bam) { sam = fopen(fn.c_str(), "w"); if (sam) fputs(H.text.c_str(), sam); return sam != nullptr; }
+		std::vector<psvr::BamRef> refs;
+		for (size_t i = 0; i < H.names.size(); ++i) refs.push_back({H.names[i], H.lens[i]});
+		return bam.open(fn.c_str(), H.text, refs);
+	}
+	bool close() { if (is_bam) return bam.close(); return fclose(sam) == 0; }
+};
+
 // what survives sam_parse1 -> sam_write1 (htslib 1.9 sam.c:1197-1424, sam_format1) for the text built by
 // single_end_handler::output_BAM (rr.cpp:479-536): POS <= 0 drops the record, RNEXT collapses to '=' ...
-static bool emit_record(FILE *out, const HeaderInfo &H, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar,
+static bool emit_record(OutFile &out, const HeaderInfo &H, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar,
                         bool has_mate, int mate_chr, uint32_t mate_pos, int isize, const std::string &seq, const std::string &qual, const std::string &tags)
 {
 	int pos = (int)ref_bg;                               // printed with %d
@@ -123,13 +143,20 @@ static bool emit_record(FILE *out, const HeaderInfo &H, const std::string &name,
 	if (pos - 1 < 0) return false;                       // "mapped query cannot have zero coordinate; treated as unmapped" -> tid = -1 -> not written
 	std::string rnext = "*";
 	long pnext = 0;
+	int mtid = -1;
 	if (has_mate) {
 		int mp = (int)mate_pos;
 		bool mate_ok = mate_chr >= 0 && mate_chr < (int)H.names.size() && !(mp - 1 < 0);
-		if (mate_ok) rnext = mate_chr == chr_id ? "=" : H.name(mate_chr);
+		if (mate_ok) rnext = mate_chr == chr_id ? "=" : H.name(mate_chr), mtid = mate_chr;
 		pnext = mp;
 	}
-	fprintf(out, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%ld\t%d\t%s\t%s%s\n", name.c_str(), flag, H.name(chr_id), pos, mapq, cigar.empty() ? "*" : cigar.c_str(), rnext.c_str(), pnext, isize,
+	if (out.is_bam) {
+		psvr::SamFields f;
+		f.qname = name, f.flag = flag, f.tid = chr_id, f.pos1 = pos, f.mapq = mapq, f.cigar = cigar.empty() ? "*" : cigar;
+		f.mtid = mtid, f.mpos1 = pnext, f.isize = isize, f.seq = seq, f.qual = qual, f.tags = tags;
+		return out.bam.write(f);
+	}
+	fprintf(out.sam, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%ld\t%d\t%s\t%s%s\n", name.c_str(), flag, H.name(chr_id), pos, mapq, cigar.empty() ? "*" : cigar.c_str(), rnext.c_str(), pnext, isize,
 	        seq.c_str(), qual.c_str(), tags.c_str());
 	return true;
 }
@@ -225,7 +252,6 @@ int main(int argc, char **argv)
 	if (argc - optind < 3) return usage();
 	if (!(o.thread_n >= 1 && o.thread_n <= 48)) { fprintf(stderr, "Input error: thread_n cannot be less than 1 or more than 48\n"); abort(); }   // xassert, rr.hpp:121
 	o.index_dir = argv[optind], o.reads = argv[optind + 1], o.header = argv[optind + 2];
-	if (!o.sam) fprintf(stderr, "[panSVR-amd] BAM output is not built into this engine yet: writing SAM text to %s\n", o.out.c_str());
 
 	HeaderInfo H;
 	fprintf(stderr, "Open original header file [%s]\n", o.header.c_str());
@@ -239,9 +265,8 @@ int main(int argc, char **argv)
 	double cpu0 = cputime();
 	FILE *fq = o.reads == "-" ? stdin : fopen(o.reads.c_str(), "r");
 	if (!fq) { fprintf(stderr, "fail to open file '%s'\n", o.reads.c_str()); abort(); }
-	FILE *fo = fopen(o.out.c_str(), "w"), *fo_ori = fopen(o.out_ori.c_str(), "w");
-	if (!fo || !fo_ori) { fprintf(stderr, "fail to open output file\n"); abort(); }
-	fputs(H.text.c_str(), fo), fputs(H.text.c_str(), fo_ori);
+	OutFile fo, fo_ori;
+	if (!fo.open(o.out, !o.sam, H) || !fo_ori.open(o.out_ori, !o.sam, H)) { fprintf(stderr, "fail to open output file\n"); abort(); }
 	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
 	fprintf(stderr, "Processing file: [%s].\n", o.reads.c_str());
 
@@ -369,7 +394,7 @@ int main(int argc, char **argv)
 		pair_base += P;
 	}
 	if (fq != stdin) fclose(fq);
-	fclose(fo), fclose(fo_ori);
+	if (!fo.close() || !fo_ori.close()) { fprintf(stderr, "fail to write output file\n"); abort(); }
 	if (frec) fclose(frec);
 	if (eng) psvr_engine_destroy(eng);
 	psvr_index_destroy(idx);

@@ -55,3 +55,29 @@ def test_gpu_engine_matches_reference_records(name, rname):
     assert n_expected == len(sam) and n_expected > 0
     ori = [l for l in open(os.path.join(tmp, "ori.sam")) if not l.startswith("@")]
     assert all("MS:i:" in l for l in ori)
+
+
+def test_gpu_cli_bam_output_equals_sam_text():
+    """Default output is BAM (like the reference's init_run): decode it with tests/bam_reader.py and compare every record,
+    field for field and tag for tag, with the SAM text of a -S run of the same input; both files (-o and -p)."""
+    import bam_reader
+    name, rname = "fx2", "reads150"
+    w = ac.workdir(name)
+    tmp = tempfile.mkdtemp(prefix="psvr_bam_")
+    base = [os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+    for mode, ext in (["-S"], "sam"), ([], "bam"):
+        r = subprocess.run([CLI, "aln"] + mode + ["-o", os.path.join(tmp, "out." + ext), "-p", os.path.join(tmp, "ori." + ext)] + base,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+    header = open(os.path.join(w, "header.sam")).read()
+    for stem in ("out", "ori"):
+        assert bam_reader.check_bgzf(os.path.join(tmp, stem + ".bam")) >= 1
+        text, refs, recs = bam_reader.read_bam(os.path.join(tmp, stem + ".bam"))
+        sam_lines = open(os.path.join(tmp, stem + ".sam")).read().split("\n")
+        sam_head = "".join(l + "\n" for l in sam_lines if l.startswith("@"))
+        sam = [l.split("\t") for l in sam_lines if l and not l.startswith("@")]
+        assert text == sam_head == "".join(l for l in header.splitlines(True) if l.startswith("@"))
+        assert [n for n, _ in refs] == [l.split("SN:")[1].split("\t")[0].strip() for l in header.splitlines() if l.startswith("@SQ")]
+        assert len(recs) == len(sam) and (stem == "ori" or len(sam) > 100)
+        for a, b in zip(sam, recs):
+            assert a == b, "\nsam: %s\nbam: %s" % ("\t".join(a), "\t".join(b))
