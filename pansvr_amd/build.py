@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
     # the drop-in CLI: plain host C++ above the C ABI (no HIP in this translation unit)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", CLI, os.path.join(CSRC, "cli_main.cpp"),
-           "-L" + HERE, "-lpsvr_engine", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+           "-L" + HERE, "-lpsvr_engine", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -15,7 +15,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace psvr {
@@ -24,18 +26,20 @@ class BgzfWriter {
 	FILE *f_ = nullptr;
 	std::vector<uint8_t> buf_;
 	static const size_t kBlock = 0xff00;      // uncompressed bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
+	static const size_t kOut = 0x10000 + 64;
 	bool ok_ = true;
-	void flush_block(const uint8_t *p, size_t n)
+	int threads_ = 1;
+	// one member: gzip header with the BC extra field, raw deflate, CRC32, ISIZE (SAMv1 4.1); returns the member size
+	static size_t compress_block(const uint8_t *p, size_t n, uint8_t *out)
 	{
-		uint8_t out[0x10000 + 64];
 		z_stream zs;
 		memset(&zs, 0, sizeof zs);
-		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok_ = false; return; }
+		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
 		zs.next_in = (Bytef *)p, zs.avail_in = (uInt)n;
-		zs.next_out = out + 18, zs.avail_out = sizeof out - 18 - 8;
+		zs.next_out = out + 18, zs.avail_out = (uInt)(kOut - 18 - 8);
 		int rc = deflate(&zs, Z_FINISH);
 		deflateEnd(&zs);
-		if (rc != Z_STREAM_END) { ok_ = false; return; }
+		if (rc != Z_STREAM_END) return 0;
 		const size_t clen = zs.total_out, bsize = clen + 18 + 8 - 1;
 		static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
 		memcpy(out, hdr, 16);
@@ -43,22 +47,46 @@ class BgzfWriter {
 		const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
 		uint8_t *t = out + 18 + clen;
 		for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
-		if (fwrite(out, 1, clen + 26, f_) != clen + 26) ok_ = false;
+		return clen + 26;
+	}
+	// blocks are independent: compress them on `threads_` threads, write in order
+	void flush_blocks(const uint8_t *p, size_t n)
+	{
+		const size_t nb = (n + kBlock - 1) / kBlock;
+		std::vector<uint8_t> out(nb * kOut);
+		std::vector<size_t> len(nb, 0);
+		std::atomic<size_t> next(0);
+		auto work = [&]() {
+			for (size_t b = next++; b < nb; b = next++) {
+				const size_t o = b * kBlock, m = n - o < kBlock ? n - o : kBlock;
+				len[b] = compress_block(p + o, m, out.data() + b * kOut);
+			}
+		};
+		const int nt = threads_ < 1 ? 1 : (size_t)threads_ > nb ? (int)nb : threads_;
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(work);
+		work();
+		for (std::thread &t : th) t.join();
+		for (size_t b = 0; b < nb; ++b) {
+			if (!len[b] || fwrite(out.data() + b * kOut, 1, len[b], f_) != len[b]) ok_ = false;
+		}
 	}
 public:
-	bool open(const char *fn) { f_ = fopen(fn, "wb"); buf_.reserve(kBlock * 2); return f_ != nullptr; }
+	bool open(const char *fn, int threads = 1) { f_ = fopen(fn, "wb"); threads_ = threads; return f_ != nullptr; }
 	void write(const void *p, size_t n)
 	{
 		const uint8_t *b = (const uint8_t *)p;
 		buf_.insert(buf_.end(), b, b + n);
-		size_t off = 0;
-		while (buf_.size() - off >= kBlock) { flush_block(buf_.data() + off, kBlock); off += kBlock; }
-		if (off) buf_.erase(buf_.begin(), buf_.begin() + off);
+		const size_t batch = kBlock * (size_t)(threads_ < 1 ? 1 : threads_) * 8;   // enough whole blocks to keep every thread busy
+		if (buf_.size() < batch) return;
+		const size_t whole = buf_.size() / kBlock * kBlock;
+		flush_blocks(buf_.data(), whole);
+		buf_.erase(buf_.begin(), buf_.begin() + whole);
 	}
 	bool close()
 	{
 		if (!f_) return false;
-		if (!buf_.empty()) flush_block(buf_.data(), buf_.size());
+		if (!buf_.empty()) flush_blocks(buf_.data(), buf_.size());
 		static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if (fwrite(eof, 1, 28, f_) != 28) ok_ = false;
 		if (fclose(f_) != 0) ok_ = false;
@@ -78,7 +106,6 @@ struct SamFields {
 
 class BamWriter {
 	BgzfWriter z_;
-	std::vector<uint8_t> rec_;
 	static void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 	static void put16(std::vector<uint8_t> &v, uint16_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }
 	static int reg2bin(int64_t beg, int64_t end)             // SAMv1 section 5.3
@@ -140,9 +167,9 @@ class BamWriter {
 		return true;
 	}
 public:
-	bool open(const char *fn, const std::string &header_text, const std::vector<BamRef> &refs)
+	bool open(const char *fn, const std::string &header_text, const std::vector<BamRef> &refs, int threads = 1)
 	{
-		if (!z_.open(fn)) return false;
+		if (!z_.open(fn, threads)) return false;
 		std::vector<uint8_t> h = {'B', 'A', 'M', 1};
 		put32(h, (uint32_t)header_text.size());
 		h.insert(h.end(), header_text.begin(), header_text.end());
@@ -156,8 +183,10 @@ public:
 		z_.write(h.data(), h.size());
 		return true;
 	}
-	bool write(const SamFields &s)
+	// appends one encoded record (block_size + body) to `out`; thread-safe (touches no writer state)
+	static bool encode(const SamFields &s, std::vector<uint8_t> &rec_)
 	{
+		const size_t base = rec_.size();
 		std::vector<uint32_t> cig;
 		int64_t rlen = 0;
 		if (!s.cigar.empty() && s.cigar != "*") {
@@ -178,7 +207,6 @@ public:
 		const bool no_seq = s.seq.empty() || s.seq == "*";
 		const uint32_t l_seq = no_seq ? 0 : (uint32_t)s.seq.size();
 		const int64_t pos0 = s.pos1 - 1;
-		rec_.clear();
 		put32(rec_, 0);                                             // block_size, patched below
 		put32(rec_, (uint32_t)s.tid), put32(rec_, (uint32_t)(int32_t)pos0);
 		rec_.push_back((uint8_t)(s.qname.size() + 1)), rec_.push_back((uint8_t)s.mapq);
@@ -197,12 +225,19 @@ public:
 		}
 		if (s.qual.empty() || s.qual == "*" || s.qual.size() != l_seq) rec_.insert(rec_.end(), l_seq, 0xff);
 		else for (char ch : s.qual) rec_.push_back((uint8_t)(ch - 33));
-		if (!put_tags(rec_, s.tags)) return false;
-		const uint32_t bs = (uint32_t)rec_.size() - 4;
-		for (int i = 0; i < 4; ++i) rec_[i] = (uint8_t)(bs >> (8 * i));
-		z_.write(rec_.data(), rec_.size());
+		if (!put_tags(rec_, s.tags)) { rec_.resize(base); return false; }
+		const uint32_t bs = (uint32_t)(rec_.size() - base) - 4;
+		for (int i = 0; i < 4; ++i) rec_[base + i] = (uint8_t)(bs >> (8 * i));
 		return true;
 	}
+	bool write(const SamFields &s)
+	{
+		std::vector<uint8_t> rec;
+		if (!encode(s, rec)) return false;
+		z_.write(rec.data(), rec.size());
+		return true;
+	}
+	void write_raw(const void *p, size_t n) { z_.write(p, n); }
 	bool close() { return z_.close(); }
 };
 

@@ -10,7 +10,9 @@
 #include <string.h>
 #include <sys/time.h>
 #include <time.h>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/psvr_engine.h"
 #include "host_io.h"
@@ -122,20 +124,22 @@ struct OutFile {
 	FILE *sam = nullptr;
 	psvr::BamWriter bam;
 	bool is_bam = false;
-	bool open(const std::string &fn, bool as_bam, const HeaderInfo &H)
+	bool open(const std::string &fn, bool as_bam, const HeaderInfo &H, int threads)
 	{
 		is_bam = as_bam;
 		if (!as_bam) { sam = fopen(fn.c_str(), "w"); if (sam) fputs(H.text.c_str(), sam); return sam != nullptr; }
 		std::vector<psvr::BamRef> refs;
 		for (size_t i = 0; i < H.names.size(); ++i) refs.push_back({H.names[i], H.lens[i]});
-		return bam.open(fn.c_str(), H.text, refs);
+		return bam.open(fn.c_str(), H.text, refs, threads);
 	}
+	// formatted records (SAM lines or encoded BAM records) of a run of pairs, in order
+	void write_raw(const std::vector<uint8_t> &b) { if (b.empty()) return; if (is_bam) bam.write_raw(b.data(), b.size()); else fwrite(b.data(), 1, b.size(), sam); }
 	bool close() { if (is_bam) return bam.close(); return fclose(sam) == 0; }
 };
 
 // what survives sam_parse1 -> sam_write1 (htslib 1.9 sam.c:1197-1424, sam_format1) for the text built by
 // single_end_handler::output_BAM (rr.cpp:479-536): POS <= 0 drops the record, RNEXT collapses to '=' ...
-static bool emit_record(OutFile &out, const HeaderInfo &H, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar,
+static bool emit_record(const OutFile &out, std::vector<uint8_t> &dst, const HeaderInfo &H, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar,
                         bool has_mate, int mate_chr, uint32_t mate_pos, int isize, const std::string &seq, const std::string &qual, const std::string &tags)
 {
 	int pos = (int)ref_bg;                               // printed with %d
@@ -154,10 +158,15 @@ static bool emit_record(OutFile &out, const HeaderInfo &H, const std::string &na
 		psvr::SamFields f;
 		f.qname = name, f.flag = flag, f.tid = chr_id, f.pos1 = pos, f.mapq = mapq, f.cigar = cigar.empty() ? "*" : cigar;
 		f.mtid = mtid, f.mpos1 = pnext, f.isize = isize, f.seq = seq, f.qual = qual, f.tags = tags;
-		return out.bam.write(f);
+		return psvr::BamWriter::encode(f, dst);
 	}
-	fprintf(out.sam, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%ld\t%d\t%s\t%s%s\n", name.c_str(), flag, H.name(chr_id), pos, mapq, cigar.empty() ? "*" : cigar.c_str(), rnext.c_str(), pnext, isize,
-	        seq.c_str(), qual.c_str(), tags.c_str());
+	char head[512];
+	int n = snprintf(head, sizeof head, "\t%d\t%s\t%d\t%d\t", flag, H.name(chr_id), pos, mapq);
+	auto put = [&](const char *p, size_t m) { dst.insert(dst.end(), (const uint8_t *)p, (const uint8_t *)p + m); };
+	put(name.data(), name.size()), put(head, (size_t)n);
+	if (cigar.empty()) put("*", 1); else put(cigar.data(), cigar.size());
+	n = snprintf(head, sizeof head, "\t%s\t%ld\t%d\t", rnext.c_str(), pnext, isize);
+	put(head, (size_t)n), put(seq.data(), seq.size()), put("\t", 1), put(qual.data(), qual.size()), put(tags.data(), tags.size()), put("\n", 1);
 	return true;
 }
 
@@ -266,7 +275,7 @@ int main(int argc, char **argv)
 	FILE *fq = o.reads == "-" ? stdin : fopen(o.reads.c_str(), "r");
 	if (!fq) { fprintf(stderr, "fail to open file '%s'\n", o.reads.c_str()); abort(); }
 	OutFile fo, fo_ori;
-	if (!fo.open(o.out, !o.sam, H) || !fo_ori.open(o.out_ori, !o.sam, H)) { fprintf(stderr, "fail to open output file\n"); abort(); }
+	if (!fo.open(o.out, !o.sam, H, o.thread_n) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n)) { fprintf(stderr, "fail to open output file\n"); abort(); }
 	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
 	fprintf(stderr, "Processing file: [%s].\n", o.reads.c_str());
 
@@ -301,13 +310,16 @@ int main(int argc, char **argv)
 		if (!rc) rc = psvr_engine_download(eng, res.data(), pres.data(), cig.data(), (int64_t)cig.size(), &used);
 		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
 		fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
-		// ---- step 2: records (output_BAM, rr.cpp:479-536)
-		for (long long p = 0; p < P; ++p) {
-			const psvr_pair_result_t &pr = pres[p];
-			if (frec) {
+		if (frec) {
+			for (long long p = 0; p < P; ++p) {
 				int lens[2] = {(int)fb.recs[2 * p].seq.size(), (int)fb.recs[2 * p + 1].seq.size()};
-				fprintf(frec, "%s\n", record_json(pair_base + p, &res[2 * p], pr, &fb.ori[2 * p], lens, cig.data(), o.trace).c_str());
+				fprintf(frec, "%s\n", record_json(pair_base + p, &res[2 * p], pres[p], &fb.ori[2 * p], lens, cig.data(), o.trace).c_str());
 			}
+		}
+		// ---- step 2: records (output_BAM, rr.cpp:479-536), formatted for runs of pairs on -t threads and written in input order
+		auto format_main = [&](long long p0, long long p1, std::vector<uint8_t> &dst) {
+		for (long long p = p0; p < p1; ++p) {
+			const psvr_pair_result_t &pr = pres[p];
 			if (!pr.gain) continue;
 			for (int k = 0; k < 2; ++k) {
 				const psvr_read_result_t &rr = res[2 * p + k];
@@ -354,11 +366,13 @@ int main(int argc, char **argv)
 					tags += ";";
 				}
 				tags += "\tRC:Z:" + rec.comment;
-				emit_record(fo, H, rec.name, flag, chr_id, ref_bg, mapq, cg, rr.has_mate != 0, rr.mate_chr_id, rr.mate_ref_bg, isize, seq, qual, tags);
+				emit_record(fo, dst, H, rec.name, flag, chr_id, ref_bg, mapq, cg, rr.has_mate != 0, rr.mate_chr_id, rr.mate_ref_bg, isize, seq, qual, tags);
 			}
 		}
+		};
 		// ---- second file (rr.cpp:776-797): pairs neither the original aligner nor the re-aligner placed well
-		for (long long p = 0; p < P; ++p) {
+		auto format_ori = [&](long long p0, long long p1, std::vector<uint8_t> &dst) {
+		for (long long p = p0; p < p1; ++p) {
 			const psvr_pair_result_t &pr = pres[p];
 			if (!(pr.max_score <= par.min_filter_score && fb.ori[2 * p].chr_id != -1 && fb.ori[2 * p + 1].chr_id != -1)) continue;
 			OriRecord orr[2];
@@ -388,8 +402,25 @@ int main(int argc, char **argv)
 				snprintf(b, sizeof b, "\tMS:i:%d", pr.max_score);
 				tags += b;
 				const uint32_t ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg;
-				emit_record(fo_ori, H, rec.name, orr[k].flag, ori.chr_id, ref_bg + 1, orr[k].mapq, orr[k].cigar, true, orr[k].mate_chr, (uint32_t)orr[k].mate_pos, orr[k].isize, seq, qual, tags);
+				emit_record(fo_ori, dst, H, rec.name, orr[k].flag, ori.chr_id, ref_bg + 1, orr[k].mapq, orr[k].cigar, true, orr[k].mate_chr, (uint32_t)orr[k].mate_pos, orr[k].isize, seq, qual, tags);
 			}
+		}
+		};
+		{
+			const long long chunk = 4096, nchunk = (P + chunk - 1) / chunk;
+			std::vector<std::vector<uint8_t>> mb(nchunk), ob(nchunk);
+			std::atomic<long long> next(0);
+			auto work = [&]() {
+				for (long long ci = next++; ci < nchunk; ci = next++) {
+					const long long p0 = ci * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+					format_main(p0, p1, mb[ci]), format_ori(p0, p1, ob[ci]);
+				}
+			};
+			std::vector<std::thread> th;
+			for (int t = 1; t < o.thread_n && t < nchunk; ++t) th.emplace_back(work);
+			work();
+			for (std::thread &t : th) t.join();
+			for (long long ci = 0; ci < nchunk; ++ci) fo.write_raw(mb[ci]), fo_ori.write_raw(ob[ci]);
 		}
 		pair_base += P;
 	}
