@@ -68,6 +68,13 @@ static double cputime()
 	return (double)clock() / CLOCKS_PER_SEC;
 }
 
+static double walltime()
+{
+	struct timeval tv;
+	gettimeofday(&tv, nullptr);
+	return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
 static char rc_char(char c)   // getReverseChar, clib/bam_file.c:316-327
 {
 	switch (c) {
@@ -289,10 +296,13 @@ int main(int argc, char **argv)
 	std::vector<uint32_t> cig;
 	long long loaded = 0, pair_base = 0;
 	int block = 0;
+	double t_read = 0, t_engine = 0, t_format = 0, t_write = 0;
 	for (;;) {
 		long long want = o.batch_pairs;
 		if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
-		if (want <= 0 || !fb.read(fq, want)) break;
+		double tw = walltime();
+		if (want <= 0 || !fb.read(fq, want, o.thread_n)) break;
+		t_read += walltime() - tw, tw = walltime();
 		loaded += fb.n_pairs();
 		if (!eng) {
 			fb.stat_params(&par);
@@ -309,6 +319,7 @@ int main(int argc, char **argv)
 		cig.resize(used + 1);
 		if (!rc) rc = psvr_engine_download(eng, res.data(), pres.data(), cig.data(), (int64_t)cig.size(), &used);
 		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
+		t_engine += walltime() - tw, tw = walltime();
 		fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
 		if (frec) {
 			for (long long p = 0; p < P; ++p) {
@@ -420,7 +431,9 @@ int main(int argc, char **argv)
 			for (int t = 1; t < o.thread_n && t < nchunk; ++t) th.emplace_back(work);
 			work();
 			for (std::thread &t : th) t.join();
+			t_format += walltime() - tw, tw = walltime();
 			for (long long ci = 0; ci < nchunk; ++ci) fo.write_raw(mb[ci]), fo_ori.write_raw(ob[ci]);
+			t_write += walltime() - tw;
 		}
 		pair_base += P;
 	}
@@ -430,5 +443,6 @@ int main(int argc, char **argv)
 	if (eng) psvr_engine_destroy(eng);
 	psvr_index_destroy(idx);
 	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
+	fprintf(stderr, "[panSVR-amd] wall: read+parse %.3f s, engine (upload+run+download) %.3f s, format %.3f s, write%s %.3f s\n", t_read, t_engine, t_format, o.sam ? "" : "+compress", t_write);
 	return 0;
 }

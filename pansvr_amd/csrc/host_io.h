@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "aln_device.h"
 
@@ -204,41 +205,79 @@ struct FastqBatch {
 	bool have_first = false;
 	long long n_pairs() const { return (long long)recs.size() / 2; }
 
-	static bool read_rec(FILE *f, FqRec *r)
-	{
-		static thread_local char *line = nullptr;
-		static thread_local size_t cap = 0;
-		std::string l[4];
-		for (int i = 0; i < 4; ++i) {
-			ssize_t n = getline(&line, &cap, f);
-			if (n <= 0) return false;
-			while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = 0;
-			l[i] = line;
-		}
-		size_t sp = l[0].find_first_of(" \t");
-		r->name = l[0].substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-		r->comment = sp == std::string::npos ? "" : l[0].substr(sp + 1);
-		r->seq = l[1], r->qual = l[3];
-		return true;
-	}
+	// raw text carried between batches: lines are located with memchr in one pass, records are then built on `threads`
+	// threads (the per-record string work dominates a serial reader)
+	std::vector<char> raw;
+	size_t raw_pos = 0, raw_len = 0;
+	bool raw_eof = false;
 	// up to max_pairs pairs, or 100 MB of bases like load_reads (rr.cpp:109,126)
-	bool read(FILE *f, long long max_pairs)
+	bool read(FILE *f, long long max_pairs, int threads = 1)
 	{
 		recs.clear(), bases.clear(), base_off.assign(1, 0), ori.clear();
-		long long total = 0;
-		FqRec a, b;
-		while ((long long)recs.size() / 2 < max_pairs && total < 100000000 && read_rec(f, &a) && read_rec(f, &b)) {
-			if (!have_first) first_comment = a.comment, have_first = true;
-			for (FqRec *r : {&a, &b}) {
-				ori.push_back(parse_ori(r->comment));
-				bases.insert(bases.end(), r->seq.begin(), r->seq.end());
-				base_off.push_back((long long)bases.size());
-				total += r->seq.size();
-				recs.push_back(*r);
-			}
+		if (raw_pos) { memmove(raw.data(), raw.data() + raw_pos, raw_len - raw_pos); raw_len -= raw_pos, raw_pos = 0; }
+		std::vector<size_t> ls;                  // start offset of every line of the batch, plus the end of the last one
+		size_t scan = 0, pair_end = 0;
+		long long total = 0, npairs = 0;
+		while (npairs < max_pairs && total < 100000000) {
+			const char *nl = scan < raw_len ? (const char *)memchr(raw.data() + scan, '\n', raw_len - scan) : nullptr;
+			size_t line_end;
+			if (nl) line_end = (size_t)(nl - raw.data());
+			else if (!raw_eof) {
+				if (raw.size() - raw_len < ((size_t)16 << 20)) raw.resize(raw.size() + ((size_t)64 << 20));
+				const size_t got = fread(raw.data() + raw_len, 1, raw.size() - raw_len, f);
+				raw_len += got;
+				if (got == 0) raw_eof = true;
+				continue;
+			} else if (scan < raw_len) line_end = raw_len;      // last line without a newline
+			else break;
+			ls.push_back(scan);
+			if ((ls.size() & 3) == 2) total += (long long)(line_end - scan);
+			scan = line_end + (nl ? 1 : 0);
+			if ((ls.size() & 7) == 0) ++npairs, pair_end = scan;
 		}
-		bases.push_back(0);
-		return !recs.empty();
+		ls.resize((size_t)npairs * 8);
+		ls.push_back(pair_end);
+		raw_pos = pair_end;
+		if (npairs == 0) { bases.push_back(0); return false; }
+		const long long R = 2 * npairs;
+		recs.resize(R), ori.resize(R), base_off.resize(R + 1);
+		auto line = [&](size_t li, const char *&b, size_t &n) {
+			b = raw.data() + ls[li];
+			n = ls[li + 1] - ls[li];
+			while (n > 0 && (b[n - 1] == '\n' || b[n - 1] == '\r')) --n;
+		};
+		std::string first_before_parse;
+		auto build = [&](long long r0, long long r1) {
+			for (long long r = r0; r < r1; ++r) {
+				const char *b; size_t n;
+				FqRec &rec = recs[r];
+				line((size_t)r * 4, b, n);
+				size_t sp = 1;
+				while (sp < n && b[sp] != ' ' && b[sp] != '\t') ++sp;
+				rec.name.assign(n ? b + 1 : b, n ? sp - 1 : 0);
+				if (sp < n) rec.comment.assign(b + sp + 1, n - sp - 1); else rec.comment.clear();
+				if (r == 0) first_before_parse = rec.comment;
+				line((size_t)r * 4 + 1, b, n), rec.seq.assign(b, n);
+				line((size_t)r * 4 + 3, b, n), rec.qual.assign(b, n);
+				ori[r] = parse_ori(rec.comment);
+			}
+		};
+		auto parallel = [&](auto &&fn) {
+			const int nt = threads < 1 ? 1 : threads;
+			const long long per = (R + nt - 1) / nt;
+			std::vector<std::thread> th;
+			for (int t = 1; t < nt; ++t) if (t * per < R) th.emplace_back(fn, t * per, (t + 1) * per < R ? (t + 1) * per : R);
+			fn(0, per < R ? per : R);
+			for (std::thread &t : th) t.join();
+		};
+		parallel(build);
+		if (!have_first) first_comment = first_before_parse, have_first = true;
+		base_off[0] = 0;
+		for (long long r = 0; r < R; ++r) base_off[r + 1] = base_off[r] + (long long)recs[r].seq.size();
+		bases.resize((size_t)base_off[R] + 1);
+		parallel([&](long long r0, long long r1) { for (long long r = r0; r < r1; ++r) memcpy(bases.data() + base_off[r], recs[r].seq.data(), recs[r].seq.size()); });
+		bases[(size_t)base_off[R]] = 0;
+		return true;
 	}
 	void stat_params(psvr_aln_params_t *p) const   // load_reads, rr.cpp:134-148
 	{

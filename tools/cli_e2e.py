@@ -31,6 +31,6 @@ for mode, ext in (["-S"], "sam"), ([], "bam"):
     dt = time.time() - t
     err = r.stderr.decode()
     print(ext, "rc", r.returncode, "wall %.2f s" % dt, "-> %.0f reads/s incl. index load" % (2 * pairs / dt), "| out MB", os.path.getsize(os.path.join(tmp, "o." + ext)) >> 20)
-    print("   ", " | ".join(l for l in err.split("\n") if "sec" in l or "TIME" in l)[:400])
+    print("   ", " | ".join(l for l in err.split("\n") if "sec" in l or "wall:" in l)[:400])
 import shutil
 shutil.rmtree(tmp, ignore_errors=True)
