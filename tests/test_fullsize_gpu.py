@@ -45,13 +45,25 @@ def canon(reads, cig):
 
 
 def test_fullsize_properties_and_prefix_parity():
+    """BASELINE configs[1]: 1 M pairs of 150 bp against 10 k anchors."""
+    run_config(dict(n_anchors=10000, seed=11), dict(seed=13), (150, 200, 400, 600), N_PAIRS, N_ORACLE, True)
+
+
+def test_cfg5_long_reads_properties_and_prefix_parity():
+    """BASELINE configs[4] shape (250 bp reads, 2 000 anchors with 2 kbp edges, indels up to 40: DP problems of several hundred
+    anti-diagonals, direction bytes in the HBM slab, K = 3..5 kernels) at 100 k pairs, oracle parity on the first 5 k."""
+    run_config(dict(n_anchors=2000, seed=17, edge=2000, allele=(60, 2000)), dict(seed=19, L=250, frag=(400, 700), maxindel=40), (250, 400, 550, 700),
+               int(os.environ.get("PSVR_CFG5_PAIRS", "100000")), 5000, False)
+
+
+def run_config(anc_kw, reads_kw, stat, N_PAIRS, N_ORACLE, split):
     from pansvr_amd import aln
-    anc = bench_data.make_anchors(10000, seed=11)
+    anc = bench_data.make_anchors(**anc_kw)
     ix = bench_data.build_index(anc, dense=True)
     index = aln.Index(ix, ["chr1", "chr2"], device=0)
-    bases, base_off, ori, isize = bench_data.make_reads(anc, N_PAIRS, seed=13)
+    bases, base_off, ori, isize = bench_data.make_reads(anc, N_PAIRS, **reads_kw)
     lens = np.diff(base_off)
-    params = aln.default_params((150, 200, 400, 600))
+    params = aln.default_params(stat)
     eng = aln.Engine(index, params)
     eng.upload(bases, base_off, ori)
     eng.run()
@@ -84,7 +96,7 @@ def test_fullsize_properties_and_prefix_parity():
     tmp = tempfile.mkdtemp(prefix="psvr_full_")
     small = {k: v for k, v in ix.items() if k != "hash"}
     bench_data.write_index_dir(small, os.path.join(tmp, "idx"))
-    bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, n_pairs=N_ORACLE)
+    bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, stat=stat, n_pairs=N_ORACLE)
     with open(os.path.join(tmp, "header.sam"), "w") as f:
         f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")
     out = subprocess.run([ac.ORACLE_EXE, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam")],
@@ -94,6 +106,9 @@ def test_fullsize_properties_and_prefix_parity():
     assert len(want) == N_ORACLE
     bad = [i for i in range(N_ORACLE) if want[i] != got[i]]
     assert not bad, "%d/%d prefix pairs differ, first %d:\noracle %s\nengine %s" % (len(bad), N_ORACLE, bad[0], json.dumps(want[bad[0]]), json.dumps(got[bad[0]]))
+    if not split:
+        eng.close(), index.close()
+        return
     # --- batch-split invariance (first 200 k pairs as 2 x 100 k with the stream state carried across)
     n2 = min(200000, N_PAIRS)
     h = n2 // 2
