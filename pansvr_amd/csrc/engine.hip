@@ -381,7 +381,7 @@ struct DpPlanDev {
 	int32_t *idx;
 	psvr_extz_t *ez;
 };
-__global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w)
+__global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny_ok)
 {
 	__shared__ unsigned int lh[256];
 	lh[threadIdx.x] = 0;
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w)
 		const DpDesc &x = d.desc[i];
 		d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
 		int need;
-		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need);
+		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need, tiny_ok != 0);
 		int cls = 0;
 		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
-		d.plen[i] = (kind == 0 || kind > 5) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
+		d.plen[i] = (kind == 0 || (kind > 5 && kind != PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
 		int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
 		d.bucket[i] = b;
 		atomicAdd(&lh[b], 1u);
@@ -623,7 +623,7 @@ struct GpuBE {
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
 		pd.hist = plan_hist.as<unsigned long long>(), pd.idx = plan_idx.as<int32_t>(), pd.ez = d.ez;
 		PSVR_HIP(hipMemsetAsync(d.qlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(d.tlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(pd.plen + n, 0, 4, stream));
-		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200);
+		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200, dp_tiny_ok(dpP, true) ? 1 : 0);
 		st_scan((const int32_t *)d.qlen, n + 1, 1, 0, 0ll, d.q_off);
 		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
 		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
@@ -641,7 +641,7 @@ struct GpuBE {
 		long long bstart[256], acc = 0;
 		memset(bstart, 0, sizeof bstart);
 		std::vector<Launch3> ls;
-		const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
+		const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
 		for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 			for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
 				int b = kind_order[ko] * PSVR_DP_NUM_LDS_CLASSES + cls;

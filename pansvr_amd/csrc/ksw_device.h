@@ -45,9 +45,14 @@ struct DpBatch { // device pointers of one batch
 	long long n;               // problems in this launch
 };
 
+#define PSVR_DP_KIND_TINY 11
+#define PSVR_DP_TINY_MAX 16            // extd2_tiny_kernel: qlen, tlen <= 16, one thread per alignment
 static const int kDpWaves = 4;   // alignments (wavefronts) per workgroup of the register-resident kernels
 template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
+__global__ void extd2_tiny_kernel(DpBatch B, DpParams P, int max_rows);        // ksw_kernels.hip
+// the tiny kernel needs the lean regime (values fit int8, band never clips a 16 x 16 matrix) and only the flags it implements
+__host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 
 // true when the band [(r-w+1)>>1, (r+w)>>1] never clips the DP matrix: then st0/en0 follow the matrix edges only, every
 // in-band cell's (r-1,t-1)/(r-1,t) neighbours are in-band or one of the explicit boundary values (ksw2_extd2_sse.c:142-156),
@@ -87,12 +92,14 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 // Direction bytes stay in LDS only while the whole footprint is at most this (keeps >= 32 waves per CU resident);
 // larger problems stream them to an HBM slab and trace back through L2
 #define PSVR_DP_PG_THRESHOLD 4096
-#define PSVR_DP_NUM_KINDS 11
+#define PSVR_DP_NUM_KINDS 12
 // kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM),
+// 11 = extd2_tiny_kernel (one thread per alignment; *need = 512 x anti-diagonals, which bins the problems by size),
 // 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
-__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need)
+__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool tiny_ok = false)
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
+	if (tiny_ok && qlen <= PSVR_DP_TINY_MAX && tlen <= PSVR_DP_TINY_MAX) { *need = (qlen + tlen - 1) * 512; return PSVR_DP_KIND_TINY; }
 	int T = (tlen + 15) / 16 * 16;
 	long long n = dp_reg_lds_need(qlen, tlen, w);
 	if (fast_ok && T <= 320) {

@@ -119,9 +119,9 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 			return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld: qlen=%d tlen=%d exceeds %d", (long long)i, ql, tl, kMaxLen);
 		}
 		int need = 0;
-		int kind = dp_classify(ql, tl, par->w, fast_ok, variant, pl->P.skip != 0, &need);
+		int kind = dp_classify(ql, tl, par->w, fast_ok, variant, pl->P.skip != 0, &need, dp_tiny_ok(pl->P, fast_ok));
 		if (kind < 0) { delete pl; return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld needs %d B of LDS", (long long)i, need); }
-		if ((kind == 0 || kind > 5) && ql > 0 && tl > 0) {
+		if ((kind == 0 || (kind > 5 && kind != PSVR_DP_KIND_TINY)) && ql > 0 && tl > 0) {
 			poff[i] = pslab;
 			pslab += (dp_p_bytes(ql, tl, par->w) + 255) & ~(int64_t)255;
 		}
@@ -132,7 +132,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	std::vector<int32_t> idx;
 	idx.reserve(n);
 	// general kernel first, then the HBM-direction-byte kernels, then the LDS ones; large LDS classes first
-	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
+	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
 	for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 		for (int cls = kNumLdsClasses - 1; cls >= 0; --cls) {
 			auto &b = bucket[kind_order[ko] * kNumLdsClasses + cls];

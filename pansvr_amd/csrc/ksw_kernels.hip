@@ -365,6 +365,115 @@ template __global__ void extd2_reg_kernel<5, true>(DpBatch, DpParams);
 
 
 // ------------------------------------------------------------------------------------------
+// tiny problems: one THREAD per alignment
+// ------------------------------------------------------------------------------------------
+// Most DP calls of the `aln` path are end-to-end gap fills of a few bases (median 6 x 6): a wavefront per problem spends its
+// time in per-diagonal bookkeeping with a handful of lanes active.  Here 64 problems with qlen, tlen <= 16 share a wavefront,
+// each thread sweeping its own matrix anti-diagonal by anti-diagonal in the lean regime of dp_lean_loop (same recurrences,
+// same boundary values, same tie order, same z-drop rule; nothing of the SSE layout can be observed at this size).
+// Per-thread state lives in LDS in [slot][thread] order (bank-conflict free): per column t one word u|v|x|y (int8 each) and
+// one word x2|y2|H (int8, int8, int16), plus the direction bytes of rows x 16 cells; the CIGAR is staged in the dead state words.
+__global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, int max_rows)
+{
+	extern __shared__ __align__(16) uint32_t tiny_lds[];
+	const int lane = threadIdx.x;
+	const long long slot = (long long)blockIdx.x * 64 + lane;
+	if (slot >= B.n) return;
+	uint32_t *W0 = tiny_lds + lane, *W1 = tiny_lds + 16 * 64 + lane;       // element t at [t * 64]
+	uint8_t *PD = (uint8_t *)(tiny_lds + 2 * 16 * 64) + lane;              // cell (r, t) at [(r * 16 + t) * 64]
+	const int pid = B.idx[slot];
+	const int qlen = B.qlen[pid], tlen = B.tlen[pid];
+	psvr_extz_t *out = B.ez + pid;
+	EzAcc ez;
+	ez.reset();
+	if (P.skip || qlen <= 0 || tlen <= 0 || qlen > PSVR_DP_TINY_MAX || tlen > PSVR_DP_TINY_MAX || qlen + tlen - 1 > max_rows) { write_ez(out, ez, 0); return; }
+	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
+	unsigned long long qp = 0, tp = 0;                                      // 4 bits per base
+	for (int i = 0; i < qlen; ++i) qp |= (unsigned long long)(query[i] & 15) << (4 * i);
+	for (int i = 0; i < tlen; ++i) tp |= (unsigned long long)(target[i] & 15) << (4 * i);
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
+	auto pack0 = [](int u, int v, int x, int y) { return (uint32_t)(u & 0xff) | (uint32_t)(v & 0xff) << 8 | (uint32_t)(x & 0xff) << 16 | (uint32_t)(y & 0xff) << 24; };
+	auto pack1 = [](int x2, int y2, int h) { return (uint32_t)(x2 & 0xff) | (uint32_t)(y2 & 0xff) << 8 | (uint32_t)(h & 0xffff) << 16; };
+	auto ur_of = [&](int r) { return r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2); };
+	for (int t = 0; t < tlen; ++t) {
+		W0[t * 64] = pack0(ur_of(t), neg_qe, neg_qe, neg_qe);                // u/y/y2 of the first cell of column t (:153-156)
+		W1[t * 64] = pack1(neg_qe2, neg_qe2, -P.qe_pre);
+	}
+	const int n_rows = qlen + tlen - 1;
+	for (int r = 0; r < n_rows; ++r) {
+		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
+		// (r-1, st0-1): the boundary column -1 (:142-152) or the old state of the slot left of the band
+		int x1 = neg_qe, v1 = ur_of(r), x21 = neg_qe2, h1 = 0;
+		if (st0 > 0) {
+			const uint32_t a = W0[(st0 - 1) * 64], b = W1[(st0 - 1) * 64];
+			v1 = s8(a >> 8), x1 = s8(a >> 16), x21 = s8(b), h1 = (int)(int16_t)(b >> 16);
+		}
+		int bh = (int)0x80000000, H_en0 = 0, H_st0 = 0;
+		unsigned bk = 0xffffffffu;
+		for (int t = st0; t <= en0; ++t) {
+			const uint32_t a = W0[t * 64], b = W1[t * 64];
+			const int ut = s8(a), vo = s8(a >> 8), xo = s8(a >> 16), yo = s8(a >> 24), x2o = s8(b), y2o = s8(b >> 8), ho = (int)(int16_t)(b >> 16);
+			const int xt1 = x1, vt1 = v1, x2t1 = x21, hl = h1;
+			x1 = xo, v1 = vo, x21 = x2o, h1 = ho;                               // old values of this slot feed the next column
+			const int tc = (int)(tp >> (4 * t)) & 15, qc = (int)(qp >> (4 * (r - t))) & 15;
+			int sc = tc == qc ? P.sc_mch : P.sc_mis;
+			sc = (tc == P.m1 || qc == P.m1) ? P.sc_N : sc;
+			int za = xt1 + vt1, zb = yo + ut, za2 = x2t1 + vt1, zb2 = y2o + ut;
+			int z = max(max(sc, za), zb);
+			z = max(max(z, za2), zb2);
+			int d = 4;
+			d = za2 == z ? 3 : d;
+			d = zb == z ? 2 : d;
+			d = za == z ? 1 : d;
+			d = sc == z ? 0 : d;
+			z = min(z, P.sc_mch);
+			const int un = z - vt1, vn = z - ut;
+			const int zq = z - P.q, zq2 = z - P.q2;
+			za -= zq, zb -= zq, za2 -= zq2, zb2 -= zq2;
+			d |= (za > 0 ? 0x08 : 0) | (zb > 0 ? 0x10 : 0) | (za2 > 0 ? 0x20 : 0) | (zb2 > 0 ? 0x40 : 0);
+			const int hn = (t == en0 && en0 > 0) ? hl + un : ho + vn;             // exact H (:316-351)
+			W0[t * 64] = pack0(un, vn, max(za, 0) - qe8, max(zb, 0) - qe8);
+			W1[t * 64] = pack1(max(za2, 0) - qe28, max(zb2, 0) - qe28, hn);
+			if (with_cigar) PD[(r * 16 + t) * 64] = (uint8_t)d;
+			if (t == en0) H_en0 = hn;
+			if (t == st0) H_st0 = hn;
+			const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
+			                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
+			if (hn > bh || (hn == bh && rank < bk)) bh = hn, bk = rank;          // the reference's order among equal cells (:322-349)
+		}
+		const int max_t = bk == 0 ? en0 : st0 + (int)((bk - 1u) & 4095u);
+		if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
+		if (r - st0 == qlen - 1 && H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
+		if (ez.apply_zdrop(bh, r, max_t, P.zdrop, P.e2)) break;
+		if (r == n_rows - 1 && en0 == tlen - 1) ez.score = H_en0;
+	}
+	int n_cigar = 0;
+	if (with_cigar) {
+		int i0 = -1, j0 = -1;
+		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+		else if (!ez.zdropped && (P.flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
+		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+		if (i0 >= 0 && j0 >= 0) {
+			const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
+			// at most qlen + tlen <= 32 ops: staged in the 32 state words, which are dead now
+			n_cigar = traceback(i0, j0, qlen, tlen, w,
+				[&](int r, int k) { return (int)PD[(r * 16 + k) * 64]; },
+				[&](int k, uint32_t word) { (k < 16 ? W0[k * 64] : W1[(k - 16) * 64]) = word; });
+			uint32_t *dst = B.cigar + out->cigar_off;
+			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
+			for (int m = 0; m < n_cigar; ++m) {
+				const int k = rev ? m : n_cigar - 1 - m;
+				dst[m] = k < 16 ? W0[k * 64] : W1[(k - 16) * 64];
+			}
+		}
+	}
+	write_ez(out, ez, n_cigar);
+}
+
+// ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image
 //   extd2: u|v|x|y|x2|y2|s|sf|qr   (ksw2_extd2_sse.c:100-103)
 //   extz2: u|v|x|y|s|sf|qr         (ksw2_extz2_sse.c:85-87)

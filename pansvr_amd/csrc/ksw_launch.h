@@ -9,7 +9,7 @@ inline const char *dp_kind_name(int kind, int variant)
 {
 	static const char *n[PSVR_DP_NUM_KINDS] = {"extd2_lds_kernel", "extd2_reg_kernel<1,lds>", "extd2_reg_kernel<2,lds>", "extd2_reg_kernel<3,lds>", "extd2_reg_kernel<4,lds>",
 	                                           "extd2_reg_kernel<5,lds>", "extd2_reg_kernel<1,hbm>", "extd2_reg_kernel<2,hbm>", "extd2_reg_kernel<3,hbm>", "extd2_reg_kernel<4,hbm>",
-	                                           "extd2_reg_kernel<5,hbm>"};
+	                                           "extd2_reg_kernel<5,hbm>", "extd2_tiny_kernel"};
 	if (kind == 0 && variant == 1) return "extz2_lds_kernel";
 	return n[kind];
 }
@@ -18,6 +18,11 @@ inline void dp_launch_kind(int kind, int variant, unsigned count, int lds, hipSt
 {
 	DpBatch B = B0;
 	B.n = count, B.lds_per_wave = lds;
+	if (kind == PSVR_DP_KIND_TINY) {        // `lds` is the size bin: 512 bytes per anti-diagonal
+		const int max_rows = lds / 512;
+		hipLaunchKernelGGL(extd2_tiny_kernel, dim3((count + 63) / 64), dim3(64), (size_t)8192 + (size_t)max_rows * 1024, stream, B, P, max_rows);
+		return;
+	}
 	const bool reg = kind >= 1;
 	dim3 g(reg ? (count + kDpWaves - 1) / kDpWaves : count), b(reg ? 64 * kDpWaves : 64);
 	if (reg) lds *= kDpWaves;

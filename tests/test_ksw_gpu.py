@@ -1,8 +1,9 @@
 """-m gpu: the HIP DP kernels (through the C ABI, seam B2) against
 (1) the committed reference known-answer vectors and (2) the oracle on fresh random inputs."""
+import numpy as np
 import pytest
 
-from ksw_cases import mat5, random_cases
+from ksw_cases import rand_seq, case, mat5, random_cases
 from ksw_ref import run_oracle
 from test_oracle_ksw import diff, load_kat
 
@@ -45,6 +46,33 @@ def test_gpu_matches_oracle_random(variant):
         if g != want:
             bad.append((i, len(c["query"]), len(c["target"]), diff(want, g)))
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:3])
+
+
+def test_gpu_tiny_problems_match_oracle():
+    """qlen, tlen <= 16 go to the one-thread-per-alignment kernel (extd2_tiny_kernel): every shape 1..16 x 1..16 several
+    times over, with N bases, the flags that kernel implements (extension-only, reversed CIGAR, score-only) and z-drop values
+    small enough to trigger on a 16-base matrix."""
+    rng = np.random.RandomState(4242)
+    cases = []
+    for rep in range(6):
+        for ql in range(1, 17):
+            for tl in range(1, 17):
+                q = rand_seq(rng, ql)
+                t = (list(q[:min(ql, tl)]) + rand_seq(rng, tl))[:tl] if rng.randint(2) else rand_seq(rng, tl)
+                t = [int(x) for x in t]
+                for _ in range(rng.randint(3)):
+                    t[rng.randint(tl)] = int(rng.randint(5))           # substitutions, some to N (4)
+                if rng.randint(8) == 0:
+                    q[rng.randint(ql)] = 4
+                flag = int(rng.choice([0, 0, 0, 0x40, 0x80, 0xC0, 0x01, 0x41]))
+                cases.append(case(q, t, flag=flag, zdrop=int(rng.choice([400, 400, 10, 3])), end_bonus=int(rng.choice([-1, 0, 5]))))
+    got = run_gpu(cases, "extd2")
+    bad = []
+    for i, (c, g) in enumerate(zip(cases, got)):
+        want = run_oracle(c, "extd2")
+        if g != want:
+            bad.append((i, c["flag"], c["zdrop"], len(c["query"]), len(c["target"]), diff(want, g)))
+    assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(cases), bad[:3])
 
 
 def test_gpu_empty_and_degenerate():
