@@ -377,7 +377,7 @@ struct DpPlanDev {
 	int32_t *qlen, *tlen; long long *q_off, *t_off, *p_off;
 	int32_t *plen;                 // padded direction-byte bytes for general-kernel problems (0 otherwise), as int32 units of 256 B
 	int32_t *bucket;               // bucket id per problem
-	unsigned long long *hist;      // [6*13] counts, then cursors
+	unsigned long long *hist;      // [256] counts, [256] cursors, then [16] the longest query per strip class + [1] the scratch top
 	int32_t *idx;
 	psvr_extz_t *ez;
 };
@@ -394,9 +394,10 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need, tiny_ok != 0);
 		int cls = 0;
 		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
-		d.plen[i] = (kind == 0 || (kind > 5 && kind != PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
+		d.plen[i] = (kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
 		int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
 		d.bucket[i] = b;
+		if (kind == PSVR_DP_KIND_STRIP) atomicMax(d.hist + 512 + cls, (unsigned long long)x.qlen);
 		atomicAdd(&lh[b], 1u);
 	}
 	__syncthreads();
@@ -433,7 +434,7 @@ struct GpuBE {
 	hipStream_t stream = nullptr;
 	hipError_t last = hipSuccess;
 	std::vector<std::pair<std::string, long long>> launches;   // for psvr_engine_stats
-	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, pslab;
+	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, pslab, strip_ws;
 	DpParams dpP;
 	bool dp_ready = false;
 
@@ -616,8 +617,8 @@ struct GpuBE {
 		// upper bounds for the sequence buffers: every problem has qlen, tlen < 1600; size from the actual lens
 		if (!core.ensure_dp(n, 0, 0, 0)) return set_error(PSVR_ERR_NOMEM, "DP buffers");
 		PSVR_HIP(plan_bucket.ensure(n * 4)); PSVR_HIP(plan_idx.ensure(n * 4)); PSVR_HIP(plan_plen.ensure((n + 1) * 4)); PSVR_HIP(plan_poff.ensure((n + 1) * 8));
-		PSVR_HIP(plan_hist.ensure(512 * 8)); PSVR_HIP(plan_bstart.ensure(256 * 8));
-		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 512 * 8, stream));
+		PSVR_HIP(plan_hist.ensure(544 * 8)); PSVR_HIP(plan_bstart.ensure(256 * 8));
+		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 544 * 8, stream));
 		DpPlanDev pd;
 		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
@@ -628,9 +629,10 @@ struct GpuBE {
 		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
 		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
 		PSVR_HIP(hipGetLastError());
-		unsigned long long hist[256];
+		unsigned long long hist[256], qmax[16];
 		long long tot[3];
 		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 256 * 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(qmax, (char *)plan_hist.p + 512 * 8, 16 * 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[0], d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[1], d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[2], pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
@@ -638,10 +640,17 @@ struct GpuBE {
 		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
+		// scratch of the strip kernel: every wavefront bump-allocates what its 64 problems need; bound per class by its longest query
+		unsigned long long ws_bytes = 0;
+		for (int cls = 0; cls < PSVR_DP_NUM_LDS_CLASSES; ++cls) {
+			const unsigned long long cnt = hist[PSVR_DP_KIND_STRIP * PSVR_DP_NUM_LDS_CLASSES + cls];
+			if (cnt) { const int lanes = dp_team_lanes(cls + 1); ws_bytes += (cnt * lanes + 63) / 64 * dp_team_ws_bytes((int)qmax[cls], cls + 1, lanes); }
+		}
+		PSVR_HIP(strip_ws.ensure((size_t)ws_bytes + 256));
 		long long bstart[256], acc = 0;
 		memset(bstart, 0, sizeof bstart);
 		std::vector<Launch3> ls;
-		const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
+		const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 12, 11};
 		for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 			for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
 				int b = kind_order[ko] * PSVR_DP_NUM_LDS_CLASSES + cls;
@@ -660,13 +669,18 @@ struct GpuBE {
 		B.qseq = d.qbuf, B.q_off = (const int64_t *)d.q_off, B.qlen = d.qlen;
 		B.tseq = d.tbuf, B.t_off = (const int64_t *)d.t_off, B.tlen = d.tlen;
 		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = (const int64_t *)plan_poff.p, B.p_unit_shift = 8;   // slab offsets in 256-byte units
+		B.ws = (uint8_t *)strip_ws.p, B.ws_top = plan_hist.as<unsigned long long>() + 528, B.ws_cap = ws_bytes;   // the top counter was zeroed with the histograms
+		TeamLaunch team;
 		for (const Launch3 &L : ls) {
+			if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds) + 1, L.first, L.count); continue; }
 			B.idx = plan_idx.as<int32_t>() + L.first;
 			t0(dp_kind_name(L.kind, 0));
 			dp_launch_kind(L.kind, 0, (unsigned)L.count, L.lds, stream, B, dpP);
 			t1();
 			PSVR_HIP(hipGetLastError());
 		}
+		B.idx = plan_idx.as<int32_t>();
+		if (team.T.n_classes) { t0("extd2_team_kernel"); team.launch(stream, B, dpP); t1(); PSVR_HIP(hipGetLastError()); }
 		return PSVR_OK;
 	}
 	struct Launch3 { int kind, lds; long long first, count; };

@@ -43,16 +43,37 @@ struct DpBatch { // device pointers of one batch
 	int32_t p_unit_shift;
 	int32_t lds_per_wave;      // reg kernels: dynamic LDS bytes of one wavefront's problem
 	long long n;               // problems in this launch
+	uint8_t *ws; unsigned long long *ws_top; unsigned long long ws_cap;   // strip kernel: per-wavefront scratch, bump-allocated
 };
 
+#define PSVR_DP_NUM_LDS_CLASSES 13
 #define PSVR_DP_KIND_TINY 11
+#define PSVR_DP_KIND_STRIP 12
+#define PSVR_DP_STRIP 16               // extd2_team_kernel: size classes count 16-column strips
 #define PSVR_DP_TINY_MAX 16            // extd2_tiny_kernel: qlen, tlen <= 16, one thread per alignment
 static const int kDpWaves = 4;   // alignments (wavefronts) per workgroup of the register-resident kernels
 template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
 __global__ void extd2_tiny_kernel(DpBatch B, DpParams P, int max_rows);        // ksw_kernels.hip
-// the tiny kernel needs the lean regime (values fit int8, band never clips a 16 x 16 matrix) and only the flags it implements
+// all size classes of the team kernel go out in ONE launch (a class alone rarely fills the chip): block b serves class c with
+// first_block[c] <= b < first_block[c + 1]; its alignments are idx[first_slot[c] + ...], count[c] of them
+struct TeamPlan {
+	int32_t n_classes;
+	int32_t first_block[PSVR_DP_NUM_LDS_CLASSES + 1];
+	int32_t n_strips16[PSVR_DP_NUM_LDS_CLASSES];
+	long long first_slot[PSVR_DP_NUM_LDS_CLASSES], count[PSVR_DP_NUM_LDS_CLASSES];
+};
+template <int LANES> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip
+// the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
+// lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips
+__host__ __device__ inline int dp_team_lanes(int n_strips16) { return 4; }
+// scratch bytes one wavefront of the team kernel needs for alignments with at most qmax query bases in that class
+__host__ __device__ inline unsigned long long dp_team_ws_bytes(int qmax, int n_strips16, int lanes)
+{
+	const int sw = 4 * lanes, pb = 64 / lanes, n_strips = (n_strips16 * 16 + sw - 1) / sw;
+	return (unsigned long long)256 * n_strips * (qmax + sw - 1) + (unsigned long long)pb * 28 * (qmax + sw * n_strips + 1);
+}
 
 // true when the band [(r-w+1)>>1, (r+w)>>1] never clips the DP matrix: then st0/en0 follow the matrix edges only, every
 // in-band cell's (r-1,t-1)/(r-1,t) neighbours are in-band or one of the explicit boundary values (ksw2_extd2_sse.c:142-156),
@@ -60,7 +81,6 @@ __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { re
 __host__ __device__ inline bool dp_band_never_binds(int qlen, int tlen, int w) { return qlen <= w && tlen <= w + 1; }
 
 // ---- size classes shared by the host planner (ksw_host.hip) and the device-side planner (engine.hip)
-#define PSVR_DP_NUM_LDS_CLASSES 13
 #define PSVR_DP_MAX_LDS (160 * 1024)
 __host__ __device__ inline int dp_lds_class_bytes(int cls)
 {
@@ -92,7 +112,7 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 // Direction bytes stay in LDS only while the whole footprint is at most this (keeps >= 32 waves per CU resident);
 // larger problems stream them to an HBM slab and trace back through L2
 #define PSVR_DP_PG_THRESHOLD 4096
-#define PSVR_DP_NUM_KINDS 12
+#define PSVR_DP_NUM_KINDS 13
 // kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM),
 // 11 = extd2_tiny_kernel (one thread per alignment; *need = 512 x anti-diagonals, which bins the problems by size),
 // 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
@@ -100,6 +120,12 @@ __host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
 	if (tiny_ok && qlen <= PSVR_DP_TINY_MAX && tlen <= PSVR_DP_TINY_MAX) { *need = (qlen + tlen - 1) * 512; return PSVR_DP_KIND_TINY; }
+	// one thread per alignment, 16-column strips in registers: whenever the band never clips the matrix (the lean regime).
+	// The size class is the number of strips (1..13), expressed through `need` as that class's byte threshold.
+	if (tiny_ok && dp_band_never_binds(qlen, tlen, w < 0 ? (qlen > tlen ? qlen : tlen) : w) && tlen <= PSVR_DP_STRIP * PSVR_DP_NUM_LDS_CLASSES) {
+		*need = dp_lds_class_bytes((tlen + PSVR_DP_STRIP - 1) / PSVR_DP_STRIP - 1);
+		return PSVR_DP_KIND_STRIP;
+	}
 	int T = (tlen + 15) / 16 * 16;
 	long long n = dp_reg_lds_need(qlen, tlen, w);
 	if (fast_ok && T <= 320) {

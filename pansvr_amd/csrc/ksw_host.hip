@@ -78,8 +78,8 @@ struct psvr_dp_plan {
 	int64_t n = 0;
 	DpParams P;
 	std::vector<Launch> launches;
-	DevBuf d_idx, d_poff, d_qlen, d_tlen;
-	int64_t pslab_bytes = 0;
+	DevBuf d_idx, d_poff, d_qlen, d_tlen, d_wstop;
+	int64_t pslab_bytes = 0, ws_bytes = 0;    // direction-byte slab, then (256-aligned) the strip kernel's scratch
 	std::string desc;
 };
 
@@ -121,7 +121,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 		int need = 0;
 		int kind = dp_classify(ql, tl, par->w, fast_ok, variant, pl->P.skip != 0, &need, dp_tiny_ok(pl->P, fast_ok));
 		if (kind < 0) { delete pl; return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld needs %d B of LDS", (long long)i, need); }
-		if ((kind == 0 || (kind > 5 && kind != PSVR_DP_KIND_TINY)) && ql > 0 && tl > 0) {
+		if ((kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) && ql > 0 && tl > 0) {
 			poff[i] = pslab;
 			pslab += (dp_p_bytes(ql, tl, par->w) + 255) & ~(int64_t)255;
 		}
@@ -132,13 +132,19 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	std::vector<int32_t> idx;
 	idx.reserve(n);
 	// general kernel first, then the HBM-direction-byte kernels, then the LDS ones; large LDS classes first
-	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
+	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 12, 11};
 	for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 		for (int cls = kNumLdsClasses - 1; cls >= 0; --cls) {
 			auto &b = bucket[kind_order[ko] * kNumLdsClasses + cls];
 			if (b.empty()) continue;
 			Launch L{kind_order[ko], kLdsClasses[cls], (int64_t)idx.size(), (int64_t)b.size()};
 			pl->launches.push_back(L);
+			if (L.kind == PSVR_DP_KIND_STRIP) {      // every wavefront bump-allocates its scratch; bound by the class's longest query
+				int qmax = 0;
+				for (int32_t i : b) qmax = std::max(qmax, qlen[i]);
+				const int lanes = dp_team_lanes(cls + 1);
+				pl->ws_bytes += (int64_t)(((uint64_t)b.size() * lanes + 63) / 64 * dp_team_ws_bytes(qmax, cls + 1, lanes));
+			}
 			idx.insert(idx.end(), b.begin(), b.end());
 			char buf[160];
 			snprintf(buf, sizeof buf, "%s[lds=%d] x%lld; ", dp_kind_name(L.kind, variant), L.lds_bytes, (long long)L.count);
@@ -149,6 +155,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	PSVR_HIP(pl->d_poff.alloc(n * 8));
 	PSVR_HIP(pl->d_qlen.alloc(n * 4));
 	PSVR_HIP(pl->d_tlen.alloc(n * 4));
+	PSVR_HIP(pl->d_wstop.alloc(8));
 	if (n) {
 		PSVR_HIP(hipMemcpy(pl->d_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
 		PSVR_HIP(hipMemcpy(pl->d_poff.p, poff.data(), n * 8, hipMemcpyHostToDevice));
@@ -160,7 +167,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	return PSVR_OK;
 }
 
-extern "C" int64_t psvr_dp_plan_workspace_bytes(const psvr_dp_plan_t *pl) { return pl ? pl->pslab_bytes + 256 : 0; }
+extern "C" int64_t psvr_dp_plan_workspace_bytes(const psvr_dp_plan_t *pl) { return pl ? ((pl->pslab_bytes + 255) & ~(int64_t)255) + pl->ws_bytes + 256 : 0; }
 
 extern "C" int psvr_dp_plan_describe(const psvr_dp_plan_t *pl, char *buf, size_t buflen)
 {
@@ -177,7 +184,7 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 {
 	if (!pl) return set_error(PSVR_ERR_ARG, "psvr_dp_plan_launch: null plan");
 	if (pl->n == 0) return PSVR_OK;
-	if (!d_qseq || !d_q_off || !d_tseq || !d_t_off || !d_ez || !d_cigar || (pl->pslab_bytes && !d_work))
+	if (!d_qseq || !d_q_off || !d_tseq || !d_t_off || !d_ez || !d_cigar || ((pl->pslab_bytes || pl->ws_bytes) && !d_work))
 		return set_error(PSVR_ERR_ARG, "psvr_dp_plan_launch: null device pointer");
 	hipStream_t stream = (hipStream_t)stream_;
 	DpBatch B;
@@ -185,11 +192,18 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 	B.tseq = d_tseq, B.t_off = d_t_off, B.tlen = pl->d_tlen.as<int32_t>();
 	B.ez = d_ez, B.cigar = d_cigar;
 	B.pslab = (uint8_t *)d_work, B.p_off = pl->d_poff.as<int64_t>(), B.p_unit_shift = 0;
+	B.ws = (uint8_t *)d_work + ((pl->pslab_bytes + 255) & ~(int64_t)255), B.ws_top = pl->d_wstop.as<unsigned long long>(), B.ws_cap = (unsigned long long)pl->ws_bytes;
+	if (pl->ws_bytes) PSVR_HIP(hipMemsetAsync(pl->d_wstop.p, 0, 8, stream));
+	TeamLaunch team;
 	for (const Launch &L : pl->launches) {
+		if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds_bytes) + 1, L.first, L.count); continue; }
 		B.idx = pl->d_idx.as<int32_t>() + L.first;
 		dp_launch_kind(L.kind, pl->variant, (unsigned)L.count, L.lds_bytes, stream, B, pl->P);
 		PSVR_HIP(hipGetLastError());
 	}
+	B.idx = pl->d_idx.as<int32_t>();
+	team.launch(stream, B, pl->P);
+	PSVR_HIP(hipGetLastError());
 	return PSVR_OK;
 }
 

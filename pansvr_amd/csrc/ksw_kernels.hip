@@ -172,7 +172,7 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 	}
 	__builtin_amdgcn_wave_barrier();
 	int e_max = 0, e_max_t = -1, e_max_q = -1, e_mqe = PSVR_KSW_NEG_INF, e_mqe_t = -1, e_mte = PSVR_KSW_NEG_INF, e_mte_q = -1;
-	int e_score = PSVR_KSW_NEG_INF, e_zd = 0;
+	int e_score = PSVR_KSW_NEG_INF, e_zd = 0, last_H = PSVR_KSW_NEG_INF;
 	for (int r = 0; r < n_rows; ++r) {
 		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
 		int ur = s8(-P.e2);                // v of column -1 (:142-152); only the first long_thres + 1 diagonals differ
@@ -262,7 +262,7 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 			for (int c = 0; c < K; ++c)
 				if ((en0 >> 6) == c) H_en0 = __builtin_amdgcn_readlane(H[c], en0 & 63);
 			if (H_en0 > e_mte) e_mte = H_en0, e_mte_q = r - (((en0 + 16) & ~15) - 1);
-			if (r == n_rows - 1) e_score = H_en0;
+			if (r == n_rows - 1) last_H = H_en0;
 		}
 		if (r - st0 == qlen - 1) {
 			int H_st0 = 0;
@@ -279,6 +279,7 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 			const int l = tl > ql ? tl - ql : ql - tl;
 			if (P.zdrop >= 0 && e_max - max_H > P.zdrop + l * P.e2) { e_zd = 1; break; }
 		}
+		if (r == n_rows - 1) e_score = last_H;             // only when the last diagonal did not z-drop (:350-351 come after the check)
 	}
 	ez_out.max = e_max, ez_out.max_t = e_max_t, ez_out.max_q = e_max_q;
 	ez_out.mqe = e_mqe, ez_out.mqe_t = e_mqe_t, ez_out.mte = e_mte, ez_out.mte_q = e_mte_q;
@@ -472,6 +473,208 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 	}
 	write_ez(out, ez, n_cigar);
 }
+
+// ------------------------------------------------------------------------------------------
+// lean regime, any size: a TEAM of 4 or 8 lanes per alignment, 4 target columns per lane in registers
+// ------------------------------------------------------------------------------------------
+// A wavefront per alignment keeps ~40 of 64 lanes busy and pays ~200 instructions of per-diagonal bookkeeping.  Here a
+// wavefront carries 16 (or 8) alignments; each is swept in strips of 16 (32) target columns, every lane of the team holding
+// the state of 4 columns (u,v,x,y,x2,y2,H) in registers with static indices.  A strip is swept anti-diagonal by anti-diagonal
+// exactly like dp_lean_loop sweeps its lanes: a column reads the old v/x/x2/H of the column to its left, so a lane visits
+// its columns from right to left and takes the neighbour lane's last column through one DPP row_shr:1 per value at the
+// start of the step.  What crosses a strip boundary -- v,x,x2,H of the strip's last column on every anti-diagonal -- goes
+// through a per-alignment array E[r] in scratch memory, ping-ponged between strips and read one step ahead.  The
+// per-diagonal results the z-drop / end-score rules need (the maximum with the reference's tie order, H at the band ends)
+// are folded into D[r], D2[r], D3[r] as the strips pass and evaluated in anti-diagonal order afterwards; diagonals past a
+// z-drop are computed but never looked at.  Direction bytes: one dword per lane and step.  Scratch is laid out
+// [index][lane or team] so a wavefront touches consecutive addresses; it bump-allocates it (sized by the longest query among
+// its alignments, which the planner keeps similar by binning on the strip count).  ~85 vector instructions per cell and
+// lane, i.e. ~1.5 wavefront instructions per cell instead of ~7.
+template <int LANES>
+__global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
+{
+	constexpr int SW = 4 * LANES, PB = 64 / LANES;                   // strip width, alignments per wavefront
+	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
+	int cls = 0;
+	while (cls + 1 < T.n_classes && (int)blockIdx.x >= T.first_block[cls + 1]) ++cls;
+	const int n_strips16 = T.n_strips16[cls];
+	const long long slot = (long long)((int)blockIdx.x - T.first_block[cls]) * PB + team;
+	const bool live = slot < T.count[cls];
+	int pid = 0, qlen = 0, tlen = 0;
+	if (live) pid = B.idx[T.first_slot[cls] + slot], qlen = B.qlen[pid], tlen = B.tlen[pid];
+	const int n_strips = (n_strips16 * 16 + SW - 1) / SW;
+	const int qmax = wave_max_i32(qlen > 0 ? qlen : 0);
+	const int R = qmax + SW - 1, NR = qmax + SW * n_strips + 1;
+	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES);
+	unsigned long long base = 0;
+	if (lane == 0) base = atomicAdd(B.ws_top, need);
+	base = (unsigned long long)uni64((long long)base);
+	psvr_extz_t *out = B.ez + pid;
+	EzAcc ez;
+	ez.reset();
+	const bool bad_shape = qlen <= 0 || tlen <= 0 || (tlen + SW - 1) / SW > n_strips;
+	if (!live) return;
+	if (P.skip || bad_shape || base + need > B.ws_cap) { if (ql == 0) write_ez(out, ez, 0); return; }
+	uint8_t *w0 = B.ws + base;
+	const size_t offE = (size_t)256 * n_strips * R;
+	uint32_t *PD = (uint32_t *)w0 + lane;                             // strip s, step k at [(s * R + k) * 64]
+	uint2 *E[2] = {(uint2 *)(w0 + offE) + team, (uint2 *)(w0 + offE + (size_t)8 * PB * NR) + team};   // diagonal r at [r * PB]
+	int *D = (int *)(w0 + offE + (size_t)16 * PB * NR) + team, *D2 = D + (size_t)PB * NR, *D3 = D2 + (size_t)PB * NR;
+	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
+	const int n_rows = qlen + tlen - 1;
+	auto ur_of = [&](int r) { return r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2); };
+	const int ns = (tlen + SW - 1) / SW;
+	for (int s = 0; s < ns; ++s) {
+		const int c0 = SW * s;
+		const int ncols = tlen - c0 < SW ? tlen - c0 : SW;
+		const int jl = tlen - 1 - c0;                                   // the last target column, if it is in this strip (else >= SW)
+		const int jb = 4 * ql;                                          // this lane's first column of the strip
+		int U[4], V[4], X[4], Y[4], X2[4], Y2[4], H[4];
+		unsigned TW = 0;                                              // target codes of this lane's columns, one nibble each
+#pragma unroll
+		for (int jj = 0; jj < 4; ++jj) {
+			U[jj] = ur_of(c0 + jb + jj);                                // u/y/y2 of the first cell of a column (:153-156)
+			V[jj] = X[jj] = Y[jj] = neg_qe, X2[jj] = Y2[jj] = neg_qe2;
+			H[jj] = -P.qe_pre;
+			TW |= (unsigned)(jb + jj < ncols ? (target[c0 + jb + jj] & 15) : 0) << (4 * jj);
+		}
+		const uint2 *Ein = E[(s + 1) & 1];
+		uint2 *Eout = E[s & 1];
+		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
+		// loaded one step ahead, so the loads have a whole step to arrive
+		uint2 e_prev = make_uint2(0u, 0u);
+		int d_cur = 0;
+		if (s > 0) {
+			e_prev = Ein[(size_t)(c0 - 1) * PB];
+			if (0 <= qlen - 2) d_cur = D[(size_t)c0 * PB];
+		}
+		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? (query[0 - jb] & 15u) : 0u;   // query[k - jb] for k = 0
+		unsigned W = 0;                                               // query window: nibble jj = query[k - jb - jj]
+		const int ksteps = qlen + ncols - 1;
+		for (int k = 0; k < ksteps; ++k) {
+			const int r = c0 + k;
+			const unsigned q_nxt = (unsigned)(k + 1 - jb) < (unsigned)qlen ? (query[k + 1 - jb] & 15u) : 0u;
+			W = (W << 4) | q_cur;
+			const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
+			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			const int sel_t = en0 > 0 ? en0 : -1;
+			// the column left of this lane's first one: the neighbour lane's last column (old values), or for the team's first lane
+			// column -1 (:142-152) / the previous strip's last column on diagonal r-1
+			int vl = __builtin_amdgcn_update_dpp(0, V[3], 0x111, 0xf, 0xf, false), xl = __builtin_amdgcn_update_dpp(0, X[3], 0x111, 0xf, 0xf, false);
+			int x2l = __builtin_amdgcn_update_dpp(0, X2[3], 0x111, 0xf, 0xf, false), hl = __builtin_amdgcn_update_dpp(0, H[3], 0x111, 0xf, 0xf, false);
+			uint2 e_next = make_uint2(0u, 0u);
+			int d_nxt = 0;
+			const int dprev = d_cur;
+			if (s > 0) {
+				e_next = Ein[(size_t)r * PB];
+				if (k + 1 <= qlen - 2) d_nxt = D[(size_t)(r + 1) * PB];      // earlier strips reached that diagonal (their last is c0 + qlen - 2)
+			}
+			if (ql == 0) {
+				if (s > 0) vl = s8(e_prev.x), xl = s8(e_prev.x >> 8), x2l = s8(e_prev.x >> 16), hl = (int)e_prev.y;
+				else vl = ur_of(r), xl = neg_qe, x2l = neg_qe2, hl = 0;
+			}
+			const int jq = k - (qlen - 1);                               // column of this step's cell in the last query row
+			unsigned best = 0;
+			int h_en0 = 0, h_st0 = 0;
+			bool has_en0 = false, has_st0 = false;
+			uint32_t dw = 0;
+#pragma unroll
+			for (int jj = 3; jj >= 0; --jj) {
+				const int j = jb + jj, t = c0 + j, i = k - j;
+				const bool act = ((unsigned)i < (unsigned)qlen) & (j < ncols);
+				const int xt1 = jj ? X[jj ? jj - 1 : 0] : xl, vt1 = jj ? V[jj ? jj - 1 : 0] : vl, x2t1 = jj ? X2[jj ? jj - 1 : 0] : x2l, hleft = jj ? H[jj ? jj - 1 : 0] : hl;
+				const int qc = (int)(W >> (4 * jj)) & 15, tc = (int)(TW >> (4 * jj)) & 15;
+				int sc = tc == qc ? P.sc_mch : P.sc_mis;
+				sc = ((tc == P.m1) | (qc == P.m1)) ? P.sc_N : sc;
+				const int ut = U[jj];
+				int za = xt1 + vt1, zb = Y[jj] + ut, za2 = x2t1 + vt1, zb2 = Y2[jj] + ut;
+				int z = max(max(sc, za), zb);
+				z = max(max(z, za2), zb2);
+				int d = 4;                                               // first of {sc,a,b,a2,b2} that reaches the maximum (:176-213)
+				d = za2 == z ? 3 : d;
+				d = zb == z ? 2 : d;
+				d = za == z ? 1 : d;
+				d = sc == z ? 0 : d;
+				z = min(z, P.sc_mch);
+				const int un = z - vt1, vn = z - ut;
+				const int zq = z - P.q, zq2 = z - P.q2;
+				za -= zq, zb -= zq, za2 -= zq2, zb2 -= zq2;
+				d |= (za > 0 ? 0x08 : 0) | (zb > 0 ? 0x10 : 0) | (za2 > 0 ? 0x20 : 0) | (zb2 > 0 ? 0x40 : 0);
+				const int hn = t == sel_t ? hleft + un : H[jj] + vn;     // exact H (:316-351)
+				const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
+				                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
+				const unsigned key = (unsigned)(hn + 0x4000) << 16 | (0x7fffu - rank);   // larger H first, then the reference's order (:322-349)
+				if (act) {
+					U[jj] = un, V[jj] = vn;
+					X[jj] = max(za, 0) - qe8, Y[jj] = max(zb, 0) - qe8;
+					X2[jj] = max(za2, 0) - qe28, Y2[jj] = max(zb2, 0) - qe28;
+					H[jj] = hn;
+					best = max(best, key);
+					dw |= (uint32_t)d << (8 * jj);
+					if (j == jl) h_en0 = hn, has_en0 = true;
+					if (j == jq) h_st0 = hn, has_st0 = true;
+				}
+			}
+			// team maximum (butterfly inside the quad, then across the two quads of an 8-lane team)
+			best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0xB1, 0xf, 0xf, false));
+			best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x4E, 0xf, 0xf, false));
+			if (LANES == 8) best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x141, 0xf, 0xf, false));
+			if (with_cigar) PD[(size_t)(s * R + k) * 64] = dw;
+			if (ql == LANES - 1 && s + 1 < ns) Eout[(size_t)r * PB] = make_uint2((uint32_t)(V[3] & 0xff) | (uint32_t)(X[3] & 0xff) << 8 | (uint32_t)(X2[3] & 0xff) << 16, (uint32_t)H[3]);
+			if (ql == 0) D[(size_t)r * PB] = (int)max(best, (unsigned)dprev);
+			if (has_en0) D2[(size_t)r * PB] = h_en0;                      // cell (r - (tlen-1), tlen-1)
+			if (has_st0) D3[(size_t)r * PB] = h_st0;                      // cell (qlen-1, r - qlen + 1)
+			e_prev = e_next, d_cur = d_nxt, q_cur = q_nxt;
+		}
+	}
+	if (ql != 0) return;
+	__threadfence_block();                                            // the other lanes' D2/D3 stores
+	// the per-diagonal rules, in anti-diagonal order (ksw2_extd2_sse.c:316-351, ksw_apply_zdrop)
+	for (int r = 0; r < n_rows; ++r) {
+		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
+		const unsigned key = (unsigned)D[(size_t)r * PB];
+		const int max_H = (int)(key >> 16) - 0x4000;
+		const unsigned rank = 0x7fffu - (key & 0xffffu);
+		const int max_t = rank == 0 ? en0 : st0 + (int)((rank - 1u) & 4095u);
+		int H_en0 = 0;
+		if (en0 == tlen - 1) {
+			H_en0 = D2[(size_t)r * PB];
+			if (H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
+		}
+		if (r - st0 == qlen - 1) {
+			const int H_st0 = D3[(size_t)r * PB];
+			if (H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
+		}
+		if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) break;
+		if (r == n_rows - 1) ez.score = H_en0;                           // en0 == tlen - 1 on the last diagonal
+	}
+	int n_cigar = 0;
+	if (with_cigar) {
+		int i0 = -1, j0 = -1;
+		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
+		else if (!ez.zdropped && (P.flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
+		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
+		if (i0 >= 0 && j0 >= 0) {
+			const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
+			const uint8_t *pb = (const uint8_t *)((uint32_t *)w0 + team * LANES);   // the team's 4 * LANES direction bytes of a step are contiguous
+			uint32_t *stage = (uint32_t *)E[0];                        // <= qlen + tlen ops; the strip-boundary arrays are dead now
+			n_cigar = traceback(i0, j0, qlen, tlen, w,
+				[&](int r, int k) {                                     // k counts from the 16-rounded band start of row r, as in the reference
+					const int t = k + (max(0, r - qlen + 1) & ~15), s = t / SW;
+					return (int)pb[(size_t)(s * R + (r - SW * s)) * 256 + (t - SW * s)];
+				},
+				[&](int k, uint32_t word) { stage[(size_t)k * PB * 2] = word; });
+			uint32_t *dst = B.cigar + out->cigar_off;
+			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
+			for (int m = 0; m < n_cigar; ++m) dst[m] = stage[(size_t)(rev ? m : n_cigar - 1 - m) * PB * 2];
+		}
+	}
+	write_ez(out, ez, n_cigar);
+}
+template __global__ void extd2_team_kernel<4>(DpBatch, DpParams, TeamPlan);
 
 // ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image

@@ -9,7 +9,7 @@ inline const char *dp_kind_name(int kind, int variant)
 {
 	static const char *n[PSVR_DP_NUM_KINDS] = {"extd2_lds_kernel", "extd2_reg_kernel<1,lds>", "extd2_reg_kernel<2,lds>", "extd2_reg_kernel<3,lds>", "extd2_reg_kernel<4,lds>",
 	                                           "extd2_reg_kernel<5,lds>", "extd2_reg_kernel<1,hbm>", "extd2_reg_kernel<2,hbm>", "extd2_reg_kernel<3,hbm>", "extd2_reg_kernel<4,hbm>",
-	                                           "extd2_reg_kernel<5,hbm>", "extd2_tiny_kernel"};
+	                                           "extd2_reg_kernel<5,hbm>", "extd2_tiny_kernel", "extd2_team_kernel"};
 	if (kind == 0 && variant == 1) return "extz2_lds_kernel";
 	return n[kind];
 }
@@ -41,6 +41,29 @@ inline void dp_launch_kind(int kind, int variant, unsigned count, int lds, hipSt
 		if (variant == 0) hipLaunchKernelGGL(extd2_lds_kernel<0>, g, b, lds, stream, B, P);
 		else hipLaunchKernelGGL(extd2_lds_kernel<1>, g, b, lds, stream, B, P);
 	}
+}
+
+// the team kernel: every class in one launch (largest classes first, their wavefronts run longest)
+struct TeamLaunch {
+	TeamPlan T;
+	TeamLaunch() { T.n_classes = 0; T.first_block[0] = 0; }
+	void add(int n_strips16, long long first_slot, long long count)
+	{
+		const int c = T.n_classes++;
+		T.n_strips16[c] = n_strips16, T.first_slot[c] = first_slot, T.count[c] = count;
+		T.first_block[c + 1] = T.first_block[c] + (int)((count + 15) / 16);
+	}
+	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
+	{
+		if (T.n_classes) hipLaunchKernelGGL(extd2_team_kernel<4>, dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+	}
+};
+// the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
+inline int dp_class_of(int lds)
+{
+	int cls = 0;
+	while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < lds) ++cls;
+	return cls;
 }
 
 inline hipError_t dp_allow_big_lds()
