@@ -384,7 +384,9 @@ struct DpPlanDev {
 __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny_ok)
 {
 	__shared__ unsigned int lh[256];
+	__shared__ unsigned int lq[PSVR_DP_NUM_LDS_CLASSES];       // longest query per team-kernel class, aggregated per block
 	lh[threadIdx.x] = 0;
+	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES) lq[threadIdx.x] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < d.n) {
@@ -397,11 +399,12 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 		d.plen[i] = (kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
 		int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
 		d.bucket[i] = b;
-		if (kind == PSVR_DP_KIND_STRIP) atomicMax(d.hist + 512 + cls, (unsigned long long)x.qlen);
+		if (kind == PSVR_DP_KIND_STRIP) atomicMax(&lq[cls], (unsigned int)x.qlen);
 		atomicAdd(&lh[b], 1u);
 	}
 	__syncthreads();
 	if (lh[threadIdx.x]) atomicAdd(d.hist + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
+	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES && lq[threadIdx.x]) atomicMax(d.hist + 512 + threadIdx.x, (unsigned long long)lq[threadIdx.x]);
 }
 __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
 {
