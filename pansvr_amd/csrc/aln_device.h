@@ -40,7 +40,7 @@ static const int kLenKmer = 20, kSeedStep = 5, kUniPosNMax = 32;   // rr.hpp:26-
 static const int kMaxOut = 6;                                       // MAX_OUTPUT_NUMBER
 static const int kMaxReadLen = 1600;                                // MAX_READ_LEN, rr.hpp:322
 static const int kFwd = 1, kRev = 0;                                // clib/utils.h:72-73
-static const int kSegMax = 96;                                      // CIGAR pieces per candidate
+static const int kSegMax = 160;                                     // CIGAR pieces per candidate (a DP piece takes three slots until walk_read has numbered it)
 static const int kCigMax = 256;                                     // merged CIGAR ops per candidate
 static const int kMemSlot = 32;                                     // MEMs per read-strand before spilling to the bump region
 
@@ -106,7 +106,7 @@ struct ChainCand {               // one sort_output() pick (rr.cpp:212-293)
 };
 
 struct Seg {                     // one piece of KSW_ALN_handler::cigar_tmp, in push order
-	int32_t kind;                // 0 literal op, 1 DP result
+	int32_t kind;                // 0 literal op, 1 DP result, 2 payload of the DP piece in front of it (skipped by assemble_candidate)
 	int32_t a, b;                // literal: type,size ; DP: problem id, emit order (0 forward i=0.., 1 reverse)
 };
 
@@ -819,6 +819,7 @@ struct WalkState {
 	int32_t read_score; uint32_t total_q_len;
 	bool is_simple;
 	Seg *seg; int n_seg; int bad; int seg_cap;
+	int n_dp;                    // DP pieces queued by this read so far (local numbering until walk_read assigns the ids)
 };
 
 PSVR_HD void seg_lit(WalkState &w, int type, int size)
@@ -892,12 +893,14 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 		if (type != 2) w.read_score += PSVR_KSW_NEG_INF;                  // ez.mqe after ksw_reset_extz
 		return;
 	}
-	long long id = arena_alloc(c.dp, 1);
-	if (id < 0 || w.n_seg >= w.seg_cap) { w.bad = 1; return; }
-	DpDesc &d = c.dp.base[id];
-	d.read = (int32_t)w.read, d.strand = w.strand, d.q_st = read_st, d.qlen = (int32_t)qlen, d.ref_st = (uint32_t)ref_st, d.tlen = (int32_t)tlen, d.type = type, d.pad = 0;
-	Seg &s = w.seg[w.n_seg++];
-	s.kind = 1, s.a = (int32_t)id, s.b = type;
+	// the DP problem is queued here but numbered later: walk_read reserves the ids of all its read's problems with one
+	// allocation (the queue's counter is the hot spot of this stage).  Until then the coordinates ride in two payload slots.
+	if (w.n_seg + 3 > w.seg_cap) { w.bad = 1; return; }
+	Seg *s = w.seg + w.n_seg;
+	s[0].kind = 1, s[0].a = w.n_dp++, s[0].b = type;
+	s[1].kind = 2, s[1].a = read_st, s[1].b = (int32_t)qlen;
+	s[2].kind = 2, s[2].a = ref_st, s[2].b = (int32_t)tlen;
+	w.n_seg += 3;
 	stat_add(c, ST_DP, 1);
 	stat_add(c, ST_CELLS, (unsigned long long)qlen * tlen);
 }
@@ -908,12 +911,13 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 PSVR_HD int walk_seg_cap(const Ctx &c, long long read, int k)
 {
 	const int is_rev = c.ccand[read * 12 + k].direction == kRev;
-	const int cap = 3 * (int)c.strand[read * 2 + is_rev].us_n + 4;
+	const int n = (int)c.strand[read * 2 + is_rev].us_n;
+	const int cap = 3 * n + 4 + 2 * (n + 1);              // + two payload slots per DP piece (at most one per node + the left extension)
 	return cap > kSegMax ? kSegMax : cap;
 }
 
 // candidate k of `read`; its CandWork slot and its slice of the piece arena were reserved by walk_read
-PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap)
+PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap, int dp_first)
 {
 	const ChainCand &cc = c.ccand[read * 12 + k];
 	const int is_rev = cc.direction == kRev;
@@ -924,7 +928,7 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k, long lo
 	WalkState w;
 	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
 	w.read_w = c.rb + (read * 2 + is_rev) * (long long)c.wmax, w.packed_ok = c.has_n4[read] == 0;
-	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap;
+	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap, w.n_dp = dp_first;
 	const int BIG = 0x7fffffff;
 	int aln_read_begin = read_l, aln_read_end = read_l, aln_ref_begin = BIG, aln_ref_end = BIG;
 	int last_aln_begin = read_l, last_ref_begin = BIG, unitig_mis = 0;
@@ -975,6 +979,7 @@ PSVR_HDN inline void walk_candidate(const Ctx &c, long long read, int k, long lo
 	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = rba, cw.bad = w.bad, cw.seg_off = so;
 	if (w.bad) *c.err = 10 + w.bad;
 	stat_add(c, ST_CAND, 1);
+	return w.n_dp;
 }
 
 // all candidates of one read.  The arenas are bump allocators on one counter each: reserving per read instead of per
@@ -989,10 +994,30 @@ PSVR_HDN inline void walk_read(const Ctx &c, long long read)
 	const long long cw0 = arena_alloc(c.cw, (unsigned long long)nc);
 	long long so = arena_alloc(c.seg, (unsigned long long)total);
 	if (cw0 < 0 || so < 0) return;
+	int n_dp = 0;
+	const long long so0 = so;
 	for (int k = 0; k < nc; ++k) {
 		const int cap = walk_seg_cap(c, read, k);
-		walk_candidate(c, read, k, cw0 + k, so, cap);
+		n_dp = walk_candidate(c, read, k, cw0 + k, so, cap, n_dp);
 		so += cap;
+	}
+	if (n_dp == 0) return;
+	// number the queued DP problems: one reservation for the whole read, then their descriptors
+	const long long id0 = arena_alloc(c.dp, (unsigned long long)n_dp);
+	so = so0;
+	for (int k = 0; k < nc; ++k) {
+		const CandWork &cw = c.cw.base[cw0 + k];
+		Seg *seg = c.seg.base + so;
+		for (int i = 0; i < cw.n_seg; ++i) {
+			if (seg[i].kind != 1) continue;
+			if (id0 < 0) { c.cw.base[cw0 + k].bad = 1; *c.err = 11; seg[i].a = 0; continue; }
+			DpDesc &d = c.dp.base[id0 + seg[i].a];
+			const ChainCand &cc = c.ccand[read * 12 + k];
+			d.read = (int32_t)read, d.strand = cc.direction == kRev, d.q_st = seg[i + 1].a, d.qlen = seg[i + 1].b, d.ref_st = (uint32_t)seg[i + 2].a, d.tlen = seg[i + 2].b;
+			d.type = seg[i].b, d.pad = 0;
+			seg[i].a = (int32_t)(id0 + seg[i].a);
+		}
+		so += walk_seg_cap(c, read, k);
 	}
 }
 
@@ -1027,6 +1052,7 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	// cigar_tmp in push order is seg[0..n_seg) with DP pieces expanded; reverseGIGAR walks it from the back
 	for (int si = cw.n_seg - 1; si >= 0; --si) {
 		const Seg &s = seg[si];
+		if (s.kind == 2) continue;
 		int cnt = 1;
 		const psvr_extz_t *ez = nullptr;
 		const uint32_t *cg = nullptr;
