@@ -193,7 +193,8 @@ def main():
         traffic = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            kd = pj["kernels"].get(dom.replace(",hbm>", ", true>").replace(",lds>", ", false>"))
+            want = dom.replace(",hbm>", ", true>").replace(",lds>", ", false>")
+            kd = pj["kernels"].get(want) or next((v for k, v in pj["kernels"].items() if k.split("<")[0] == want), None)
             if kd and pj.get("pairs_per_gpu") == args.pairs:
                 traffic = int((kd["fetch_KiB_per_step"] + kd["write_KiB_per_step"]) * 1024)
         except Exception:
