@@ -377,15 +377,23 @@ struct DpPlanDev {
 	int32_t *qlen, *tlen; long long *q_off, *t_off, *p_off;
 	int32_t *plen;                 // padded direction-byte bytes for general-kernel problems (0 otherwise), as int32 units of 256 B
 	int32_t *bucket;               // bucket id per problem
-	unsigned long long *hist;      // [256] counts, [256] cursors, then [16] the longest query per strip class + [1] the scratch top
+	unsigned long long *hist;      // [512] counts, [512] cursors, then [16] the longest query per team-kernel class + [1] the scratch top
 	int32_t *idx;
 	psvr_extz_t *ez;
 };
+// bucket ids: kind * 13 + class for the wavefront / tiny kernels (< 256); the team kernel's problems are additionally binned by
+// query length inside their class (256 + class * 16 + (qlen - 1) / 16), so that the 16 alignments of a wavefront have similar
+// numbers of steps per strip
+__device__ __forceinline__ int dp_bucket_of(int kind, int cls, int qlen)
+{
+	if (kind == PSVR_DP_KIND_STRIP) { int qb = (qlen - 1) >> 4; return 256 + cls * 16 + (qb > 15 ? 15 : qb); }
+	return (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
+}
 __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny_ok)
 {
-	__shared__ unsigned int lh[256];
+	__shared__ unsigned int lh[512];
 	__shared__ unsigned int lq[PSVR_DP_NUM_LDS_CLASSES];       // longest query per team-kernel class, aggregated per block
-	lh[threadIdx.x] = 0;
+	lh[threadIdx.x] = 0, lh[threadIdx.x + 256] = 0;
 	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES) lq[threadIdx.x] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -397,27 +405,27 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 		int cls = 0;
 		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
 		d.plen[i] = (kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
-		int b = (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
+		const int b = dp_bucket_of(kind, cls, x.qlen);
 		d.bucket[i] = b;
 		if (kind == PSVR_DP_KIND_STRIP) atomicMax(&lq[cls], (unsigned int)x.qlen);
 		atomicAdd(&lh[b], 1u);
 	}
 	__syncthreads();
-	if (lh[threadIdx.x]) atomicAdd(d.hist + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
-	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES && lq[threadIdx.x]) atomicMax(d.hist + 512 + threadIdx.x, (unsigned long long)lq[threadIdx.x]);
+	for (int t = threadIdx.x; t < 512; t += 256) if (lh[t]) atomicAdd(d.hist + t, (unsigned long long)lh[t]);
+	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES && lq[threadIdx.x]) atomicMax(d.hist + 1024 + threadIdx.x, (unsigned long long)lq[threadIdx.x]);
 }
 __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
 {
-	__shared__ unsigned int lh[256];
-	__shared__ unsigned long long lb[256];
-	lh[threadIdx.x] = 0;
+	__shared__ unsigned int lh[512];
+	__shared__ unsigned long long lb[512];
+	lh[threadIdx.x] = 0, lh[threadIdx.x + 256] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	int b = 0;
 	unsigned int me = 0;
 	if (i < d.n) { b = d.bucket[i]; me = atomicAdd(&lh[b], 1u); }
 	__syncthreads();
-	if (lh[threadIdx.x]) lb[threadIdx.x] = atomicAdd(d.hist + 256 + threadIdx.x, (unsigned long long)lh[threadIdx.x]);
+	for (int t = threadIdx.x; t < 512; t += 256) if (lh[t]) lb[t] = atomicAdd(d.hist + 512 + t, (unsigned long long)lh[t]);
 	__syncthreads();
 	if (i < d.n) {
 		d.idx[bucket_start[b] + lb[b] + me] = (int32_t)i;
@@ -620,8 +628,8 @@ struct GpuBE {
 		// upper bounds for the sequence buffers: every problem has qlen, tlen < 1600; size from the actual lens
 		if (!core.ensure_dp(n, 0, 0, 0)) return set_error(PSVR_ERR_NOMEM, "DP buffers");
 		PSVR_HIP(plan_bucket.ensure(n * 4)); PSVR_HIP(plan_idx.ensure(n * 4)); PSVR_HIP(plan_plen.ensure((n + 1) * 4)); PSVR_HIP(plan_poff.ensure((n + 1) * 8));
-		PSVR_HIP(plan_hist.ensure(544 * 8)); PSVR_HIP(plan_bstart.ensure(256 * 8));
-		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 544 * 8, stream));
+		PSVR_HIP(plan_hist.ensure(1056 * 8)); PSVR_HIP(plan_bstart.ensure(512 * 8));
+		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 1056 * 8, stream));
 		DpPlanDev pd;
 		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
@@ -632,10 +640,10 @@ struct GpuBE {
 		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
 		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
 		PSVR_HIP(hipGetLastError());
-		unsigned long long hist[256], qmax[16];
+		unsigned long long hist[512], qmax[16];
 		long long tot[3];
-		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 256 * 8, hipMemcpyDeviceToHost, stream));
-		PSVR_HIP(hipMemcpyAsync(qmax, (char *)plan_hist.p + 512 * 8, 16 * 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 512 * 8, hipMemcpyDeviceToHost, stream));
+		PSVR_HIP(hipMemcpyAsync(qmax, (char *)plan_hist.p + 1024 * 8, 16 * 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[0], d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[1], d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
 		PSVR_HIP(hipMemcpyAsync(&tot[2], pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
@@ -644,24 +652,30 @@ struct GpuBE {
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
 		// scratch of the strip kernel: every wavefront bump-allocates what its 64 problems need; bound per class by its longest query
-		unsigned long long ws_bytes = 0;
+		unsigned long long ws_bytes = 0, team_cnt[PSVR_DP_NUM_LDS_CLASSES];
 		for (int cls = 0; cls < PSVR_DP_NUM_LDS_CLASSES; ++cls) {
-			const unsigned long long cnt = hist[PSVR_DP_KIND_STRIP * PSVR_DP_NUM_LDS_CLASSES + cls];
-			if (cnt) { const int lanes = dp_team_lanes(cls + 1); ws_bytes += (cnt * lanes + 63) / 64 * dp_team_ws_bytes((int)qmax[cls], cls + 1, lanes); }
+			team_cnt[cls] = 0;
+			for (int qb = 0; qb < 16; ++qb) team_cnt[cls] += hist[256 + cls * 16 + qb];
+			if (team_cnt[cls]) { const int lanes = dp_team_lanes(cls + 1); ws_bytes += (team_cnt[cls] * lanes + 63) / 64 * dp_team_ws_bytes((int)qmax[cls], cls + 1, lanes); }
 		}
 		PSVR_HIP(strip_ws.ensure((size_t)ws_bytes + 256));
-		long long bstart[256], acc = 0;
+		long long bstart[512], acc = 0;
 		memset(bstart, 0, sizeof bstart);
 		std::vector<Launch3> ls;
-		const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 12, 11};
-		for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
+		const int kind_order[PSVR_DP_NUM_KINDS - 1] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
+		for (int ko = 0; ko < PSVR_DP_NUM_KINDS - 1; ++ko)
 			for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
 				int b = kind_order[ko] * PSVR_DP_NUM_LDS_CLASSES + cls;
 				bstart[b] = acc;
 				if (hist[b]) ls.push_back(Launch3{kind_order[ko], dp_lds_class_bytes(cls), acc, (long long)hist[b]});
 				acc += (long long)hist[b];
 			}
-		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 256 * 8, hipMemcpyHostToDevice, stream));
+		// the team kernel's classes, longest first; inside a class the query-length bins in descending order
+		for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
+			if (team_cnt[cls]) ls.push_back(Launch3{PSVR_DP_KIND_STRIP, dp_lds_class_bytes(cls), acc, (long long)team_cnt[cls]});
+			for (int qb = 15; qb >= 0; --qb) bstart[256 + cls * 16 + qb] = acc, acc += (long long)hist[256 + cls * 16 + qb];
+		}
+		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 512 * 8, hipMemcpyHostToDevice, stream));
 		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
 		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
 		t0("k_dp_fetch");
@@ -672,7 +686,7 @@ struct GpuBE {
 		B.qseq = d.qbuf, B.q_off = (const int64_t *)d.q_off, B.qlen = d.qlen;
 		B.tseq = d.tbuf, B.t_off = (const int64_t *)d.t_off, B.tlen = d.tlen;
 		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = (const int64_t *)plan_poff.p, B.p_unit_shift = 8;   // slab offsets in 256-byte units
-		B.ws = (uint8_t *)strip_ws.p, B.ws_top = plan_hist.as<unsigned long long>() + 528, B.ws_cap = ws_bytes;   // the top counter was zeroed with the histograms
+		B.ws = (uint8_t *)strip_ws.p, B.ws_top = plan_hist.as<unsigned long long>() + 1040, B.ws_cap = ws_bytes;   // the top counter was zeroed with the histograms
 		TeamLaunch team;
 		for (const Launch3 &L : ls) {
 			if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds) + 1, L.first, L.count); continue; }

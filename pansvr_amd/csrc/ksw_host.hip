@@ -137,6 +137,8 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 		for (int cls = kNumLdsClasses - 1; cls >= 0; --cls) {
 			auto &b = bucket[kind_order[ko] * kNumLdsClasses + cls];
 			if (b.empty()) continue;
+			// team kernel: alignments of similar query length share a wavefront (their strips take similar numbers of steps)
+			if (kind_order[ko] == PSVR_DP_KIND_STRIP) std::stable_sort(b.begin(), b.end(), [&](int32_t x, int32_t y) { return qlen[x] > qlen[y]; });
 			Launch L{kind_order[ko], kLdsClasses[cls], (int64_t)idx.size(), (int64_t)b.size()};
 			pl->launches.push_back(L);
 			if (L.kind == PSVR_DP_KIND_STRIP) {      // every wavefront bump-allocates its scratch; bound by the class's longest query
