@@ -687,6 +687,7 @@ struct GpuBE {
 		B.tseq = d.tbuf, B.t_off = (const int64_t *)d.t_off, B.tlen = d.tlen;
 		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = (const int64_t *)plan_poff.p, B.p_unit_shift = 8;   // slab offsets in 256-byte units
 		B.ws = (uint8_t *)strip_ws.p, B.ws_top = plan_hist.as<unsigned long long>() + 1040, B.ws_cap = ws_bytes;   // the top counter was zeroed with the histograms
+		B.err = c.err;
 		TeamLaunch team;
 		for (const Launch3 &L : ls) {
 			if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds) + 1, L.first, L.count); continue; }

@@ -3,18 +3,17 @@
 // Replaces ksw_extd2_sse / ksw_extz2_sse (reference: src/kswlib/ksw2_extd2_sse.c:26-396,
 // ksw2_extz2_sse.c:23-305) and ksw_backtrack_D / ksw_apply_zdrop (src/kswlib/ksw2.h:119-151,245-261).
 //
-// Design (MI355X-first, not a port of the SSE code):
-//   * one 64-lane wavefront owns one alignment; lane L of chunk c owns target column t = 64c + L
-//     for the whole run, so the eight per-column DP state values (u,v,x,y,x2,y2,s,H) never leave
-//     VGPRs;  the (r-1,t-1) neighbours arrive by a DPP wave_shr:1 with the inter-chunk carry fed
-//     through v_readlane;
-//   * chunks of one anti-diagonal are visited from high t to low t so the carry is still "old";
-//   * the 7-bit direction bytes of the band are staged in LDS (one row per anti-diagonal, the
-//     reference's n_col_*16 row pitch) and the traceback walks them from LDS;
-//   * the per-diagonal exact max / arg-max (with the reference's 4-lane tie-break order) is a
-//     two-pass DPP row_shr/row_bcast wave reduction, no LDS traffic;
-//   * the reference's 16-lane block rounding of [st,en] is kept bit-for-bit: lanes outside the band
-//     but inside the rounded block are computed and later read back exactly as the SSE code does.
+// Design (MI355X-first, not a port of the SSE code).  Four kernels share the recurrences; the planners route a problem by shape:
+//   * extd2_team_kernel<4>  -- the `aln` path's kernel: band never clips the matrix, values fit int8 (dp_band_never_binds &&
+//     nowrap_ok).  4 lanes per alignment, 16 alignments per wavefront, the matrix swept in strips of 16 target columns with
+//     the state of 4 columns per lane in registers; see the kernel for the strip boundary / per-diagonal bookkeeping.
+//   * extd2_tiny_kernel     -- same regime, qlen, tlen <= 16: one thread per alignment, state in LDS.
+//   * extd2_reg_kernel<K,PG> -- one 64-lane wavefront per alignment, lane L of chunk c owns target column t = 64c + L, the
+//     per-column state (u,v,x,y,x2,y2,s,H) in VGPRs, (r-1,t-1) neighbours by DPP wave_shr:1 with the inter-chunk carry
+//     through v_readlane, direction bytes in LDS or an HBM slab, exact max / arg-max by DPP reductions.  Its dp_main_loop
+//     keeps the reference's 16-lane block rounding of [st,en] bit for bit (lanes outside the band but inside the rounded
+//     block are computed and read back exactly as the SSE code does, 8-bit wrap included): needed when the band clips.
+//   * extd2_lds_kernel<VAR>  -- any shape and flag, and the single-affine extz2 variant: state in LDS in the reference's layout.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,7 +42,8 @@ struct DpBatch { // device pointers of one batch
 	int32_t p_unit_shift;
 	int32_t lds_per_wave;      // reg kernels: dynamic LDS bytes of one wavefront's problem
 	long long n;               // problems in this launch
-	uint8_t *ws; unsigned long long *ws_top; unsigned long long ws_cap;   // strip kernel: per-wavefront scratch, bump-allocated
+	uint8_t *ws; unsigned long long *ws_top; unsigned long long ws_cap;   // team kernel: per-wavefront scratch, bump-allocated
+	int *err;                  // set to 20 if that scratch runs out (cannot happen with the planners' bounds; never silent)
 };
 
 #define PSVR_DP_NUM_LDS_CLASSES 13

@@ -157,7 +157,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	PSVR_HIP(pl->d_poff.alloc(n * 8));
 	PSVR_HIP(pl->d_qlen.alloc(n * 4));
 	PSVR_HIP(pl->d_tlen.alloc(n * 4));
-	PSVR_HIP(pl->d_wstop.alloc(8));
+	PSVR_HIP(pl->d_wstop.alloc(16));      // scratch top (8 B) + error flag (4 B)
 	if (n) {
 		PSVR_HIP(hipMemcpy(pl->d_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
 		PSVR_HIP(hipMemcpy(pl->d_poff.p, poff.data(), n * 8, hipMemcpyHostToDevice));
@@ -195,7 +195,8 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 	B.ez = d_ez, B.cigar = d_cigar;
 	B.pslab = (uint8_t *)d_work, B.p_off = pl->d_poff.as<int64_t>(), B.p_unit_shift = 0;
 	B.ws = (uint8_t *)d_work + ((pl->pslab_bytes + 255) & ~(int64_t)255), B.ws_top = pl->d_wstop.as<unsigned long long>(), B.ws_cap = (unsigned long long)pl->ws_bytes;
-	if (pl->ws_bytes) PSVR_HIP(hipMemsetAsync(pl->d_wstop.p, 0, 8, stream));
+	B.err = (int *)(pl->d_wstop.as<unsigned long long>() + 1);
+	PSVR_HIP(hipMemsetAsync(pl->d_wstop.p, 0, 16, stream));
 	TeamLaunch team;
 	for (const Launch &L : pl->launches) {
 		if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds_bytes) + 1, L.first, L.count); continue; }
@@ -249,6 +250,11 @@ static int dp_batch_host(int variant, int device, int64_t n,
 	                         dez.as<psvr_extz_t>(), dcig.as<uint32_t>(), dwork.p, nullptr);
 	if (rc) return rc;
 	PSVR_HIP(hipDeviceSynchronize());
+	{
+		int kerr = 0;
+		PSVR_HIP(hipMemcpy(&kerr, (char *)pl->d_wstop.p + 8, 4, hipMemcpyDeviceToHost));
+		if (kerr) return set_error(PSVR_ERR_OVERFLOW, "DP kernel scratch exhausted (internal error %d)", kerr);
+	}
 	PSVR_HIP(hipMemcpy(ez, dez.p, n * sizeof(psvr_extz_t), hipMemcpyDeviceToHost));
 	if (want_cigar) PSVR_HIP(hipMemcpy(cigar, dcig.p, cig * 4, hipMemcpyDeviceToHost));
 	return PSVR_OK;

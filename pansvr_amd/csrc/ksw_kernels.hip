@@ -514,6 +514,7 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 	ez.reset();
 	const bool bad_shape = qlen <= 0 || tlen <= 0 || (tlen + SW - 1) / SW > n_strips;
 	if (!live) return;
+	if (base + need > B.ws_cap && B.err) *B.err = 20;
 	if (P.skip || bad_shape || base + need > B.ws_cap) { if (ql == 0) write_ez(out, ez, 0); return; }
 	uint8_t *w0 = B.ws + base;
 	const size_t offE = (size_t)256 * n_strips * R;
