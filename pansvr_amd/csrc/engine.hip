@@ -481,8 +481,22 @@ struct GpuBE {
 	void *dalloc(size_t n) { void *p = nullptr; hipError_t e = hipMalloc(&p, n ? n : 16); note(e); return e == hipSuccess ? p : nullptr; }
 	void dfree(void *p) { if (p) (void)hipFree(p); }
 	void dzero(void *p, size_t n) { note(hipMemsetAsync(p, 0, n, stream)); }
-	void h2d(void *d, const void *h, size_t n) { note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); }
-	void d2h(void *h, const void *d, size_t n) { note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); }
+	// small transfers (counters, lists of a few thousand pairs) go through a pinned staging buffer: a copy to or from pageable
+	// memory costs several times the latency
+	void *pin = nullptr;
+	static constexpr size_t kPin = (size_t)4 << 20;
+	void *pinned() { if (!pin && hipHostMalloc(&pin, kPin, hipHostMallocDefault) != hipSuccess) pin = nullptr; return pin; }
+	void h2d(void *d, const void *h, size_t n)
+	{
+		if (n && n <= kPin && pinned()) { memcpy(pin, h, n); note(hipMemcpyAsync(d, pin, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); return; }
+		note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream));
+	}
+	void d2h(void *h, const void *d, size_t n)
+	{
+		if (n && n <= kPin && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); memcpy(h, pin, n); return; }
+		note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream));
+	}
+	~GpuBE() { if (pin) (void)hipHostFree(pin); }
 	void fill_i64(long long *p, long long n, int stride, int off, long long v)
 	{
 		if (n) hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, stride, off, v);
@@ -553,8 +567,14 @@ struct GpuBE {
 	{
 		if (!n) return;
 		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 20 + 16));
-		note(hipMemcpyAsync(tmp_idx.p, idx, n * 4, hipMemcpyHostToDevice, stream));
+		h2d(tmp_idx.p, idx, n * 4);
 		hipLaunchKernelGGL(k_gather_listed, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, b, cc, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
+		if ((size_t)n * 20 <= kPin && pinned()) {
+			note(hipMemcpyAsync(pin, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
+			note(hipStreamSynchronize(stream));
+			memcpy(oa, pin, n * 8), memcpy(ob, (char *)pin + n * 8, n * 8), memcpy(oc, (char *)pin + n * 16, n * 4);
+			return;
+		}
 		note(hipMemcpyAsync(oa, tmp_out.p, n * 8, hipMemcpyDeviceToHost, stream));
 		note(hipMemcpyAsync(ob, (char *)tmp_out.p + n * 8, n * 8, hipMemcpyDeviceToHost, stream));
 		note(hipMemcpyAsync(oc, (char *)tmp_out.p + n * 16, n * 4, hipMemcpyDeviceToHost, stream));
@@ -642,12 +662,18 @@ struct GpuBE {
 		PSVR_HIP(hipGetLastError());
 		unsigned long long hist[512], qmax[16];
 		long long tot[3];
-		PSVR_HIP(hipMemcpyAsync(hist, plan_hist.p, 512 * 8, hipMemcpyDeviceToHost, stream));
-		PSVR_HIP(hipMemcpyAsync(qmax, (char *)plan_hist.p + 1024 * 8, 16 * 8, hipMemcpyDeviceToHost, stream));
-		PSVR_HIP(hipMemcpyAsync(&tot[0], d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
-		PSVR_HIP(hipMemcpyAsync(&tot[1], d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
-		PSVR_HIP(hipMemcpyAsync(&tot[2], pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
-		PSVR_HIP(hipStreamSynchronize(stream));
+		{
+			// one synchronisation for all five readbacks, through the pinned staging buffer when it exists
+			char stackbuf[512 * 8 + 16 * 8 + 24];
+			char *hb = pinned() ? (char *)pin : stackbuf;
+			PSVR_HIP(hipMemcpyAsync(hb, plan_hist.p, 512 * 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4096, (char *)plan_hist.p + 1024 * 8, 16 * 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4224, d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4232, d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4240, pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipStreamSynchronize(stream));
+			memcpy(hist, hb, 4096), memcpy(qmax, hb + 4096, 128), memcpy(tot, hb + 4224, 24);
+		}
 		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
@@ -675,7 +701,7 @@ struct GpuBE {
 			if (team_cnt[cls]) ls.push_back(Launch3{PSVR_DP_KIND_STRIP, dp_lds_class_bytes(cls), acc, (long long)team_cnt[cls]});
 			for (int qb = 15; qb >= 0; --qb) bstart[256 + cls * 16 + qb] = acc, acc += (long long)hist[256 + cls * 16 + qb];
 		}
-		PSVR_HIP(hipMemcpyAsync(plan_bstart.p, bstart, 512 * 8, hipMemcpyHostToDevice, stream));
+		h2d(plan_bstart.p, bstart, 512 * 8);
 		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
 		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
 		t0("k_dp_fetch");
