@@ -552,13 +552,13 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 			e_prev = Ein[(size_t)(c0 - 1) * PB];
 			if (0 <= qlen - 2) d_cur = D[(size_t)c0 * PB];
 		}
-		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? (query[0 - jb] & 15u) : 0u;   // query[k - jb] for k = 0
+		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? query[0 - jb] : 0u;   // query[k - jb] for k = 0 (raw byte: masking it here would wait for the load)
 		unsigned W = 0;                                               // query window: nibble jj = query[k - jb - jj]
 		const int ksteps = qlen + ncols - 1;
 		for (int k = 0; k < ksteps; ++k) {
 			const int r = c0 + k;
-			const unsigned q_nxt = (unsigned)(k + 1 - jb) < (unsigned)qlen ? (query[k + 1 - jb] & 15u) : 0u;
-			W = (W << 4) | q_cur;
+			const unsigned q_nxt = (unsigned)(k + 1 - jb) < (unsigned)qlen ? query[k + 1 - jb] : 0u;
+			W = (W << 4) | (q_cur & 15u);
 			const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
 			const int en1 = st0 + (en0 - st0) / 4 * 4;
 			const int sel_t = en0 > 0 ? en0 : -1;
