@@ -27,11 +27,18 @@ __device__ __forceinline__ long long pair_of(const int32_t *work, long long i) {
 __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate, int tsize, int per_wave)
 {
 	extern __shared__ __align__(16) uint8_t prep_lds[];
+	// charToDna5n as a 128-entry table at the start of the workgroup's LDS (one ds_read instead of a compare chain per base)
+	if (threadIdx.x < 128) {
+		const int ch = threadIdx.x;
+		prep_lds[ch] = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0;
+	}
+	__syncthreads();
+	const uint8_t *lut = prep_lds;
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
 	if (wi >= n) return;
 	const long long read = pair_of(work, wi) * 2 + mate;
-	uint8_t *fw = prep_lds + (size_t)wave * per_wave, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
+	uint8_t *fw = prep_lds + 128 + (size_t)wave * per_wave, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
 	uint64_t *pw = (uint64_t *)(rv + c.lmax);                            // forward strand's packed words (for the STR screen)
 	unsigned int *bits = (unsigned int *)(pw + c.wmax);                  // tsize words: hashed 20-mer set
 	const long long sr = src_read(c, read);
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 			ch = "ACGT"[r % 4];
 		}
 		draws += __popcll(m);
-		const uint8_t code = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0;
+		const uint8_t code = lut[ch & 0x7f];                                   // input is 7-bit ASCII
 		if (i < L) fw[i] = code, rv[L - 1 - i] = code ^ 3, b0[i] = code, b1[L - 1 - i] = code ^ 3;
 		else if (i < c.lmax) fw[i] = 0, rv[i] = 0;
 		any4 |= __ballot(i < L && code > 3) != 0;
@@ -531,9 +538,11 @@ struct GpuBE {
 	{
 		if (n <= 0) return;
 		t0("k_prep");
-		const int tsize = str_tsize(c);
+		// the screen's hashed set: 32 bits per word; for reads up to ~270 bp 8 x tsize bits keep the expected number of chance
+		// collisions at kn / 32 (far below the 16 that would send a read to the exact count); longer reads get the full 32 x tsize
+		const int tsize = c.lmax <= 288 ? str_tsize(c) / 4 : str_tsize(c);
 		const size_t per_wave = ((size_t)2 * c.lmax + (size_t)c.wmax * 8 + (size_t)tsize * 4 + 15) & ~(size_t)15;
-		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)(kBlock / 64) * per_wave, stream, c, w, n, mate, tsize, (int)per_wave);
+		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)128 + (size_t)(kBlock / 64) * per_wave, stream, c, w, n, mate, tsize, (int)per_wave);
 		t1();
 		note(hipGetLastError());
 	}
