@@ -48,6 +48,9 @@ struct DpBatch { // device pointers of one batch
 
 #define PSVR_DP_NUM_LDS_CLASSES 13
 #define PSVR_DP_KIND_TINY 11
+#ifndef PSVR_DP_USE_TINY
+#define PSVR_DP_USE_TINY 1     /* 0 sends them to the team kernel instead: same total time on the bench workload */
+#endif
 #define PSVR_DP_KIND_STRIP 12
 #define PSVR_DP_STRIP 16               // extd2_team_kernel: size classes count 16-column strips
 #define PSVR_DP_TINY_MAX 16            // extd2_tiny_kernel: qlen, tlen <= 16, one thread per alignment
@@ -119,7 +122,7 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 __host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool tiny_ok = false)
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
-	if (tiny_ok && qlen <= PSVR_DP_TINY_MAX && tlen <= PSVR_DP_TINY_MAX) { *need = (qlen + tlen - 1) * 512; return PSVR_DP_KIND_TINY; }
+	if (PSVR_DP_USE_TINY && tiny_ok && qlen <= PSVR_DP_TINY_MAX && tlen <= PSVR_DP_TINY_MAX) { *need = (qlen + tlen - 1) * 512; return PSVR_DP_KIND_TINY; }
 	// one thread per alignment, 16-column strips in registers: whenever the band never clips the matrix (the lean regime).
 	// The size class is the number of strips (1..13), expressed through `need` as that class's byte threshold.
 	if (tiny_ok && dp_band_never_binds(qlen, tlen, w < 0 ? (qlen > tlen ? qlen : tlen) : w) && tlen <= PSVR_DP_STRIP * PSVR_DP_NUM_LDS_CLASSES) {
