@@ -11,6 +11,8 @@
 #include <sys/time.h>
 #include <time.h>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -290,52 +292,65 @@ int main(int argc, char **argv)
 	psvr_aln_params_default(&par);
 	par.match = o.match, par.mismatch = o.mismatch, par.gap_open = o.gap_open, par.gap_ex = o.gap_ex, par.gap_open2 = o.gap_open2, par.gap_ex2 = o.gap_ex2, par.zdrop = o.zdrop;
 	psvr_engine_t *eng = nullptr;
-	FastqBatch fb;
-	std::vector<psvr_read_result_t> res;
-	std::vector<psvr_pair_result_t> pres;
-	std::vector<uint32_t> cig;
-	long long loaded = 0, pair_base = 0;
+	// classify_pipeline's three overlapped steps (rr.cpp:100-131, kt_pipeline): load_reads | align | output_results.  Three job
+	// slots cycle through the stages in input order, so the output order is the input order.
+	struct Job {
+		std::vector<FqRec> recs; std::vector<char> bases; std::vector<long long> base_off; std::vector<psvr_ori_t> ori;
+		std::vector<psvr_read_result_t> res; std::vector<psvr_pair_result_t> pres; std::vector<uint32_t> cig;
+		long long pair_base = 0;
+		int state = 0;              // 0 free, 1 loaded, 2 aligned
+		bool last = false;          // end-of-input marker travelling through the stages
+		long long n_pairs() const { return (long long)recs.size() / 2; }
+	};
+	Job jobs[3];
+	std::mutex mu;
+	std::condition_variable cv;
+	auto wait_state = [&](Job &J, int st) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return J.state == st; }); };
+	auto set_state = [&](Job &J, int st) { { std::lock_guard<std::mutex> lk(mu); J.state = st; } cv.notify_all(); };
 	int block = 0;
 	double t_read = 0, t_engine = 0, t_format = 0, t_write = 0;
-	for (;;) {
-		long long want = o.batch_pairs;
-		if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
-		double tw = walltime();
-		if (want <= 0 || !fb.read(fq, want, o.thread_n)) break;
-		t_read += walltime() - tw, tw = walltime();
-		loaded += fb.n_pairs();
-		if (!eng) {
-			fb.stat_params(&par);
-			fprintf(stderr, "Current used read status: READ_LEN=%d; ISIZE_MIN=%d; ISIZE_MID=%d; ISIZE_MAX=%d; filter_score_full_match=%d\n", par.normal_read_length, par.isize_min, 0,
-			        par.isize_max, par.min_filter_score);
-			if (psvr_engine_create(idx, &par, &eng)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
+	std::thread reader([&]() {
+		FastqBatch fb;
+		long long loaded = 0, pair_base = 0;
+		for (int slot = 0;; slot = (slot + 1) % 3) {
+			Job &J = jobs[slot];
+			wait_state(J, 0);
+			long long want = o.batch_pairs;
+			if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
+			double tw = walltime();
+			const bool ok = want > 0 && fb.read(fq, want, o.thread_n);
+			t_read += walltime() - tw;
+			if (!ok) { J.last = true; set_state(J, 1); return; }
+			if (loaded == 0) fb.stat_params(&par);          // STAT_ of the very first read (rr.cpp:134-148), before the first batch is aligned
+			loaded += fb.n_pairs();
+			J.recs.swap(fb.recs), J.bases.swap(fb.bases), J.base_off.swap(fb.base_off), J.ori.swap(fb.ori);
+			J.pair_base = pair_base, pair_base += J.n_pairs();
+			set_state(J, 1);
 		}
-		const long long P = fb.n_pairs(), R = 2 * P;
-		res.resize(R), pres.resize(P);
-		int rc = psvr_engine_upload(eng, P, fb.bases.data(), (const int64_t *)fb.base_off.data(), fb.ori.data());
-		if (!rc) rc = psvr_engine_run(eng, o.trace ? 1 : 0, nullptr);
-		int64_t used = 0;
-		if (!rc) { rc = psvr_engine_download(eng, nullptr, nullptr, nullptr, 0, &used); if (rc == PSVR_ERR_OVERFLOW) rc = 0; }
-		cig.resize(used + 1);
-		if (!rc) rc = psvr_engine_download(eng, res.data(), pres.data(), cig.data(), (int64_t)cig.size(), &used);
-		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
-		t_engine += walltime() - tw, tw = walltime();
+	});
+	std::thread writer([&]() {
+		for (int slot = 0;; slot = (slot + 1) % 3) {
+			Job &J = jobs[slot];
+			wait_state(J, 2);
+			if (J.last) return;
+			const long long P = J.n_pairs();
+		double tw = walltime();
 		fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
 		if (frec) {
 			for (long long p = 0; p < P; ++p) {
-				int lens[2] = {(int)fb.recs[2 * p].seq.size(), (int)fb.recs[2 * p + 1].seq.size()};
-				fprintf(frec, "%s\n", record_json(pair_base + p, &res[2 * p], pres[p], &fb.ori[2 * p], lens, cig.data(), o.trace).c_str());
+				int lens[2] = {(int)J.recs[2 * p].seq.size(), (int)J.recs[2 * p + 1].seq.size()};
+				fprintf(frec, "%s\n", record_json(J.pair_base + p, &J.res[2 * p], J.pres[p], &J.ori[2 * p], lens, J.cig.data(), o.trace).c_str());
 			}
 		}
 		// ---- step 2: records (output_BAM, rr.cpp:479-536), formatted for runs of pairs on -t threads and written in input order
 		auto format_main = [&](long long p0, long long p1, std::vector<uint8_t> &dst) {
 		for (long long p = p0; p < p1; ++p) {
-			const psvr_pair_result_t &pr = pres[p];
+			const psvr_pair_result_t &pr = J.pres[p];
 			if (!pr.gain) continue;
 			for (int k = 0; k < 2; ++k) {
-				const psvr_read_result_t &rr = res[2 * p + k];
-				const FqRec &rec = fb.recs[2 * p + k];
-				const psvr_ori_t &ori = fb.ori[2 * p + k];
+				const psvr_read_result_t &rr = J.res[2 * p + k];
+				const FqRec &rec = J.recs[2 * p + k];
+				const psvr_ori_t &ori = J.ori[2 * p + k];
 				if (rr.primary == -1) continue;                          // primary_result == NULL
 				const bool is_ori = rr.primary == -2;
 				if (o.not_ori && is_ori) continue;
@@ -351,7 +366,7 @@ int main(int argc, char **argv)
 				} else {
 					const psvr_cand_t &cd = rr.cand[rr.primary];
 					chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
-					cg = cigar_string(cd, cig.data());
+					cg = cigar_string(cd, J.cig.data());
 				}
 				if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
 				int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
@@ -384,10 +399,10 @@ int main(int argc, char **argv)
 		// ---- second file (rr.cpp:776-797): pairs neither the original aligner nor the re-aligner placed well
 		auto format_ori = [&](long long p0, long long p1, std::vector<uint8_t> &dst) {
 		for (long long p = p0; p < p1; ++p) {
-			const psvr_pair_result_t &pr = pres[p];
-			if (!(pr.max_score <= par.min_filter_score && fb.ori[2 * p].chr_id != -1 && fb.ori[2 * p + 1].chr_id != -1)) continue;
+			const psvr_pair_result_t &pr = J.pres[p];
+			if (!(pr.max_score <= par.min_filter_score && J.ori[2 * p].chr_id != -1 && J.ori[2 * p + 1].chr_id != -1)) continue;
 			OriRecord orr[2];
-			bool ok = parse_ori_record(fb.recs[2 * p].comment, &orr[0]) && parse_ori_record(fb.recs[2 * p + 1].comment, &orr[1]);
+			bool ok = parse_ori_record(J.recs[2 * p].comment, &orr[0]) && parse_ori_record(J.recs[2 * p + 1].comment, &orr[1]);
 			if (!ok) continue;
 			bool proper = pr.proper != 0;
 			for (int k = 0; proper && k < 2; ++k) {
@@ -395,16 +410,16 @@ int main(int argc, char **argv)
 				if (mx == -1) { proper = false; break; }
 				if (mx == -2) { if (ori_has_clip(orr[k].cigar, 25)) proper = false; }
 				else {                                               // bam_has_clip_or_unmapped_new (rr.cpp:735-743): sums the 'I' ops
-					const psvr_cand_t &cd = res[2 * p + k].cand[mx];
+					const psvr_cand_t &cd = J.res[2 * p + k].cand[mx];
 					int tot = 0;
-					for (uint32_t j = 0; j < cd.n_cigar; ++j) { uint32_t wv = cig[cd.cigar_off + j]; if ((wv & 0xf) == 1) tot += (int)(int16_t)(wv >> 4); }
+					for (uint32_t j = 0; j < cd.n_cigar; ++j) { uint32_t wv = J.cig[cd.cigar_off + j]; if ((wv & 0xf) == 1) tot += (int)(int16_t)(wv >> 4); }
 					if (cd.n_cigar == 0 || tot >= 25) proper = false;
 				}
 			}
 			if (proper) continue;
 			for (int k = 0; k < 2; ++k) {
-				const FqRec &rec = fb.recs[2 * p + k];
-				const psvr_ori_t &ori = fb.ori[2 * p + k];
+				const FqRec &rec = J.recs[2 * p + k];
+				const psvr_ori_t &ori = J.ori[2 * p + k];
 				std::string seq = rec.seq, qual = rec.qual;
 				if (orr[k].flag & 0x10) rev_seq(seq), rev_qual(qual);
 				std::string tags;
@@ -435,8 +450,32 @@ int main(int argc, char **argv)
 			for (long long ci = 0; ci < nchunk; ++ci) fo.write_raw(mb[ci]), fo_ori.write_raw(ob[ci]);
 			t_write += walltime() - tw;
 		}
-		pair_base += P;
+			set_state(J, 0);
+		}
+	});
+	for (int slot = 0;; slot = (slot + 1) % 3) {
+		Job &J = jobs[slot];
+		wait_state(J, 1);
+		if (J.last) { set_state(J, 2); break; }
+		double tw = walltime();
+		if (!eng) {
+			fprintf(stderr, "Current used read status: READ_LEN=%d; ISIZE_MIN=%d; ISIZE_MID=%d; ISIZE_MAX=%d; filter_score_full_match=%d\n", par.normal_read_length, par.isize_min, 0,
+			        par.isize_max, par.min_filter_score);
+			if (psvr_engine_create(idx, &par, &eng)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
+		}
+		const long long P = J.n_pairs(), R = 2 * P;
+		J.res.resize(R), J.pres.resize(P);
+		int rc = psvr_engine_upload(eng, P, J.bases.data(), (const int64_t *)J.base_off.data(), J.ori.data());
+		if (!rc) rc = psvr_engine_run(eng, o.trace ? 1 : 0, nullptr);
+		int64_t used = 0;
+		if (!rc) { rc = psvr_engine_download(eng, nullptr, nullptr, nullptr, 0, &used); if (rc == PSVR_ERR_OVERFLOW) rc = 0; }
+		J.cig.resize(used + 1);
+		if (!rc) rc = psvr_engine_download(eng, J.res.data(), J.pres.data(), J.cig.data(), (int64_t)J.cig.size(), &used);
+		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
+		t_engine += walltime() - tw;
+		set_state(J, 2);
 	}
+	reader.join(), writer.join();
 	if (fq != stdin) fclose(fq);
 	if (!fo.close() || !fo_ori.close()) { fprintf(stderr, "fail to write output file\n"); abort(); }
 	if (frec) fclose(frec);

@@ -97,6 +97,8 @@ template <class BE> struct EngineCore {
 	int32_t *d_ctot = nullptr, *d_src = nullptr;     // per slot: total draws of the last evaluation; slot -> input pair
 	uint8_t *d_sens = nullptr;                       // per pair: known count-sensitive
 	int32_t *d_slist = nullptr;                      // newly detected sensitive pairs
+	char *d_bases = nullptr; long long *d_off = nullptr; psvr_ori_t *d_ori = nullptr;   // the uploaded batch
+	long long cap_S = 0, cap_bases = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
 	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
 	int32_t *d_cmask = nullptr;                      // totals with the host-resolved pairs masked out
 	struct Special { int32_t pair; uint8_t n1, n2; int32_t vslot, nvar; };
@@ -180,20 +182,14 @@ template <class BE> struct EngineCore {
 	// ---- batch upload: allocate everything sized by the batch
 	int upload(long long n_pairs, const char *bases, const int64_t *base_off, const psvr_ori_t *ori)
 	{
-		for (void *p : owned) be.dfree(p);
-		owned.clear();
 		P = n_pairs, R = 2 * n_pairs;
 		total_bases = R ? base_off[R] : 0;
 		int lmax = 0;
 		for (long long r = 0; r < R; ++r) { long long l = base_off[r + 1] - base_off[r]; if (l > lmax) lmax = (int)l; }
 		if (lmax > kMaxReadLen) { err = "read longer than MAX_READ_LEN 1600"; return PSVR_ERR_UNSUPPORTED; }
 		c.n_pairs = P;
-		c.lmax = (lmax + 31) & ~31;
-		if (c.lmax < 32) c.lmax = 32;
-		c.wmax = c.lmax / 32 + 2;
-		char *d_bases = alloc<char>(total_bases + 16);
-		long long *d_off = alloc<long long>(R + 1);
-		psvr_ori_t *d_ori = alloc<psvr_ori_t>(R);
+		int lm = (lmax + 31) & ~31;
+		if (lm < 32) lm = 32;
 		// pairs whose reads will draw for 1..3 N bases (early-out reads draw nothing: rr.cpp:414 returns first)
 		special.clear();
 		V = 0;
@@ -217,8 +213,25 @@ template <class BE> struct EngineCore {
 		}
 		const long long shadow_cap = P / 16 + 8192;
 		S = P + V + shadow_cap;
-		const long long RS = 2 * S;                                 // reads incl. shadow slots
 		c.n_slots = S;
+		// a pipeline feeds batch after batch of similar size: keep every per-batch buffer (and the arenas) while the new batch fits
+		const bool fits = !owned.empty() && S <= cap_S && lm <= cap_lm && total_bases <= cap_bases && P <= cap_P;
+		if (fits) {
+			be.h2d(d_bases, bases, total_bases);
+			be.h2d(d_off, base_off, (R + 1) * 8);
+			be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
+			upload_variants();
+			return PSVR_OK;
+		}
+		for (void *p : owned) be.dfree(p);
+		owned.clear();
+		cap_S = S, cap_lm = lm, cap_bases = total_bases, cap_P = P;
+		c.lmax = lm;
+		c.wmax = c.lmax / 32 + 2;
+		d_bases = alloc<char>(total_bases + 16);
+		d_off = alloc<long long>(R + 1);
+		d_ori = alloc<psvr_ori_t>(R);
+		const long long RS = 2 * S;                                 // reads incl. shadow slots
 		c.poff = alloc<long long>(S), c.rcnt = alloc<int32_t>(3 * S), d_noff = alloc<long long>(S);
 		c.hoff = alloc<long long>(RS), c.hcnt = alloc<int32_t>(RS), d_nhoff = alloc<long long>(RS);
 		c.active = alloc<uint8_t>(RS), c.unmapped = alloc<uint8_t>(RS), c.is_str = alloc<uint8_t>(RS), c.has_n4 = alloc<uint8_t>(RS);
@@ -249,8 +262,14 @@ template <class BE> struct EngineCore {
 		be.h2d(d_off, base_off, (R + 1) * 8);
 		be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
 		c.bases = d_bases, c.base_off = d_off, c.ori = d_ori;
-		// variant slots: pair s at every combination of its N-substitution residues.  Only those slots force draws, so the
-		// table is zeroed on the device and just their rows are uploaded, once per batch.
+		upload_variants();
+		return PSVR_OK;
+	}
+
+	// variant slots: pair s at every combination of its N-substitution residues.  Only those slots force draws, so the
+	// table is zeroed on the device and just their rows are uploaded, once per batch.
+	void upload_variants()
+	{
 		{
 			std::vector<uint8_t> force((size_t)8 * V, 0);
 			h_vsrc.assign(V, 0), h_sp_idx.assign(special.size(), 0);
@@ -272,7 +291,6 @@ template <class BE> struct EngineCore {
 			be.dzero(d_force, (size_t)8 * S);
 			if (V) be.h2d(d_force + (size_t)8 * P, force.data(), force.size());
 		}
-		return PSVR_OK;
 	}
 
 	void free_arenas()
