@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 // its alignments, which the planner keeps similar by binning on the strip count).  ~85 vector instructions per cell and
 // lane, i.e. ~1.5 wavefront instructions per cell instead of ~7.
 template <int LANES>
-__global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)   // <= 128 VGPRs: the kernel is issue-bound and wants 4 wavefronts per SIMD
 {
 	constexpr int SW = 4 * LANES, PB = 64 / LANES;                   // strip width, alignments per wavefront
 	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 	uint8_t *w0 = B.ws + base;
 	const size_t offE = (size_t)256 * n_strips * R;
 	uint32_t *PD = (uint32_t *)w0 + lane;                             // strip s, step k at [(s * R + k) * 64]
-	uint2 *E[2] = {(uint2 *)(w0 + offE) + team, (uint2 *)(w0 + offE + (size_t)8 * PB * NR) + team};   // diagonal r at [r * PB]
+	uint32_t *E[2] = {(uint32_t *)(w0 + offE) + team, (uint32_t *)(w0 + offE + (size_t)8 * PB * NR) + team};   // diagonal r at [r * PB] (8 bytes per entry are reserved: the CIGAR is staged here later)
 	int *D = (int *)(w0 + offE + (size_t)16 * PB * NR) + team, *D2 = D + (size_t)PB * NR, *D3 = D2 + (size_t)PB * NR;
 	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
 	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
@@ -527,6 +527,19 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	const int n_rows = qlen + tlen - 1;
 	auto ur_of = [&](int r) { return r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2); };
+	// H is tracked by vertical steps only, H(i,t) = H(i-1,t) + v(i,t).  The reference takes a horizontal step for the last
+	// in-band cell of a diagonal (:322), which is the same number: both deltas come from one z.  For the top row that needs the
+	// value "above" it: -qe for column 0 (the reference's H[0] = v - qe at r == 0, :351), then the boundary u of every column
+	// added up, since H(0,t) = H(0,t-1) + u(0,t) and v(0,t) - u(0,t) + v(0,t-1) = ur(t).
+	auto h_above = [&](int t) {
+		int h = -P.qe_pre;
+		const int lt = P.long_thres;
+		if (t >= 1) {
+			if (lt >= 1) h += t < lt ? t * s8(-P.e) : (lt - 1) * s8(-P.e) + s8(P.long_diff) + (t - lt) * s8(-P.e2);
+			else h += t * s8(-P.e2);
+		}
+		return h;
+	};
 	const int ns = (tlen + SW - 1) / SW;
 	for (int s = 0; s < ns; ++s) {
 		const int c0 = SW * s;
@@ -539,14 +552,14 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 		for (int jj = 0; jj < 4; ++jj) {
 			U[jj] = ur_of(c0 + jb + jj);                                // u/y/y2 of the first cell of a column (:153-156)
 			V[jj] = X[jj] = Y[jj] = neg_qe, X2[jj] = Y2[jj] = neg_qe2;
-			H[jj] = -P.qe_pre;
+			H[jj] = h_above(c0 + jb + jj);
 			TW |= (unsigned)(jb + jj < ncols ? (target[c0 + jb + jj] & 15) : 0) << (4 * jj);
 		}
-		const uint2 *Ein = E[(s + 1) & 1];
-		uint2 *Eout = E[s & 1];
+		const uint32_t *Ein = E[(s + 1) & 1];
+		uint32_t *Eout = E[s & 1];
 		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
 		// loaded one step ahead, so the loads have a whole step to arrive
-		uint2 e_prev = make_uint2(0u, 0u);
+		uint32_t e_prev = 0;
 		int d_cur = 0;
 		if (s > 0) {
 			e_prev = Ein[(size_t)(c0 - 1) * PB];
@@ -561,12 +574,11 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 			W = (W << 4) | (q_cur & 15u);
 			const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
 			const int en1 = st0 + (en0 - st0) / 4 * 4;
-			const int sel_t = en0 > 0 ? en0 : -1;
 			// the column left of this lane's first one: the neighbour lane's last column (old values), or for the team's first lane
 			// column -1 (:142-152) / the previous strip's last column on diagonal r-1
 			int vl = __builtin_amdgcn_update_dpp(0, V[3], 0x111, 0xf, 0xf, false), xl = __builtin_amdgcn_update_dpp(0, X[3], 0x111, 0xf, 0xf, false);
-			int x2l = __builtin_amdgcn_update_dpp(0, X2[3], 0x111, 0xf, 0xf, false), hl = __builtin_amdgcn_update_dpp(0, H[3], 0x111, 0xf, 0xf, false);
-			uint2 e_next = make_uint2(0u, 0u);
+			int x2l = __builtin_amdgcn_update_dpp(0, X2[3], 0x111, 0xf, 0xf, false);
+			uint32_t e_next = 0;
 			int d_nxt = 0;
 			const int dprev = d_cur;
 			if (s > 0) {
@@ -574,19 +586,17 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 				if (k + 1 <= qlen - 2) d_nxt = D[(size_t)(r + 1) * PB];      // earlier strips reached that diagonal (their last is c0 + qlen - 2)
 			}
 			if (ql == 0) {
-				if (s > 0) vl = s8(e_prev.x), xl = s8(e_prev.x >> 8), x2l = s8(e_prev.x >> 16), hl = (int)e_prev.y;
-				else vl = ur_of(r), xl = neg_qe, x2l = neg_qe2, hl = 0;
+				if (s > 0) vl = s8(e_prev), xl = s8(e_prev >> 8), x2l = s8(e_prev >> 16);
+				else vl = ur_of(r), xl = neg_qe, x2l = neg_qe2;
 			}
 			const int jq = k - (qlen - 1);                               // column of this step's cell in the last query row
 			unsigned best = 0;
-			int h_en0 = 0, h_st0 = 0;
-			bool has_en0 = false, has_st0 = false;
 			uint32_t dw = 0;
 #pragma unroll
 			for (int jj = 3; jj >= 0; --jj) {
 				const int j = jb + jj, t = c0 + j, i = k - j;
 				const bool act = ((unsigned)i < (unsigned)qlen) & (j < ncols);
-				const int xt1 = jj ? X[jj ? jj - 1 : 0] : xl, vt1 = jj ? V[jj ? jj - 1 : 0] : vl, x2t1 = jj ? X2[jj ? jj - 1 : 0] : x2l, hleft = jj ? H[jj ? jj - 1 : 0] : hl;
+				const int xt1 = jj ? X[jj ? jj - 1 : 0] : xl, vt1 = jj ? V[jj ? jj - 1 : 0] : vl, x2t1 = jj ? X2[jj ? jj - 1 : 0] : x2l;
 				const int qc = (int)(W >> (4 * jj)) & 15, tc = (int)(TW >> (4 * jj)) & 15;
 				int sc = tc == qc ? P.sc_mch : P.sc_mis;
 				sc = ((tc == P.m1) | (qc == P.m1)) ? P.sc_N : sc;
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 				const int zq = z - P.q, zq2 = z - P.q2;
 				za -= zq, zb -= zq, za2 -= zq2, zb2 -= zq2;
 				d |= (za > 0 ? 0x08 : 0) | (zb > 0 ? 0x10 : 0) | (za2 > 0 ? 0x20 : 0) | (zb2 > 0 ? 0x40 : 0);
-				const int hn = t == sel_t ? hleft + un : H[jj] + vn;     // exact H (:316-351)
+				const int hn = H[jj] + vn;                               // exact H (:316-351), see h_above
 				const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
 				                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
 				const unsigned key = (unsigned)(hn + 0x4000) << 16 | (0x7fffu - rank);   // larger H first, then the reference's order (:322-349)
@@ -615,8 +625,6 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 					H[jj] = hn;
 					best = max(best, key);
 					dw |= (uint32_t)d << (8 * jj);
-					if (j == jl) h_en0 = hn, has_en0 = true;
-					if (j == jq) h_st0 = hn, has_st0 = true;
 				}
 			}
 			// team maximum (butterfly inside the quad, then across the two quads of an 8-lane team)
@@ -624,10 +632,17 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 			best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x4E, 0xf, 0xf, false));
 			if (LANES == 8) best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x141, 0xf, 0xf, false));
 			if (with_cigar) PD[(size_t)(s * R + k) * 64] = dw;
-			if (ql == LANES - 1 && s + 1 < ns) Eout[(size_t)r * PB] = make_uint2((uint32_t)(V[3] & 0xff) | (uint32_t)(X[3] & 0xff) << 8 | (uint32_t)(X2[3] & 0xff) << 16, (uint32_t)H[3]);
+			if (ql == LANES - 1 && s + 1 < ns) Eout[(size_t)r * PB] = (uint32_t)(V[3] & 0xff) | (uint32_t)(X[3] & 0xff) << 8 | (uint32_t)(X2[3] & 0xff) << 16;
 			if (ql == 0) D[(size_t)r * PB] = (int)max(best, (unsigned)dprev);
-			if (has_en0) D2[(size_t)r * PB] = h_en0;                      // cell (r - (tlen-1), tlen-1)
-			if (has_st0) D3[(size_t)r * PB] = h_st0;                      // cell (qlen-1, r - qlen + 1)
+			// H at the band ends, for mte / mqe / score: the lane that owns the column writes it (one 4-way select per step)
+			if ((unsigned)(jl - jb) < 4u && (unsigned)(k - jl) < (unsigned)qlen) {            // cell (r - (tlen-1), tlen-1)
+				const int jx = jl - jb;
+				D2[(size_t)r * PB] = jx == 0 ? H[0] : jx == 1 ? H[1] : jx == 2 ? H[2] : H[3];
+			}
+			if ((unsigned)(jq - jb) < 4u && jq < ncols) {                                     // cell (qlen-1, r - qlen + 1)
+				const int jx = jq - jb;
+				D3[(size_t)r * PB] = jx == 0 ? H[0] : jx == 1 ? H[1] : jx == 2 ? H[2] : H[3];
+			}
 			e_prev = e_next, d_cur = d_nxt, q_cur = q_nxt;
 		}
 	}
@@ -667,10 +682,10 @@ __global__ __launch_bounds__(64) void extd2_team_kernel(DpBatch B, DpParams P, T
 					const int t = k + (max(0, r - qlen + 1) & ~15), s = t / SW;
 					return (int)pb[(size_t)(s * R + (r - SW * s)) * 256 + (t - SW * s)];
 				},
-				[&](int k, uint32_t word) { stage[(size_t)k * PB * 2] = word; });
+				[&](int k, uint32_t word) { stage[(size_t)k * PB] = word; });
 			uint32_t *dst = B.cigar + out->cigar_off;
 			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
-			for (int m = 0; m < n_cigar; ++m) dst[m] = stage[(size_t)(rev ? m : n_cigar - 1 - m) * PB * 2];
+			for (int m = 0; m < n_cigar; ++m) dst[m] = stage[(size_t)(rev ? m : n_cigar - 1 - m) * PB];
 		}
 	}
 	write_ez(out, ez, n_cigar);
