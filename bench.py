@@ -65,7 +65,7 @@ def main():
 
     t_setup = time.time()
     anc = bench_data.make_anchors(args.anchors, seed=11)
-    ix_arrays = bench_data.build_index(anc, dense=True)
+    ix_arrays = bench_data.build_index_cli(anc, dense=True)      # `panSVR index`: byte-identical to the reference builder's files
     index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
     ix_sparse, ix_small = ix_arrays["hash_sparse"], {k: v for k, v in ix_arrays.items() if k != "hash"}
     ix_hash = ix_arrays["hash"] if rank == 0 and args.cpu_pairs > 0 else None

@@ -19,6 +19,7 @@
 #include "../../include/psvr_engine.h"
 #include "host_io.h"
 #include "bam_writer.h"
+#include "index_build.h"
 
 using namespace psvr;
 
@@ -231,8 +232,31 @@ static std::string cigar_string(const psvr_cand_t &c, const uint32_t *cig)
 	return s;
 }
 
+// `panSVR index [-k 22] [--sparse-hash] <anchors.fa> <IndexDir>`: what `deBGA index -k 22 <anchors.fa> <IndexDir>` builds
+// (panSVR_run.sh runs it on the SV anchor reference before `aln`).  Host only.
+static int index_main(int argc, char **argv)
+{
+	bool dense = true;
+	std::vector<std::string> pos;
+	for (int i = 2; i < argc; ++i) {
+		if (!strcmp(argv[i], "-k") && i + 1 < argc) { if (atoi(argv[++i]) != 22) { fprintf(stderr, "panSVR aln probes a k = 22 index: -k must be 22\n"); return 1; } }
+		else if (!strcmp(argv[i], "--sparse-hash")) dense = false;
+		else pos.push_back(argv[i]);
+	}
+	if (pos.size() != 2) { fprintf(stderr, "usage: panSVR index [-k 22] [--sparse-hash] <anchors.fa> <IndexDir>\n"); return 1; }
+	psvr::IndexBuilder b;
+	psvr::BuiltIndex ix;
+	if (!b.build(pos[0].c_str(), &ix)) { fprintf(stderr, "[panSVR-amd] index: %s\n", b.error().c_str()); return 2; }
+	std::string dir = pos[1], err;
+	while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
+	if (!psvr::IndexBuilder::write_dir(ix, dir, dense, &err)) { fprintf(stderr, "[panSVR-amd] index: %s\n", err.c_str()); return 2; }
+	fprintf(stderr, "[panSVR-amd] index: %zu unipaths, %llu distinct 22-mers, %zu positions\n", ix.seqf.size() - 1, (unsigned long long)ix.n_kmer, ix.pos.size());
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
+	if (argc >= 2 && !strcmp(argv[1], "index")) return index_main(argc, argv);
 	if (argc < 2 || (strcmp(argv[1], "aln") && strcmp(argv[1], "fc_aln"))) {
 		fprintf(stderr, "panSVR (MI355X engine): only the read re-alignment step is implemented here.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n");
 		return 1;

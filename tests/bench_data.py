@@ -64,6 +64,39 @@ def build_index(anc, dense=True):
                 posp=np.arange(U + 1, dtype=np.uint64), hash=h, hash_sparse=sparse, kmer=(v & np.uint64(0xffff)).astype(np.uint32), off=offs, chr=chr_text)
 
 
+def build_index_cli(anc, dense=True):
+    """The same dict as build_index, but through `panSVR index` (pansvr_amd/csrc/index_build.h), the builder that reproduces the
+    reference's index files byte for byte -- also for the handful of 22-mers a random 12 Mbp anchor set repeats."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    import index_fixture
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp(prefix="psvr_idxb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        codes, starts = anc["codes"], anc["starts"]
+        with open(os.path.join(tmp, "anchors.fa"), "wb") as f:
+            for i, nm in enumerate(anc["names"]):
+                f.write(b">" + nm.encode() + b"\n")
+                f.write(lut[codes[starts[i]:starts[i + 1]]].tobytes() + b"\n")
+        subprocess.check_call([os.path.join(root, "pansvr_amd", "bin", "panSVR"), "index", "-k", "22", "--sparse-hash", os.path.join(tmp, "anchors.fa"), tmp],
+                              stderr=subprocess.DEVNULL)
+        a = index_fixture.load_arrays(tmp) if dense else None
+        if a is None:
+            a = {}
+            for k, fn, dt in (("ref_seq", "ref.seq", np.uint64), ("seq", "unipath.seqb", np.uint64), ("seqf", "unipath.seqfb", np.uint64), ("pos", "unipath.pos", np.uint64),
+                              ("posp", "unipath.posp", np.uint64), ("kmer", "unipath_g.kmer", np.uint32), ("off", "unipath_g.offset", np.uint64)):
+                a[k] = np.fromfile(os.path.join(tmp, fn), dtype=dt)
+            a["hash"] = None
+            a["chr"] = open(os.path.join(tmp, "unipath.chr")).read()
+        a["hash_sparse"] = np.fromfile(os.path.join(tmp, "unipath_g.hash.sparse"), dtype=np.uint32).reshape(-1, 2)
+        return a
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def write_index_dir(ix, path, dense_hash=None):
     """On-disk form for the oracle executable (sparse first level, see tests/index_fixture.py).  dense_hash: also write the
     2 GiB prefix-sum table unipath_g.hash, which the reference's own loader (oracle/_ref/ref_aln) reads."""
