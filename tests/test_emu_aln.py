@@ -43,3 +43,31 @@ def test_emulated_engine_matches_reference_records(emu, name, rname):
     assert len(got) == len(want)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if normalise(a) != normalise(b)]
     assert not bad, "%d/%d pairs differ; first %d:\nref: %s\nemu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
+
+
+@pytest.mark.parametrize("variant", ["crlf", "no_final_newline", "tiny_batches", "truncated_pair"])
+def test_fastq_reader_edge_cases(emu, variant):
+    """host_io.h's batch reader (memchr line scan + records built on threads) on awkward inputs: CR LF line ends, a last line without
+    a newline, batches of 7 pairs (raw text carried across batches), and a trailing incomplete pair (ignored, like the
+    reference's read loop).  The records must be those of the plain file."""
+    w = ac.workdir("fx1")
+    text = open(os.path.join(w, "reads150.fq")).read()
+    n_keep = 300
+    lines = text.split("\n")[:8 * n_keep]
+    extra = []
+    if variant == "crlf":
+        data = "\r\n".join(lines) + "\r\n"
+    elif variant == "no_final_newline":
+        data = "\n".join(lines)
+    elif variant == "tiny_batches":
+        data = "\n".join(lines) + "\n"
+        extra = ["--batch", "7"]
+    else:
+        data = "\n".join(lines + lines[:4]) + "\n"          # one more read without its mate
+    path = os.path.join(w, "edge_%s.fq" % variant)
+    open(path, "w", newline="").write(data)
+    out = subprocess.run([emu, os.path.join(ac.golden_dir("fx1"), "idx"), path, os.path.join(w, "header.sam"), "--trace"] + extra,
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+    got = [normalise(l) for l in out.split("\n") if l.strip()]
+    want = [normalise(l) for l in ac.golden_lines("fx1", "reads150")[:n_keep]]
+    assert got == want
