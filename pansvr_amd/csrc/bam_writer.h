@@ -187,6 +187,7 @@ public:
 	static bool encode(const SamFields &s, std::vector<uint8_t> &rec_)
 	{
 		const size_t base = rec_.size();
+		if (s.qname.empty() || s.qname.size() > 254) return false;   // l_read_name is one byte (htslib: "query name too long")
 		std::vector<uint32_t> cig;
 		int64_t rlen = 0;
 		if (!s.cigar.empty() && s.cigar != "*") {
@@ -211,6 +212,7 @@ public:
 		put32(rec_, (uint32_t)s.tid), put32(rec_, (uint32_t)(int32_t)pos0);
 		rec_.push_back((uint8_t)(s.qname.size() + 1)), rec_.push_back((uint8_t)s.mapq);
 		put16(rec_, (uint16_t)reg2bin(pos0 < 0 ? 0 : pos0, (pos0 < 0 ? 0 : pos0) + (rlen > 0 ? rlen : 1)));
+		if (cig.size() > 0xffff) { rec_.resize(base); return false; }     // n_cigar_op is 16 bits (no CG:B long-CIGAR tag is written)
 		put16(rec_, (uint16_t)cig.size()), put16(rec_, (uint16_t)s.flag);
 		put32(rec_, l_seq);
 		put32(rec_, (uint32_t)s.mtid), put32(rec_, (uint32_t)(int32_t)(s.mpos1 - 1)), put32(rec_, (uint32_t)s.isize);
