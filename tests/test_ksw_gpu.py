@@ -75,6 +75,31 @@ def test_gpu_tiny_problems_match_oracle():
     assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(cases), bad[:3])
 
 
+def test_gpu_random_scoring_and_bands_match_oracle():
+    """Scoring parameters and band widths other than the path's (the CLI exposes -M -m -O -E -P -F -z): every kernel family gets
+    exercised -- small bands clip the matrix (wavefront kernels with the SSE artefacts), large penalties leave the int8-safe
+    regime (no lean sweep), swapped gap pairs hit the pre-swap qe quirk."""
+    rng = np.random.RandomState(9001)
+    cases = []
+    for _ in range(14):
+        match = int(rng.randint(1, 4))
+        mismatch = int(rng.randint(1, 31))
+        q, e = int(rng.randint(2, 33)), int(rng.randint(0, 4))
+        q2, e2 = int(rng.randint(2, 41)), int(rng.randint(0, 3))
+        w = int(rng.choice([200, 200, 200, 64, 16, 5, -1]))
+        zdrop = int(rng.choice([400, 400, 50, 10, -1]))
+        for c in random_cases(int(rng.randint(1 << 30)), 90, 140):
+            c.update(match=match, mismatch=mismatch, q=q, e=e, q2=q2, e2=e2, w=w, zdrop=zdrop, flag=int(rng.choice([0, 0, 0x40, 0x80])))
+            cases.append(c)
+    got = run_gpu(cases, "extd2")
+    bad = []
+    for i, (c, g) in enumerate(zip(cases, got)):
+        want = run_oracle(c, "extd2")
+        if g != want:
+            bad.append((i, {k: c[k] for k in ("match", "mismatch", "q", "e", "q2", "e2", "w", "zdrop", "flag")}, len(c["query"]), len(c["target"]), diff(want, g)))
+    assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(cases), bad[:3])
+
+
 def test_gpu_empty_and_degenerate():
     from pansvr_amd import ksw
     p = ksw.make_params(5, mat5(2, 12), 16, 1, 32, 0, 200, 400, -1, 0)
