@@ -902,10 +902,11 @@ struct Aligner {
 	PE ps;
 };
 
-Aligner *aligner_create(const Index *idx)
+Aligner *aligner_create(const Index *idx, const Params *par)
 {
 	Aligner *a = new Aligner;
 	a->idx = idx;
+	if (par) a->P = *par;                   // MAP_PARA::get_option's scoring options (-M -m -O -E -P -F -z), before the handlers read them
 	a->grand.seed(1);                       // rand() is never seeded by the reference
 	a->ps.idx = idx, a->ps.grand = &a->grand;
 	a->ps.init(0, 0, 0, 0);                  // rr.cpp:64 (options still zero)
@@ -1034,25 +1035,29 @@ bool read_fastq_record(FILE *f, Read *r)
 } // namespace orc
 
 #ifdef ORC_ALN_MAIN
-// aln_oracle <index_dir> <reads.fq> <header.sam> [--trace] [--limit N] [--stats [--print]]
+// aln_oracle <index_dir> <reads.fq> <header.sam> [--trace] [--limit N] [--stats [--print]] [--score M,m,O,E,P,F,z]
 // stderr: "ALIGN_SECONDS <s>" = wall of the per-pair loop alone (index load excluded), which bench.py reports.
 int main(int argc, char **argv)
 {
 	if (argc < 4) { fprintf(stderr, "usage: aln_oracle <index_dir> <reads.fq> <header.sam> [--trace] [--limit N] [--stats]\n"); return 1; }
 	bool trace = false, stats = false, print = false;
 	long limit = -1;
+	orc::Params par;
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
 		else if (!strcmp(argv[i], "--stats")) stats = true;
 		else if (!strcmp(argv[i], "--print")) print = true;
 		else if (!strcmp(argv[i], "--limit") && i + 1 < argc) limit = atol(argv[++i]);
+		else if (!strcmp(argv[i], "--score") && i + 1 < argc) {
+			if (sscanf(argv[++i], "%d,%d,%d,%d,%d,%d,%d", &par.match, &par.mismatch, &par.gap_open, &par.gap_ex, &par.gap_open2, &par.gap_ex2, &par.zdrop) != 7) { fprintf(stderr, "--score wants seven integers\n"); return 1; }
+		}
 	}
 	std::vector<std::string> names;
 	if (!orc::read_header_names(argv[3], &names)) { fprintf(stderr, "cannot read %s\n", argv[3]); return 2; }
 	orc::Index idx;
 	std::string err;
 	if (!idx.load(argv[1], names, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 2; }
-	orc::Aligner *a = orc::aligner_create(&idx);
+	orc::Aligner *a = orc::aligner_create(&idx, &par);
 	FILE *fq = fopen(argv[2], "r");
 	if (!fq) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
 	orc::Read r1, r2;

@@ -82,7 +82,7 @@ struct Read {
 };
 
 struct Aligner;
-Aligner *aligner_create(const Index *idx);
+Aligner *aligner_create(const Index *idx, const Params *par = nullptr);
 void aligner_destroy(Aligner *);
 // processes one pair exactly as align_read_pair does (read_realignment.cpp:750-767) and returns the
 // record line the reference harness prints for it

@@ -33,13 +33,15 @@ def golden_lines(name, rname):
         return [l for l in f.read().split("\n") if l]
 
 
-def run_oracle(name, rname, trace=True, limit=None):
+def run_oracle(name, rname, trace=True, limit=None, score=None):
     w = workdir(name)
     cmd = [ORACLE_EXE, os.path.join(golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
     if trace:
         cmd.append("--trace")
     if limit:
         cmd += ["--limit", str(limit)]
+    if score:
+        cmd += ["--score", ",".join(str(x) for x in score)]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, check=True).stdout.decode()
     return [l.strip() for l in out.split("\n") if l.strip()]
 

@@ -81,3 +81,25 @@ def test_gpu_cli_bam_output_equals_sam_text():
         assert len(recs) == len(sam) and (stem == "ori" or len(sam) > 100)
         for a, b in zip(sam, recs):
             assert a == b, "\nsam: %s\nbam: %s" % ("\t".join(a), "\t".join(b))
+
+
+@pytest.mark.parametrize("score", [(3, 9, 12, 2, 24, 1, 200), (1, 4, 6, 1, 20, 0, 50), (2, 30, 40, 3, 60, 2, 400)])
+def test_gpu_cli_scoring_options_match_oracle(score):
+    """-M -m -O -E -P -F -z: the engine against the CPU restatement run with the same options (the reference objects behind the
+    golden records only ran the defaults).  The third set leaves the int8-safe regime, so its DP goes through the wavefront
+    kernels instead of the team kernel."""
+    name, rname = "fx2", "reads150"
+    w = ac.workdir(name)
+    tmp = tempfile.mkdtemp(prefix="psvr_score_")
+    rec = os.path.join(tmp, "records.jsonl")
+    M, m, O, E, P, F, z = score
+    cmd = [CLI, "aln", "-S", "-M", str(M), "-m", str(m), "-O", str(O), "-E", str(E), "-P", str(P), "-F", str(F), "-z", str(z), "-o", os.path.join(tmp, "o.sam"), "-p",
+           os.path.join(tmp, "p.sam"), "--records", rec, "--trace", os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = [normalise(l) for l in open(rec).read().split("\n") if l.strip()]
+    want = [normalise(l) for l in ac.run_oracle(name, rname, trace=True, score=score)]
+    assert len(got) == len(want)
+    bad = [i for i, (a, b) in enumerate(zip(want, got)) if a != b]
+    assert not bad, "%d/%d pairs differ; first %d:\norc: %s\ngpu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
+    assert got != [normalise(l) for l in ac.golden_lines(name, rname)]        # the options really changed the results
