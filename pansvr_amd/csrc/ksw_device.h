@@ -70,7 +70,10 @@ template <int LANES> __global__ void extd2_team_kernel(DpBatch B, DpParams P, Te
 // the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 // lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips
-__host__ __device__ inline int dp_team_lanes(int n_strips16) { return 4; }
+#ifndef PSVR_DP_TEAM_LANES
+#define PSVR_DP_TEAM_LANES 4      /* 2 (8-column strips, 32 alignments per wavefront) wastes less of the diagonal ramps but leaves too few wavefronts on the bench workload: 5.7 vs 4.9 ms */
+#endif
+__host__ __device__ inline int dp_team_lanes(int n_strips16) { return PSVR_DP_TEAM_LANES; }
 // scratch bytes one wavefront of the team kernel needs for alignments with at most qmax query bases in that class
 __host__ __device__ inline unsigned long long dp_team_ws_bytes(int qmax, int n_strips16, int lanes)
 {

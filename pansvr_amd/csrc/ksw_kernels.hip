@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 			}
 			// team maximum (butterfly inside the quad, then across the two quads of an 8-lane team)
 			best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0xB1, 0xf, 0xf, false));
-			best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x4E, 0xf, 0xf, false));
+			if (LANES >= 4) best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x4E, 0xf, 0xf, false));
 			if (LANES == 8) best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x141, 0xf, 0xf, false));
 			if (with_cigar) PD[(size_t)(s * R + k) * 64] = dw;
 			if (ql == LANES - 1 && s + 1 < ns) Eout[(size_t)r * PB] = (uint32_t)(V[3] & 0xff) | (uint32_t)(X[3] & 0xff) << 8 | (uint32_t)(X2[3] & 0xff) << 16;
@@ -691,6 +691,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 	write_ez(out, ez, n_cigar);
 }
 template __global__ void extd2_team_kernel<4>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_kernel<2>(DpBatch, DpParams, TeamPlan);
 
 // ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image

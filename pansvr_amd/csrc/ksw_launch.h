@@ -51,11 +51,14 @@ struct TeamLaunch {
 	{
 		const int c = T.n_classes++;
 		T.n_strips16[c] = n_strips16, T.first_slot[c] = first_slot, T.count[c] = count;
-		T.first_block[c + 1] = T.first_block[c] + (int)((count + 15) / 16);
+		const int pb = 64 / dp_team_lanes(n_strips16);
+		T.first_block[c + 1] = T.first_block[c] + (int)((count + pb - 1) / pb);
 	}
 	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
 	{
-		if (T.n_classes) hipLaunchKernelGGL(extd2_team_kernel<4>, dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		if (!T.n_classes) return;
+		if (dp_team_lanes(1) == 2) hipLaunchKernelGGL(extd2_team_kernel<2>, dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		else hipLaunchKernelGGL(extd2_team_kernel<4>, dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
 	}
 };
 // the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
