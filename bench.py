@@ -57,6 +57,7 @@ def main():
             local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
     # the engine library, the CLI (its `index` sub-command builds the bench index) and the checkers: built here if the tree is a
     # fresh checkout (no-ops otherwise); one rank builds, the others wait
     if rank == 0:
@@ -65,7 +66,6 @@ def main():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     if world > 1:
         dist.barrier()
-    torch.cuda.set_device(local_rank)
     xdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else None
 
     import bench_data
