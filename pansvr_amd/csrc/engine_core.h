@@ -380,6 +380,8 @@ template <class BE> struct EngineCore {
 	// ---- one full run of the uploaded batch (rand state is NOT advanced: call commit() for that)
 	struct Win { int32_t pair; long long eval_off; int32_t eval_tot; std::vector<long long> off; std::vector<int32_t> tot; };   // window-resolved pair
 	// state of the current batch's resolution, kept so that rebase() can continue from it
+	std::vector<int32_t> w_listed, w_cur_tot, w_res;    // scratch of the host offset walk, kept across iterations
+	std::vector<long long> w_pre, w_cur_off;
 	std::vector<int32_t> h_vsrc, h_sp_idx;            // variant slot -> pair; pairs with variant slots (built by upload())
 	std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
 	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
@@ -483,14 +485,20 @@ template <class BE> struct EngineCore {
 			}   // !skip_eval
 			skip_eval = false;
 			// every host-resolved pair: its last evaluation (offset, total) and the masked prefix in front of it
-			std::vector<int32_t> listed;
-			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
-			for (const Win &w : wins) listed.push_back(w.pair);
-			std::sort(listed.begin(), listed.end());
-			std::vector<long long> pre(listed.size()), cur_off(listed.size());
-			std::vector<int32_t> cur_tot(listed.size()), res(listed.size());
+			// (the kernels go out first: the host builds its lists while they run)
 			be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
 			be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
+			std::vector<int32_t> &listed = w_listed;
+			listed.clear();
+			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
+			if (!wins.empty()) {                              // both parts are ascending: merge instead of sorting 80 k entries again
+				const size_t mid = listed.size();
+				for (const Win &w : wins) listed.push_back(w.pair);
+				std::inplace_merge(listed.begin(), listed.begin() + mid, listed.end());
+			}
+			std::vector<long long> &pre = w_pre, &cur_off = w_cur_off;
+			std::vector<int32_t> &cur_tot = w_cur_tot, &res = w_res;
+			pre.resize(listed.size()), cur_off.resize(listed.size()), cur_tot.resize(listed.size()), res.resize(listed.size());
 			if (!listed.empty()) {
 				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data());
 			}
