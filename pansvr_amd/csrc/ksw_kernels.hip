@@ -494,6 +494,7 @@ template <int LANES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)   // <= 128 VGPRs: the kernel is issue-bound and wants 4 wavefronts per SIMD
 {
 	constexpr int SW = 4 * LANES, PB = 64 / LANES;                   // strip width, alignments per wavefront
+	constexpr int kNone = (int)0x80000000;                           // "no cell yet" in the per-diagonal maximum
 	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
 	int cls = 0;
 	while (cls + 1 < T.n_classes && (int)blockIdx.x >= T.first_block[cls + 1]) ++cls;
@@ -518,15 +519,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 	if (P.skip || bad_shape || base + need > B.ws_cap) { if (ql == 0) write_ez(out, ez, 0); return; }
 	uint8_t *w0 = B.ws + base;
 	const size_t offE = (size_t)256 * n_strips * R;
-	uint32_t *PD = (uint32_t *)w0 + lane;                             // strip s, step k at [(s * R + k) * 64]
-	uint32_t *E[2] = {(uint32_t *)(w0 + offE) + team, (uint32_t *)(w0 + offE + (size_t)8 * PB * NR) + team};   // diagonal r at [r * PB] (8 bytes per entry are reserved: the CIGAR is staged here later)
-	int *D = (int *)(w0 + offE + (size_t)16 * PB * NR) + team, *D2 = D + (size_t)PB * NR, *D3 = D2 + (size_t)PB * NR;
+	// Every scratch address is a wave-uniform base (scalar registers) plus a constant 32-bit lane offset, so a step spends no
+	// vector instruction on addresses: direction dwords of strip s, step k at [(s * R + k) * 64 + lane]; strip-boundary values
+	// (8 bytes) and the per-diagonal records D, D2, D3 (4 bytes) of diagonal r at [r * PB + team].
+	uint8_t *const uE0 = w0 + offE, *const uE1 = w0 + offE + (size_t)8 * PB * NR;
+	uint8_t *const uD = w0 + offE + (size_t)16 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
+	const unsigned l4 = 4u * (unsigned)lane, t4 = 4u * (unsigned)team, t8 = 8u * (unsigned)team;
+	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
+	auto at8 = [=](uint8_t *ub, int r) -> uint2 & { return *(uint2 *)(ub + (size_t)r * (8 * PB) + t8); };
 	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
-	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
-	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	const int n_rows = qlen + tlen - 1;
-	auto ur_of = [&](int r) { return r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2); };
+	// All difference values are kept times 8, and the five candidates of a cell carry their priority in the low three bits
+	// (sc 4, a 3, b 2, a2 1, b2 0: the first of {sc,a,b,a2,b2} that reaches the maximum wins, :176-213), so one max3 pair
+	// yields both z and the direction; x / y / x2 / y2 live with their tag added so that a candidate is a single add.
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int x_init = 8 * neg_qe + 3, y_init = 8 * neg_qe + 2, x2_init = 8 * neg_qe2 + 1, y2_init = 8 * neg_qe2;
+	const int mch_t = 8 * P.sc_mch + 4, mis_t = 8 * P.sc_mis + 4, scN_t = 8 * P.sc_N + 4, z_cap = 8 * P.sc_mch + 7;
+	const int q_m8 = 8 * P.q - 8, q2_m8 = 8 * P.q2 - 8;               // a - (z - q) > 0  <=>  tagged difference - 8 >= 0
+	const int cx = 8 - 8 * s8(P.q + P.e), cx2 = 8 - 8 * s8(P.q2 + P.e2);
+	const int long_thres = P.long_thres, ur_short = s8(-P.e), ur_at = s8(P.long_diff), ur_long = s8(-P.e2), m1 = P.m1;
+	auto ur_of = [=](int r) { return r == 0 ? neg_qe : r < long_thres ? ur_short : r == long_thres ? ur_at : ur_long; };
 	// H is tracked by vertical steps only, H(i,t) = H(i-1,t) + v(i,t).  The reference takes a horizontal step for the last
 	// in-band cell of a diagonal (:322), which is the same number: both deltas come from one z.  For the top row that needs the
 	// value "above" it: -qe for column 0 (the reference's H[0] = v - qe at r == 0, :351), then the boundary u of every column
@@ -541,109 +554,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 		return h;
 	};
 	const int ns = (tlen + SW - 1) / SW;
-	for (int s = 0; s < ns; ++s) {
+	for (int sv = 0; sv < ns; ++sv) {
+		const int s = uni(sv);                                          // the wavefront's teams sweep their strips in step: scalar registers for what depends on s and k only
 		const int c0 = SW * s;
 		const int ncols = tlen - c0 < SW ? tlen - c0 : SW;
 		const int jl = tlen - 1 - c0;                                   // the last target column, if it is in this strip (else >= SW)
 		const int jb = 4 * ql;                                          // this lane's first column of the strip
-		int U[4], V[4], X[4], Y[4], X2[4], Y2[4], H[4];
-		unsigned TW = 0;                                              // target codes of this lane's columns, one nibble each
+		int U[4], V[4], X[4], Y[4], X2[4], Y2[4], H[4], TC[4];
+		bool inr[4];                                                  // column inside the target
 #pragma unroll
 		for (int jj = 0; jj < 4; ++jj) {
-			U[jj] = ur_of(c0 + jb + jj);                                // u/y/y2 of the first cell of a column (:153-156)
-			V[jj] = X[jj] = Y[jj] = neg_qe, X2[jj] = Y2[jj] = neg_qe2;
+			U[jj] = 8 * ur_of(c0 + jb + jj);                            // u/y/y2 of the first cell of a column (:153-156)
+			V[jj] = 8 * neg_qe, X[jj] = x_init, Y[jj] = y_init, X2[jj] = x2_init, Y2[jj] = y2_init;
 			H[jj] = h_above(c0 + jb + jj);
-			TW |= (unsigned)(jb + jj < ncols ? (target[c0 + jb + jj] & 15) : 0) << (4 * jj);
+			inr[jj] = jb + jj < ncols;
+			TC[jj] = inr[jj] ? (target[c0 + jb + jj] & 15) : 0;
 		}
-		const uint32_t *Ein = E[(s + 1) & 1];
-		uint32_t *Eout = E[s & 1];
+		uint8_t *const Ein = (s & 1) ? uE0 : uE1, *const Eout = (s & 1) ? uE1 : uE0;
 		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
 		// loaded one step ahead, so the loads have a whole step to arrive
-		uint32_t e_prev = 0;
-		int d_cur = 0;
+		uint2 e_prev = make_uint2(0, 0);
+		int d_cur = kNone;
 		if (s > 0) {
-			e_prev = Ein[(size_t)(c0 - 1) * PB];
-			if (0 <= qlen - 2) d_cur = D[(size_t)c0 * PB];
+			e_prev = at8(Ein, c0 - 1);
+			if (0 <= qlen - 2) d_cur = at4(uD, c0);
 		}
 		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? query[0 - jb] : 0u;   // query[k - jb] for k = 0 (raw byte: masking it here would wait for the load)
 		unsigned W = 0;                                               // query window: nibble jj = query[k - jb - jj]
 		const int ksteps = qlen + ncols - 1;
-		for (int k = 0; k < ksteps; ++k) {
-			const int r = c0 + k;
-			const unsigned q_nxt = (unsigned)(k + 1 - jb) < (unsigned)qlen ? query[k + 1 - jb] : 0u;
-			W = (W << 4) | (q_cur & 15u);
-			const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
-			const int en1 = st0 + (en0 - st0) / 4 * 4;
-			// the column left of this lane's first one: the neighbour lane's last column (old values), or for the team's first lane
-			// column -1 (:142-152) / the previous strip's last column on diagonal r-1
-			int vl = __builtin_amdgcn_update_dpp(0, V[3], 0x111, 0xf, 0xf, false), xl = __builtin_amdgcn_update_dpp(0, X[3], 0x111, 0xf, 0xf, false);
-			int x2l = __builtin_amdgcn_update_dpp(0, X2[3], 0x111, 0xf, 0xf, false);
-			uint32_t e_next = 0;
-			int d_nxt = 0;
-			const int dprev = d_cur;
-			if (s > 0) {
-				e_next = Ein[(size_t)r * PB];
-				if (k + 1 <= qlen - 2) d_nxt = D[(size_t)(r + 1) * PB];      // earlier strips reached that diagonal (their last is c0 + qlen - 2)
-			}
-			if (ql == 0) {
-				if (s > 0) vl = s8(e_prev), xl = s8(e_prev >> 8), x2l = s8(e_prev >> 16);
-				else vl = ur_of(r), xl = neg_qe, x2l = neg_qe2;
-			}
-			const int jq = k - (qlen - 1);                               // column of this step's cell in the last query row
-			unsigned best = 0;
-			uint32_t dw = 0;
-#pragma unroll
-			for (int jj = 3; jj >= 0; --jj) {
-				const int j = jb + jj, t = c0 + j, i = k - j;
-				const bool act = ((unsigned)i < (unsigned)qlen) & (j < ncols);
-				const int xt1 = jj ? X[jj ? jj - 1 : 0] : xl, vt1 = jj ? V[jj ? jj - 1 : 0] : vl, x2t1 = jj ? X2[jj ? jj - 1 : 0] : x2l;
-				const int qc = (int)(W >> (4 * jj)) & 15, tc = (int)(TW >> (4 * jj)) & 15;
-				int sc = tc == qc ? P.sc_mch : P.sc_mis;
-				sc = ((tc == P.m1) | (qc == P.m1)) ? P.sc_N : sc;
-				const int ut = U[jj];
-				int za = xt1 + vt1, zb = Y[jj] + ut, za2 = x2t1 + vt1, zb2 = Y2[jj] + ut;
-				int z = max(max(sc, za), zb);
-				z = max(max(z, za2), zb2);
-				int d = 4;                                               // first of {sc,a,b,a2,b2} that reaches the maximum (:176-213)
-				d = za2 == z ? 3 : d;
-				d = zb == z ? 2 : d;
-				d = za == z ? 1 : d;
-				d = sc == z ? 0 : d;
-				z = min(z, P.sc_mch);
-				const int un = z - vt1, vn = z - ut;
-				const int zq = z - P.q, zq2 = z - P.q2;
-				za -= zq, zb -= zq, za2 -= zq2, zb2 -= zq2;
-				d |= (za > 0 ? 0x08 : 0) | (zb > 0 ? 0x10 : 0) | (za2 > 0 ? 0x20 : 0) | (zb2 > 0 ? 0x40 : 0);
-				const int hn = H[jj] + vn;                               // exact H (:316-351), see h_above
-				const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
-				                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
-				const unsigned key = (unsigned)(hn + 0x4000) << 16 | (0x7fffu - rank);   // larger H first, then the reference's order (:322-349)
-				if (act) {
-					U[jj] = un, V[jj] = vn;
-					X[jj] = max(za, 0) - qe8, Y[jj] = max(zb, 0) - qe8;
-					X2[jj] = max(za2, 0) - qe28, Y2[jj] = max(zb2, 0) - qe28;
-					H[jj] = hn;
-					best = max(best, key);
-					dw |= (uint32_t)d << (8 * jj);
-				}
-			}
-			// team maximum (butterfly inside the quad, then across the two quads of an 8-lane team)
-			best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0xB1, 0xf, 0xf, false));
-			if (LANES >= 4) best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x4E, 0xf, 0xf, false));
-			if (LANES == 8) best = max(best, (unsigned)__builtin_amdgcn_update_dpp(0, (int)best, 0x141, 0xf, 0xf, false));
-			if (with_cigar) PD[(size_t)(s * R + k) * 64] = dw;
-			if (ql == LANES - 1 && s + 1 < ns) Eout[(size_t)r * PB] = (uint32_t)(V[3] & 0xff) | (uint32_t)(X[3] & 0xff) << 8 | (uint32_t)(X2[3] & 0xff) << 16;
-			if (ql == 0) D[(size_t)r * PB] = (int)max(best, (unsigned)dprev);
-			// H at the band ends, for mte / mqe / score: the lane that owns the column writes it (one 4-way select per step)
-			if ((unsigned)(jl - jb) < 4u && (unsigned)(k - jl) < (unsigned)qlen) {            // cell (r - (tlen-1), tlen-1)
-				const int jx = jl - jb;
-				D2[(size_t)r * PB] = jx == 0 ? H[0] : jx == 1 ? H[1] : jx == 2 ? H[2] : H[3];
-			}
-			if ((unsigned)(jq - jb) < 4u && jq < ncols) {                                     // cell (qlen-1, r - qlen + 1)
-				const int jx = jq - jb;
-				D3[(size_t)r * PB] = jx == 0 ? H[0] : jx == 1 ? H[1] : jx == 2 ? H[2] : H[3];
-			}
-			e_prev = e_next, d_cur = d_nxt, q_cur = q_nxt;
+		// one anti-diagonal per iteration, see ksw_team_step.inc
+		const int k_mid = min(SW - 1, ksteps);
+		for (int kv = 0; kv < k_mid; ++kv) {
+			const int k = uni(kv);
+#define TEAM_MASKED 1
+#include "ksw_team_step.inc"
+#undef TEAM_MASKED
+		}
+		for (int kv = k_mid; kv < ksteps; ++kv) {
+			const int k = uni(kv);
+#define TEAM_MASKED 0
+#include "ksw_team_step.inc"
+#undef TEAM_MASKED
 		}
 	}
 	if (ql != 0) return;
@@ -651,17 +602,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 	// the per-diagonal rules, in anti-diagonal order (ksw2_extd2_sse.c:316-351, ksw_apply_zdrop)
 	for (int r = 0; r < n_rows; ++r) {
 		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
-		const unsigned key = (unsigned)D[(size_t)r * PB];
-		const int max_H = (int)(key >> 16) - 0x4000;
-		const unsigned rank = 0x7fffu - (key & 0xffffu);
-		const int max_t = rank == 0 ? en0 : st0 + (int)((rank - 1u) & 4095u);
-		int H_en0 = 0;
-		if (en0 == tlen - 1) {
-			H_en0 = D2[(size_t)r * PB];
-			if (H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
-		}
+		const int key = at4(uD, r);
+		const int max_H = key >> 16;
+		const int H_en0 = at4(uD2, r);
+		const int max_t = H_en0 == max_H ? en0 : st0 + ((0x7fff - (key & 0xffff)) & 4095);
+		if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
 		if (r - st0 == qlen - 1) {
-			const int H_st0 = D3[(size_t)r * PB];
+			const int H_st0 = at4(uD3, r);
 			if (H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
 		}
 		if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) break;
@@ -676,11 +623,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 		if (i0 >= 0 && j0 >= 0) {
 			const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
 			const uint8_t *pb = (const uint8_t *)((uint32_t *)w0 + team * LANES);   // the team's 4 * LANES direction bytes of a step are contiguous
-			uint32_t *stage = (uint32_t *)E[0];                        // <= qlen + tlen ops; the strip-boundary arrays are dead now
+			uint32_t *stage = (uint32_t *)(w0 + offE) + team;         // <= qlen + tlen ops; the strip-boundary arrays are dead now
 			n_cigar = traceback(i0, j0, qlen, tlen, w,
 				[&](int r, int k) {                                     // k counts from the 16-rounded band start of row r, as in the reference
 					const int t = k + (max(0, r - qlen + 1) & ~15), s = t / SW;
-					return (int)pb[(size_t)(s * R + (r - SW * s)) * 256 + (t - SW * s)];
+					const unsigned b = pb[(size_t)(s * R + (r - SW * s)) * 256 + (t - SW * s)], n = ~b;
+					// back to the reference's byte: direction in bits 0-2, "gap extended" for a, b, a2, b2 in bits 3-6
+					return (int)((4u - ((b >> 4) & 7u)) | ((n >> 3) & 1u) << 3 | ((n >> 2) & 1u) << 4 | ((n >> 1) & 1u) << 5 | (n & 1u) << 6);
 				},
 				[&](int k, uint32_t word) { stage[(size_t)k * PB] = word; });
 			uint32_t *dst = B.cigar + out->cigar_off;
