@@ -396,7 +396,7 @@ __device__ __forceinline__ int dp_bucket_of(int kind, int cls, int qlen)
 	if (kind == PSVR_DP_KIND_STRIP) { int qb = (qlen - 1) >> 4; return 256 + cls * 16 + (qb > 15 ? 15 : qb); }
 	return (kind < 0 ? 0 : kind) * PSVR_DP_NUM_LDS_CLASSES + cls;
 }
-__global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny_ok)
+__global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny_ok, int team_ok)
 {
 	__shared__ unsigned int lh[512];
 	__shared__ unsigned int lq[PSVR_DP_NUM_LDS_CLASSES];       // longest query per team-kernel class, aggregated per block
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 		const DpDesc &x = d.desc[i];
 		d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
 		int need;
-		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need, tiny_ok != 0);
+		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need, tiny_ok != 0, team_ok != 0);
 		int cls = 0;
 		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
 		d.plen[i] = (kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
@@ -455,6 +455,20 @@ struct GpuBE {
 	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, pslab, strip_ws;
 	DpParams dpP;
 	bool dp_ready = false;
+	static constexpr long long kTeamMinProblems = 32768;       // below this a round's DP problems go to the wavefront-per-alignment kernels
+	static constexpr int kSide = 4;                            // side streams: the DP kernels of a round are independent of each other
+	hipStream_t side[kSide] = {};
+	hipEvent_t ev_fork = nullptr, ev_join[kSide] = {};
+	bool side_ok = false;
+	bool side_streams()
+	{
+		if (side_ok) return true;
+		if (ev_fork) return false;                                // tried before and failed: stay on the one stream
+		if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
+		for (int i = 0; i < kSide; ++i)
+			if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+		return side_ok = true;
+	}
 
 	// live per-kernel timing with HIP events on the launch stream (bench.py's roofline figure)
 	bool timing = false;
@@ -503,7 +517,15 @@ struct GpuBE {
 		if (n && n <= kPin && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); memcpy(h, pin, n); return; }
 		note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream));
 	}
-	~GpuBE() { if (pin) (void)hipHostFree(pin); }
+	~GpuBE()
+	{
+		if (pin) (void)hipHostFree(pin);
+		for (int i = 0; i < kSide; ++i) {
+			if (side[i]) (void)hipStreamSynchronize(side[i]), (void)hipStreamDestroy(side[i]);
+			if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+		}
+		if (ev_fork) (void)hipEventDestroy(ev_fork);
+	}
 	void fill_i64(long long *p, long long n, int stride, int off, long long v)
 	{
 		if (n) hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, stride, off, v);
@@ -664,7 +686,9 @@ struct GpuBE {
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
 		pd.hist = plan_hist.as<unsigned long long>(), pd.idx = plan_idx.as<int32_t>(), pd.ez = d.ez;
 		PSVR_HIP(hipMemsetAsync(d.qlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(d.tlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(pd.plen + n, 0, 4, stream));
-		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200, dp_tiny_ok(dpP, true) ? 1 : 0);
+		// a round with few problems (the re-runs after the first) cannot fill the chip at 16 alignments per wavefront: its time would be one
+		// wavefront's strips x (qlen + 15) steps; a wavefront per alignment needs qlen + tlen steps
+		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200, dp_tiny_ok(dpP, true) ? 1 : 0, n >= kTeamMinProblems ? 1 : 0);
 		st_scan((const int32_t *)d.qlen, n + 1, 1, 0, 0ll, d.q_off);
 		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
 		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
@@ -724,16 +748,35 @@ struct GpuBE {
 		B.ws = (uint8_t *)strip_ws.p, B.ws_top = plan_hist.as<unsigned long long>() + 1040, B.ws_cap = ws_bytes;   // the top counter was zeroed with the histograms
 		B.err = c.err;
 		TeamLaunch team;
+		size_t n_other = 0;
 		for (const Launch3 &L : ls) {
-			if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds) + 1, L.first, L.count); continue; }
+			if (L.kind == PSVR_DP_KIND_STRIP) team.add(dp_class_of(L.lds) + 1, L.first, L.count);
+			else ++n_other;
+		}
+		// The launches of a round work on disjoint problems, and all but the team kernel's are short of wavefronts (the thread-per-alignment
+		// kernel: a few hundred that run for ~0.1 ms each): they are dealt to side streams and run beside each other and beside the team
+		// kernel.  Not while kernels are being timed.
+		const bool fan = !timing && n_other + (team.T.n_classes ? 1 : 0) > 1 && side_streams();
+		int used = 0;
+		if (fan) PSVR_HIP(hipEventRecord(ev_fork, stream));
+		for (const Launch3 &L : ls) {
+			if (L.kind == PSVR_DP_KIND_STRIP) continue;
+			hipStream_t s2 = stream;
+			if (fan) {
+				const int k = used % kSide;
+				if (used < kSide) PSVR_HIP(hipStreamWaitEvent(side[k], ev_fork, 0));
+				s2 = side[k], ++used;
+			}
 			B.idx = plan_idx.as<int32_t>() + L.first;
 			t0(dp_kind_name(L.kind, 0));
-			dp_launch_kind(L.kind, 0, (unsigned)L.count, L.lds, stream, B, dpP);
+			dp_launch_kind(L.kind, 0, (unsigned)L.count, L.lds, s2, B, dpP);
 			t1();
 			PSVR_HIP(hipGetLastError());
 		}
+		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipEventRecord(ev_join[k], side[k]));
 		B.idx = plan_idx.as<int32_t>();
 		if (team.T.n_classes) { t0("extd2_team_kernel"); team.launch(stream, B, dpP); t1(); PSVR_HIP(hipGetLastError()); }
+		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipStreamWaitEvent(stream, ev_join[k], 0));
 		return PSVR_OK;
 	}
 	struct Launch3 { int kind, lds; long long first, count; };

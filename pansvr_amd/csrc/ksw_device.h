@@ -122,13 +122,15 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 // kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM),
 // 11 = extd2_tiny_kernel (one thread per alignment; *need = 512 x anti-diagonals, which bins the problems by size),
 // 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
-__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool tiny_ok = false)
+__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool tiny_ok = false, bool team_ok = true)
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
 	if (PSVR_DP_USE_TINY && tiny_ok && qlen <= PSVR_DP_TINY_MAX && tlen <= PSVR_DP_TINY_MAX) { *need = (qlen + tlen - 1) * 512; return PSVR_DP_KIND_TINY; }
 	// one thread per alignment, 16-column strips in registers: whenever the band never clips the matrix (the lean regime).
 	// The size class is the number of strips (1..13), expressed through `need` as that class's byte threshold.
-	if (tiny_ok && dp_band_never_binds(qlen, tlen, w < 0 ? (qlen > tlen ? qlen : tlen) : w) && tlen <= PSVR_DP_STRIP * PSVR_DP_NUM_LDS_CLASSES) {
+	// (team_ok = false: a batch too small to fill the chip with 16 alignments per wavefront goes to the wavefront-per-alignment kernels,
+	// whose sweep is qlen + tlen steps instead of strips x (qlen + 15))
+	if (tiny_ok && team_ok && dp_band_never_binds(qlen, tlen, w < 0 ? (qlen > tlen ? qlen : tlen) : w) && tlen <= PSVR_DP_STRIP * PSVR_DP_NUM_LDS_CLASSES) {
 		*need = dp_lds_class_bytes((tlen + PSVR_DP_STRIP - 1) / PSVR_DP_STRIP - 1);
 		return PSVR_DP_KIND_STRIP;
 	}

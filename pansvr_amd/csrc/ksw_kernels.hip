@@ -491,7 +491,10 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 // its alignments, which the planner keeps similar by binning on the strip count).  ~85 vector instructions per cell and
 // lane, i.e. ~1.5 wavefront instructions per cell instead of ~7.
 template <int LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)   // <= 128 VGPRs: the kernel is issue-bound and wants 4 wavefronts per SIMD
+#ifndef PSVR_TEAM_WAVES
+#define PSVR_TEAM_WAVES 4          /* wavefronts per SIMD the register allocation aims at (4 = 128 VGPRs) */
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
 	constexpr int SW = 4 * LANES, PB = 64 / LANES;                   // strip width, alignments per wavefront
 	constexpr int kNone = (int)0x80000000;                           // "no cell yet" in the per-diagonal maximum

@@ -83,8 +83,10 @@ struct CpuBE {
 		for (long long i = 0; i < n; ++i) { const DpDesc &x = c.dp.base[d.begin + i]; qb += x.qlen, tb += x.tlen; }
 		if (!core.ensure_dp(n, qb, tb, qb + tb + 2 * n)) return PSVR_ERR_NOMEM;
 		long long qo = 0, to = 0;
+		static FILE *shapes = getenv("EMU_DP_SHAPES") ? fopen(getenv("EMU_DP_SHAPES"), "w") : nullptr;   // one "qlen tlen" line per DP problem, for tools/team_fill.py
 		for (long long i = 0; i < n; ++i) {
 			const DpDesc &x = c.dp.base[d.begin + i];
+			if (shapes) fprintf(shapes, "%d %d\n", x.qlen, x.tlen);
 			d.qlen[i] = x.qlen, d.tlen[i] = x.tlen, d.q_off[i] = qo, d.t_off[i] = to;
 			dp_fetch_one(c, x, d.qbuf + qo, d.tbuf + to);
 			orc_extz_t ez;
