@@ -603,19 +603,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	if (ql != 0) return;
 	__threadfence_block();                                            // the other lanes' D2/D3 stores
 	// the per-diagonal rules, in anti-diagonal order (ksw2_extd2_sse.c:316-351, ksw_apply_zdrop)
-	for (int r = 0; r < n_rows; ++r) {
-		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
-		const int key = at4(uD, r);
-		const int max_H = key >> 16;
-		const int H_en0 = at4(uD2, r);
-		const int max_t = H_en0 == max_H ? en0 : st0 + ((0x7fff - (key & 0xffff)) & 4095);
-		if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
-		if (r - st0 == qlen - 1) {
-			const int H_st0 = at4(uD3, r);
-			if (H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
+	// (the records are fetched eight diagonals at a time: one lane per alignment walks them, and a load per iteration would cost a
+	// memory round trip each)
+	bool stop = false;
+	for (int r0 = 0; r0 < n_rows && !stop; r0 += 8) {
+		int kd[8], h2[8], h3[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int r = min(r0 + u, n_rows - 1);
+			kd[u] = at4(uD, r), h2[u] = at4(uD2, r), h3[u] = at4(uD3, r);   // D3 holds a value only where the last query row meets the diagonal
 		}
-		if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) break;
-		if (r == n_rows - 1) ez.score = H_en0;                           // en0 == tlen - 1 on the last diagonal
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int r = r0 + u;
+			if (r >= n_rows || stop) continue;
+			const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
+			const int key = kd[u];
+			const int max_H = key >> 16;
+			const int H_en0 = h2[u];
+			const int max_t = H_en0 == max_H ? en0 : st0 + ((0x7fff - (key & 0xffff)) & 4095);
+			if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
+			if (r - st0 == qlen - 1 && h3[u] > ez.mqe) ez.mqe = h3[u], ez.mqe_t = st0;
+			if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) stop = true;
+			else if (r == n_rows - 1) ez.score = H_en0;                      // en0 == tlen - 1 on the last diagonal
+		}
 	}
 	int n_cigar = 0;
 	if (with_cigar) {
