@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kBlock) void k_pair(Ctx c, const int32_t *work, lon
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) pair_reads(c, pair_of(work, i));
 }
-// compaction of the dirty pairs into the two work lists; one global atomic per list and workgroup
+// compaction of the dirty pairs into the two work lists; one LDS atomic per list and wavefront (ranks inside it from a ballot), one
+// global atomic per list and workgroup
 __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt,
                                                   int32_t *outp, unsigned long long *cntp)
 {
@@ -247,9 +248,14 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 	__syncthreads();
 	long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	int d = p < c.n_pairs ? mark_dirty(c, p, noff, nhoff) : 0;
-	unsigned int me = 0;
-	if (d == 2) me = atomicAdd(&n_full, 1u);
-	else if (d == 1) me = atomicAdd(&n_pair, 1u);
+	const unsigned long long m2 = __ballot(d == 2), m1 = __ballot(d == 1), below = (1ull << (threadIdx.x & 63)) - 1;
+	unsigned int w2 = 0, w1 = 0;
+	if ((threadIdx.x & 63) == 0) {
+		if (m2) w2 = atomicAdd(&n_full, (unsigned int)__popcll(m2));
+		if (m1) w1 = atomicAdd(&n_pair, (unsigned int)__popcll(m1));
+	}
+	w2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w2), w1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w1);
+	const unsigned int me = d == 2 ? w2 + (unsigned int)__popcll(m2 & below) : w1 + (unsigned int)__popcll(m1 & below);
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		b_full = n_full ? atomicAdd(cnt, (unsigned long long)n_full) : 0;
@@ -516,6 +522,18 @@ struct GpuBE {
 	{
 		if (n && n <= kPin && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); memcpy(h, pin, n); return; }
 		note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream));
+	}
+	// two small readbacks with one synchronisation
+	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2)
+	{
+		if (n1 + n2 <= kPin && pinned()) {
+			note(hipMemcpyAsync(pin, d1, n1, hipMemcpyDeviceToHost, stream));
+			note(hipMemcpyAsync((char *)pin + n1, d2, n2, hipMemcpyDeviceToHost, stream));
+			note(hipStreamSynchronize(stream));
+			memcpy(h1, pin, n1), memcpy(h2, (char *)pin + n1, n2);
+			return;
+		}
+		d2h(h1, d1, n1), d2h(h2, d2, n2);
 	}
 	~GpuBE()
 	{

@@ -488,6 +488,8 @@ template <class BE> struct EngineCore {
 			// (the kernels go out first: the host builds its lists while they run)
 			be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
 			be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
+			be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);          // (do not depend on the walk below: they run while the host works)
+			be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
 			std::vector<int32_t> &listed = w_listed;
 			listed.clear();
 			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
@@ -538,14 +540,11 @@ template <class BE> struct EngineCore {
 			if (!listed.empty()) be.scatter_listed_i32(d_ctot, res.data(), (long long)listed.size());   // same indices as gather_listed
 			// new offsets from the totals; which pairs drew from a stale offset?
 			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
-			be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);
-			be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
 			be.dzero(d_tops + 6, 16);
 			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 6, d_workp, d_tops + 7);
 			unsigned long long nd[2] = {0, 0};
 			int32_t flags[8];
-			be.d2h(nd, d_tops + 6, 16);
-			be.d2h(flags, d_flags, 32);
+			be.d2h2(nd, d_tops + 6, 16, flags, d_flags, 32);
 			if (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5]) { c.stats = stats_ptr; return grow_and_rerun(flags, trace, want_stats, depth); }
 			if (flags[6] == 2 || flags[6] == 3) {      // a rand table ran out: extend and restart the batch
 				be.dzero(d_flags, 32);

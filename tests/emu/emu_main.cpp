@@ -24,6 +24,7 @@ struct CpuBE {
 	void dzero(void *p, size_t n) { memset(p, 0, n); }
 	void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
+	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2) { memcpy(h1, d1, n1), memcpy(h2, d2, n2); }
 	void fill_i64(long long *p, long long n, int stride, int off, long long v) { for (long long i = 0; i < n; ++i) p[off + i * stride] = v; }
 	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
 	void fill_iota(int32_t *p, long long n) { for (long long i = 0; i < n; ++i) p[i] = (int32_t)i; }
