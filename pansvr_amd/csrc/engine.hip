@@ -37,31 +37,41 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
 	if (wi >= n) return;
-	const long long read = pair_of(work, wi) * 2 + mate;
+	const long long slot = pair_of(work, wi), read = slot * 2 + mate;
 	uint8_t *fw = prep_lds + 128 + (size_t)wave * per_wave, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
 	uint64_t *pw = (uint64_t *)(rv + c.lmax);                            // forward strand's packed words (for the STR screen)
 	unsigned int *bits = (unsigned int *)(pw + c.wmax);                  // tsize words: hashed 20-mer set
-	const long long sr = src_read(c, read);
-	const psvr_ori_t o = c.ori[sr];
-	const int L = (int)(c.base_off[sr + 1] - c.base_off[sr]);
-	const long long item = (read >> 1) * 3 + (read & 1);
-	bool unm = o.unmapped != 0 || (uint32_t)o.chr_id > 24u;
-	bool act = !(L > kMaxReadLen || L < kLenKmer) && !(!unm && o.align_score == (uint32_t)(L * c.par.match));
+	// A wavefront's life here is a chain of dependent memory round trips (slot -> source read -> offsets -> bases), not arithmetic: keep the
+	// chain short.  A real pair is its own source (only variant / shadow slots look theirs up), and everything that hangs on `sr` is
+	// requested before anything is used.
+	const long long sr = (c.src && slot >= c.n_pairs) ? (long long)c.src[slot] * 2 + mate : read;
+	const uint32_t *ow = (const uint32_t *)(c.ori + sr);                 // psvr_ori_t as words: chr_id, ref_bg, read_bg, align_score, {mapq, direction, unmapped, -}
+	const uint32_t o_chr = ow[0], o_score = ow[3], o_unm = (ow[4] >> 16) & 0xffu;
+	const long long bo0 = c.base_off[sr], bo1 = c.base_off[sr + 1];
+	const long long p_off = c.poff[slot];
+	const int r_m0 = mate ? c.rcnt[slot * 3] : 0;
+	const int L = (int)(bo1 - bo0);
+	const long long item = slot * 3 + mate;
+	bool unm = o_unm != 0 || o_chr > 24u;
+	bool act = !(L > kMaxReadLen || L < kLenKmer) && !(!unm && o_score == (uint32_t)(L * c.par.match));
 	if (lane == 0) {
 		c.read_l[read] = L, c.unmapped[read] = unm, c.is_str[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
 		if (L > kMaxReadLen) *c.err = 1;
 	}
 	if (lane < 2) { Strand &st = c.strand[read * 2 + lane]; st.mem_n = st.us_n = 0; st.mem_off = st.us_off = 0; st.seed_hash = st.chain_hash = 1469598103934665603ULL; }
 	if (!act) { if (lane == 0) c.rcnt[item] = 0; return; }
-	const char *s = c.bases + c.base_off[sr];
+	const char *s = c.bases + bo0;
 	uint8_t *b0 = c.bin + (read * 2) * (long long)c.lmax, *b1 = b0 + c.lmax;
 	uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
-	const long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0);
+	const long long ro = p_off + r_m0;
 	int draws = 0;
 	bool any4 = false;
-	for (int i0 = 0; i0 < c.lmax; i0 += 64) {
+	// the first 256 bases are requested at once (a load per 64-base round would be a round trip each)
+	char pre[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) pre[u] = 64 * u + lane < L ? s[64 * u + lane] : 'A';
+	auto round = [&](int i0, char ch) {
 		const int i = i0 + lane;
-		char ch = i < L ? s[i] : 'A';
 		const bool isn = i < L && ch == 'N';
 		const unsigned long long m = __ballot(isn);
 		if (isn) {
@@ -77,7 +87,10 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 		if (i < L) fw[i] = code, rv[L - 1 - i] = code ^ 3, b0[i] = code, b1[L - 1 - i] = code ^ 3;
 		else if (i < c.lmax) fw[i] = 0, rv[i] = 0;
 		any4 |= __ballot(i < L && code > 3) != 0;
-	}
+	};
+#pragma unroll
+	for (int u = 0; u < 4; ++u) if (64 * u < c.lmax) round(64 * u, pre[u]);
+	for (int i0 = 256; i0 < c.lmax; i0 += 64) round(i0, i0 + lane < L ? s[i0 + lane] : 'A');
 	if (lane == 0) c.has_n4[read] = any4;
 	__builtin_amdgcn_wave_barrier();
 	// packed words of both strands (binary_read_64_bit, rr.cpp:295-300): word = OR of code << 2*(31 - (i & 31)).  One lane per
