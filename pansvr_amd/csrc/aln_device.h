@@ -151,6 +151,7 @@ struct Ctx {
 	const uint8_t *force;
 	// per read
 	uint8_t *active; uint8_t *unmapped; uint8_t *is_str; uint8_t *has_n4;
+	int32_t *str_list; unsigned int *str_cnt;   // GPU backend: reads whose STR screen was inconclusive (is_str == 2), for the exact count
 	int32_t *read_l;
 	uint8_t *bin;                // [read][2][lmax]
 	uint64_t *rb;                // [read][2][wmax]

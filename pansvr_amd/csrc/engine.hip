@@ -134,7 +134,10 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 		}
 		if (taken < 16) verdict = 0;
 	}
-	if (lane == 0) { c.is_str[read] = (uint8_t)verdict; c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1); }
+	if (lane == 0) {
+		c.is_str[read] = (uint8_t)verdict; c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1);
+		if (verdict == 2) c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;      // a few percent of the reads: k_str_detect runs on these only
+	}
 }
 
 // STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are counted in an open-addressing hash
@@ -144,10 +147,10 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 {
 	extern __shared__ __align__(16) uint8_t str_lds[];
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
-	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
-	if (wi >= n) return;
-	const long long read = pair_of(work, wi) * 2 + mate;
-	if (!c.active[read] || c.is_str[read] != 2) return;      // k_prep's screen has cleared all but a few percent of the reads
+	// the reads k_prep's screen could not clear (a few percent), from its list; the grid is a fixed number of wavefronts
+	const unsigned n_list = *c.str_cnt;
+	for (unsigned e = blockIdx.x * (unsigned)(kBlock / 64) + (unsigned)wave; e < n_list; e += gridDim.x * (unsigned)(kBlock / 64)) {
+	const long long read = c.str_list[e];
 	unsigned long long *key = (unsigned long long *)(str_lds + (size_t)wave * (size_t)per_wave);   // keys | counts | seed_list staging
 	unsigned int *cnt = (unsigned int *)(key + tsize);
 	const unsigned long long EMPTY = ~0ull;               // a 20-mer has 40 significant bits
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 		}
 		distinct += __popcll(__ballot(fresh));
 	}
-	if (!((uint32_t)distinct < (uint32_t)kn - 15u)) { if (lane == 0) c.is_str[read] = 0; return; }
+	if (!((uint32_t)distinct < (uint32_t)kn - 15u)) { if (lane == 0) c.is_str[read] = 0; continue; }
 	// an STR read (rare): per-offset mask, then the begin/end rules, staged in the table's tail
 	uint8_t *sl = (uint8_t *)(cnt + tsize);
 	for (int i = lane; i < kn; i += 64) {
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 	}
 	uint8_t *out = c.seed_list + read * (long long)c.lmax;
 	for (int i = lane; i < kn; i += 64) out[i] = sl[i];
+	}
 }
 // K1 seed_probe + K2 mem_extend: hash gather, bucket search, unipath lookup, MEM extension
 // Each thread first copies its strand's packed words (wmax x 8 B) into LDS -- row pitch an odd number of 8-byte words, so the
@@ -590,6 +594,7 @@ struct GpuBE {
 	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n <= 0) return;
+		dzero(c.str_cnt, 4);
 		t0("k_prep");
 		// the screen's hashed set: 32 bits per word; for reads up to ~270 bp 8 x tsize bits keep the expected number of chance
 		// collisions at kn / 32 (far below the 16 that would send a read to the exact count); longer reads get the full 32 x tsize
@@ -607,7 +612,8 @@ struct GpuBE {
 		const size_t per_wave = (size_t)tsize * 12 + (((size_t)c.lmax + 15) & ~(size_t)15);
 		const size_t lds = (size_t)(kBlock / 64) * per_wave;
 		t0("k_str_detect");
-		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), lds, stream, c, w, n, mate, tsize, (int)per_wave);
+		const long long waves = n < 8192 ? n : 8192;                      // each takes list entries in turn
+		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(waves, kBlock / 64)), dim3(kBlock), lds, stream, c, w, n, mate, tsize, (int)per_wave);
 		t1();
 		note(hipGetLastError());
 	}
