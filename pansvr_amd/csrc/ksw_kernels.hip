@@ -488,8 +488,10 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 // are folded into D[r], D2[r], D3[r] as the strips pass and evaluated in anti-diagonal order afterwards; diagonals past a
 // z-drop are computed but never looked at.  Direction bytes: one dword per lane and step.  Scratch is laid out
 // [index][lane or team] so a wavefront touches consecutive addresses; it bump-allocates it (sized by the longest query among
-// its alignments, which the planner keeps similar by binning on the strip count).  ~85 vector instructions per cell and
-// lane, i.e. ~1.5 wavefront instructions per cell instead of ~7.
+// its alignments, which the planner keeps similar by binning on the strip count).  The kernel is bound by vector issue: see
+// the price list in profiles/r01j_valu_op_rates.txt (add/sub/logic/right shift ~2 cycles, max/min/cmp/three-operand/DPP ~4) --
+// which is why the differences are kept x 8 with the candidate's priority in the low bits (below): ~80 vector instructions per
+// step and column, ~1.3 wavefront instructions per cell instead of ~7 for a wavefront per alignment.
 template <int LANES>
 #ifndef PSVR_TEAM_WAVES
 #define PSVR_TEAM_WAVES 4          /* wavefronts per SIMD the register allocation aims at (4 = 128 VGPRs) */
