@@ -313,14 +313,17 @@ __global__ void k_hoff_shadows(Ctx c, long long P, long long n)
 	for (int k = 0; k < 2; ++k) c.hoff[2 * (P + j) + k] = c.hoff[2 * (long long)c.src[P + j] + k];
 }
 // total draws of the evaluated slots; a real pair whose total changed since its previous evaluation is count-sensitive
-__global__ void k_totals(Ctx c, const int32_t *work, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, int detect)
+// cnt[1] is set when a slot's rand() or random_r draw counts differ from its previous evaluation's
+__global__ void k_totals(Ctx c, const int32_t *work, long long n, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, int detect)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	long long s = pair_of(work, i);
 	int32_t t = c.rcnt[3 * s] + c.rcnt[3 * s + 1] + c.rcnt[3 * s + 2];
+	const int32_t h0 = c.hcnt[2 * s], h1 = c.hcnt[2 * s + 1];
+	if (t != ctot[s] || h0 != hprev[2 * s] || h1 != hprev[2 * s + 1]) cnt[1] = 1;
 	if (detect && s < c.n_pairs && t != ctot[s] && !sens[s]) { sens[s] = 1; slist[atomicAdd(cnt, 1ull)] = (int32_t)s; }
-	ctot[s] = t;
+	ctot[s] = t, hprev[2 * s] = h0, hprev[2 * s + 1] = h1;
 }
 
 // exclusive scan of int32 counts into int64 offsets, three small launches: per-tile sums, scan of the tile sums
@@ -656,9 +659,9 @@ struct GpuBE {
 		hipLaunchKernelGGL(k_scatter_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n);
 	}
 	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n) { if (n) hipLaunchKernelGGL(k_hoff_shadows, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, P, n); }
-	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
+	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
 	{
-		if (n > 0) hipLaunchKernelGGL(k_totals, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, ctot, sens, slist, cnt, detect ? 1 : 0);
+		if (n > 0) hipLaunchKernelGGL(k_totals, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, ctot, hprev, sens, slist, cnt, detect ? 1 : 0);
 		note(hipGetLastError());
 	}
 	void st_assemble(const Ctx &c, long long b, long long e)

@@ -95,6 +95,7 @@ template <class BE> struct EngineCore {
 	long long *d_noff = nullptr, *d_nhoff = nullptr;
 	int32_t *d_work = nullptr, *d_workp = nullptr;   // full re-run list (real pairs then shadow slots) and the pairing-only list
 	int32_t *d_ctot = nullptr, *d_src = nullptr;     // per slot: total draws of the last evaluation; slot -> input pair
+	int32_t *d_hprev = nullptr;                      // per slot x mate: random_r draws of the last evaluation (to see whether a round changed anything)
 	uint8_t *d_sens = nullptr;                       // per pair: known count-sensitive
 	int32_t *d_slist = nullptr;                      // newly detected sensitive pairs
 	char *d_bases = nullptr; long long *d_off = nullptr; psvr_ori_t *d_ori = nullptr;   // the uploaded batch
@@ -245,6 +246,7 @@ template <class BE> struct EngineCore {
 		c.res = alloc<psvr_read_result_t>(RS), c.pres = alloc<psvr_pair_result_t>(S);
 		d_work = alloc<int32_t>(S), d_workp = alloc<int32_t>(P);
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
+		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
 		d_tops = alloc<unsigned long long>(16), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
@@ -405,7 +407,7 @@ template <class BE> struct EngineCore {
 		be.fill_i64(c.poff, S, 1, 0, grand_pos);
 		be.fill_i64(c.hoff, S, 2, 0, hrand_pos[0]);
 		be.fill_i64(c.hoff, S, 2, 1, hrand_pos[1]);
-		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_sens, P), be.dzero(d_mask, P);
+		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_hprev, 2 * S * 4), be.dzero(d_sens, P), be.dzero(d_mask, P);
 		be.fill_iota(d_src, S);
 		c.src = d_src, c.force = d_force;
 		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
@@ -455,11 +457,15 @@ template <class BE> struct EngineCore {
 			if (rc) break;
 			if (npair_only) be.st_pair(c, d_workp, npair_only);
 			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
-			be.dzero(d_tops + 8, 8);
-			be.st_totals(c, work, nfull + nshadow, d_ctot, d_sens, d_slist, d_tops + 8, work != nullptr);
-			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_sens, d_slist, d_tops + 8, true);
-			unsigned long long nnew = 0;
-			be.d2h(&nnew, d_tops + 8, 8);
+			be.dzero(d_tops + 8, 16);
+			be.st_totals(c, work, nfull + nshadow, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);
+			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, true);
+			unsigned long long nnew_chg[2] = {0, 0};           // newly count-sensitive pairs; did any evaluated slot draw a different number than last time?
+			be.d2h(nnew_chg, d_tops + 8, 16);
+			const unsigned long long nnew = nnew_chg[0];
+			// A re-run round in which every slot drew exactly as often as at its previous evaluation leaves every offset where it is: the
+			// streams are consistent, the bookkeeping below would find nothing dirty.
+			if (work != nullptr && nnew == 0 && nnew_chg[1] == 0 && nshadow == 0 && wins.empty()) break;
 			if (vcnt.empty() && V && work == nullptr) { vcnt.resize(3 * V); be.d2h(vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
 			// window tables of the pairs evaluated with offset shadows this round
 			if (nshadow > 0) {

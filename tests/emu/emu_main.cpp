@@ -51,13 +51,15 @@ struct CpuBE {
 	{
 		for (long long i = 0; i < 2 * n; ++i) walk_read(c, pr(w, i >> 1) * 2 + (i & 1));
 	}
-	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
+	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
 	{
 		for (long long i = 0; i < n; ++i) {
 			long long s = pr(w, i);
 			int32_t t = c.rcnt[3 * s] + c.rcnt[3 * s + 1] + c.rcnt[3 * s + 2];
+			const int32_t h0 = c.hcnt[2 * s], h1 = c.hcnt[2 * s + 1];
+			if (t != ctot[s] || h0 != hprev[2 * s] || h1 != hprev[2 * s + 1]) cnt[1] = 1;
 			if (detect && s < c.n_pairs && t != ctot[s] && !sens[s]) sens[s] = 1, slist[(*cnt)++] = (int32_t)s;
-			ctot[s] = t;
+			ctot[s] = t, hprev[2 * s] = h0, hprev[2 * s + 1] = h1;
 		}
 	}
 	void st_assemble(const Ctx &c, long long b, long long e) { for (long long i = b; i < e; ++i) assemble_candidate(c, i); }
