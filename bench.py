@@ -223,7 +223,7 @@ def main():
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank, %d iteration(s)/step" % (max(exchange_iters) if exchange_iters else 0)),
                                                  "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "pcie_inclusive": pcie,
-                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
+                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)
     eng.close()

@@ -1267,6 +1267,25 @@ PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, cons
 	return dirty;
 }
 
+// A pair with N bases takes over the records of the variant slot that was evaluated with exactly the residues its draws yield
+// (engine_core.h: only when that slot drew nothing else, so its result does not depend on where in the stream it stands).
+// `part` of `parts` workers copy the two read records word by word; worker 0 also moves the counters and the offset.
+// Declined (nothing touched) when the slot sampled positions with random_r: that result depends on the other streams' offsets.
+PSVR_HD void adopt_variant(const Ctx &c, long long pair, long long slot, const long long *noff, int part, int parts)
+{
+	if (c.hcnt[2 * slot] != 0 || c.hcnt[2 * slot + 1] != 0) return;
+	const uint32_t *src = (const uint32_t *)(c.res + 2 * slot);
+	uint32_t *dst = (uint32_t *)(c.res + 2 * pair);
+	const int nw = (int)(2 * sizeof(psvr_read_result_t) / 4);
+	for (int i = part; i < nw; i += parts) dst[i] = src[i];
+	if (part == 0) {
+		c.pres[pair] = c.pres[slot];
+		for (int k = 0; k < 3; ++k) c.rcnt[3 * pair + k] = c.rcnt[3 * slot + k];
+		c.hcnt[2 * pair] = c.hcnt[2 * pair + 1] = 0;
+		c.poff[pair] = noff[pair];                                       // mark_dirty then finds the pair where it belongs
+	}
+}
+
 // materialise the byte sequences of one queued DP problem (get_refseq + the reversal of left extensions,
 // rr.cpp:920-928)
 PSVR_HD void dp_fetch_base(const Ctx &c, const DpDesc &d, int i, uint8_t *q, uint8_t *t)

@@ -282,6 +282,12 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 	if (d == 2) out[b_full + me] = (int32_t)p;
 	else if (d == 1) outp[b_pair + me] = (int32_t)p;
 }
+// one wavefront per adopted pair (adopt_variant in aln_device.h)
+__global__ __launch_bounds__(kBlock) void k_adopt(Ctx c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff)
+{
+	const long long i = blockIdx.x * (long long)(kBlock / 64) + (threadIdx.x >> 6);
+	if (i < n) adopt_variant(c, pairs[i], slots[i], noff, threadIdx.x & 63, 64);
+}
 __global__ void k_fill_i64(long long *p, long long n, int stride, int off, long long v)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -657,6 +663,14 @@ struct GpuBE {
 		note(tmp_val.ensure(n * 4));
 		h2d(tmp_val.p, val, n * 4);
 		hipLaunchKernelGGL(k_scatter_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n);
+	}
+	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff)
+	{
+		if (!n) return;
+		note(tmp_idx.ensure(n * 4)), note(tmp_val.ensure(n * 4));
+		h2d(tmp_idx.p, pairs, n * 4), h2d(tmp_val.p, slots, n * 4);
+		hipLaunchKernelGGL(k_adopt, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, stream, c, (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n, noff);
+		note(hipGetLastError());
 	}
 	void copy_hoff_to_shadows(const Ctx &c, long long P, long long n) { if (n) hipLaunchKernelGGL(k_hoff_shadows, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, P, n); }
 	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
@@ -1061,9 +1075,9 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
 	const RunStats &s = e->core.stats;
 	snprintf(buf, n,
-	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
-	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();

@@ -77,7 +77,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 };
 
 struct RunStats {
-	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0;
+	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0;
 	unsigned long long counters[16] = {0};
 };
 
@@ -389,6 +389,7 @@ template <class BE> struct EngineCore {
 	std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
 	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
 	std::vector<char> is_special;                     // a special pair whose prediction failed falls back to the window method
+	std::vector<int32_t> adopted, adopt_pair, adopt_slot;   // per special pair: the variant slot whose records it carries (-1 none); this walk's new adoptions
 	long long dp_done = 0, cw_done = 0;
 	bool have_run = false;
 
@@ -415,6 +416,7 @@ template <class BE> struct EngineCore {
 		if (!h_sp_idx.empty()) be.scatter_u8(d_mask, h_sp_idx.data(), (long long)h_sp_idx.size(), 1);
 		dp_done = 0, cw_done = 0;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
+		adopted.assign(special.size(), -1), adopt_pair.clear(), adopt_slot.clear();
 		have_run = true;
 		int rc = iterate(trace, want_stats, depth, stats_ptr, false);
 		return rc;
@@ -530,6 +532,12 @@ template <class BE> struct EngineCore {
 						for (int j = 0; j < sp.n2; ++j) code |= (grand.host[t + c1 + j] & 3) << sh2, sh2 += 2;
 						const int32_t *vc = &vcnt[3 * (sp.vslot - P + code)];
 						D = vc[0] + vc[1] + vc[2];
+						// Nothing but the forced residues was drawn in that variant slot: its records ARE this pair's at any offset
+						// (adopted below instead of running the pair again where its draws have moved to)
+						if (vc[0] == sp.n1 && vc[1] == sp.n2 && vc[2] == 0 && adopted[si] != sp.vslot + code) {
+							adopted[si] = sp.vslot + code;
+							adopt_pair.push_back(s), adopt_slot.push_back(sp.vslot + code);
+						}
 					} else if (wi < wins.size() && wins[wi].pair == s) {
 						Win &w = wins[wi];
 						w.eval_off = cur_off[i], w.eval_tot = cur_tot[i];
@@ -547,6 +555,11 @@ template <class BE> struct EngineCore {
 			if (!listed.empty()) be.scatter_listed_i32(d_ctot, res.data(), (long long)listed.size());   // same indices as gather_listed
 			// new offsets from the totals; which pairs drew from a stale offset?
 			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
+			if (!adopt_pair.empty()) {
+				be.st_adopt(c, adopt_pair.data(), adopt_slot.data(), (long long)adopt_pair.size(), d_noff);
+				stats.adopted += (long long)adopt_pair.size();
+				adopt_pair.clear(), adopt_slot.clear();
+			}
 			be.dzero(d_tops + 6, 16);
 			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 6, d_workp, d_tops + 7);
 			unsigned long long nd[2] = {0, 0};

@@ -78,6 +78,7 @@ struct CpuBE {
 			else if (d == 1) outp[(*cntp)++] = (int32_t)p;
 		}
 	}
+	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff) { for (long long i = 0; i < n; ++i) adopt_variant(c, pairs[i], slots[i], noff, 0, 1); }
 	template <class Core> int st_dp(Core &core)
 	{
 		const Ctx &c = core.c;
