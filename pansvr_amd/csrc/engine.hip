@@ -254,6 +254,15 @@ __global__ __launch_bounds__(kBlock) void k_pair(Ctx c, const int32_t *work, lon
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) pair_reads(c, pair_of(work, i));
 }
+// tail of both reads (finalize_read) and the pairing in one pass: the thread pairs the records it has just written
+__global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *work, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const long long p = pair_of(work, i);
+	finalize_read(c, 2 * p), finalize_read(c, 2 * p + 1);
+	pair_reads(c, p);
+}
 // compaction of the dirty pairs into the two work lists; one LDS atomic per list and wavefront (ranks inside it from a ballot), one
 // global atomic per list and workgroup
 __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt,
@@ -635,6 +644,7 @@ struct GpuBE {
 	PSVR_STAGE(st_walk, k_walk, 2, kBlock)
 	PSVR_STAGE(st_finalize, k_finalize, 2, kBlock)
 	PSVR_STAGE(st_pair, k_pair, 1, kBlock)
+	PSVR_STAGE(st_finalize_pair, k_finalize_pair, 1, kBlock)
 #undef PSVR_STAGE
 	DevBuf tmp_idx, tmp_val, tmp_out;
 	void fill_iota(int32_t *p, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, 0ll, 0ll, n); }

@@ -375,8 +375,7 @@ template <class BE> struct EngineCore {
 		if (cw_end > cw_done) be.st_assemble(c, cw_done, cw_end);
 		stats.dp_problems += dp_end - dp_done, stats.cands += cw_end - cw_done;
 		dp_done = dp_end, cw_done = cw_end;
-		be.st_finalize(c, work, nwork);
-		be.st_pair(c, work, nwork);
+		be.st_finalize_pair(c, work, nwork);       // both reads' tails, then the pairing, by the same worker: the records stay close
 		return PSVR_OK;
 	}
 
