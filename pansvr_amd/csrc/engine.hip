@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 // Each thread first copies its strand's packed words (wmax x 8 B) into LDS -- row pitch an odd number of 8-byte words, so the
 // lanes of a wavefront spread over the banks -- because every probe and every MEM extension re-reads them; lds_pitch == 0
 // (reads too long for the LDS budget) keeps them in global memory.
-__global__ __launch_bounds__(kBlock) void k_seed(Ctx c, const int32_t *work, long long n, int mate, int lds_pitch)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed(Ctx c, const int32_t *work, long long n, int mate, int lds_pitch)
 {
 	extern __shared__ __align__(16) uint64_t seed_lds[];
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
