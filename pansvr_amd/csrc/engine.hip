@@ -445,6 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES) lq[threadIdx.x] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i == 0) d.qlen[d.n] = d.tlen[d.n] = d.plen[d.n] = 0;      // the scans run over n + 1 entries
 	if (i < d.n) {
 		const DpDesc &x = d.desc[i];
 		d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
@@ -546,22 +547,22 @@ struct GpuBE {
 	// small transfers (counters, lists of a few thousand pairs) go through a pinned staging buffer: a copy to or from pageable
 	// memory costs several times the latency
 	void *pin = nullptr;
-	static constexpr size_t kPin = (size_t)4 << 20;
+	static constexpr size_t kPin = (size_t)4 << 20, kPinUse = kPin - 4096;   // the last 4 KB are st_dp's slot for an upload nobody waits for
 	void *pinned() { if (!pin && hipHostMalloc(&pin, kPin, hipHostMallocDefault) != hipSuccess) pin = nullptr; return pin; }
 	void h2d(void *d, const void *h, size_t n)
 	{
-		if (n && n <= kPin && pinned()) { memcpy(pin, h, n); note(hipMemcpyAsync(d, pin, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); return; }
+		if (n && n <= kPinUse && pinned()) { memcpy(pin, h, n); note(hipMemcpyAsync(d, pin, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); return; }
 		note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream));
 	}
 	void d2h(void *h, const void *d, size_t n)
 	{
-		if (n && n <= kPin && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); memcpy(h, pin, n); return; }
+		if (n && n <= kPinUse && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); memcpy(h, pin, n); return; }
 		note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream));
 	}
 	// two small readbacks with one synchronisation
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2)
 	{
-		if (n1 + n2 <= kPin && pinned()) {
+		if (n1 + n2 <= kPinUse && pinned()) {
 			note(hipMemcpyAsync(pin, d1, n1, hipMemcpyDeviceToHost, stream));
 			note(hipMemcpyAsync((char *)pin + n1, d2, n2, hipMemcpyDeviceToHost, stream));
 			note(hipStreamSynchronize(stream));
@@ -656,7 +657,7 @@ struct GpuBE {
 		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 20 + 16));
 		h2d(tmp_idx.p, idx, n * 4);
 		hipLaunchKernelGGL(k_gather_listed, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, b, cc, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
-		if ((size_t)n * 20 <= kPin && pinned()) {
+		if ((size_t)n * 20 <= kPinUse && pinned()) {
 			note(hipMemcpyAsync(pin, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
 			note(hipStreamSynchronize(stream));
 			memcpy(oa, pin, n * 8), memcpy(ob, (char *)pin + n * 8, n * 8), memcpy(oc, (char *)pin + n * 16, n * 4);
@@ -749,7 +750,6 @@ struct GpuBE {
 		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
 		pd.hist = plan_hist.as<unsigned long long>(), pd.idx = plan_idx.as<int32_t>(), pd.ez = d.ez;
-		PSVR_HIP(hipMemsetAsync(d.qlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(d.tlen + n, 0, 4, stream)); PSVR_HIP(hipMemsetAsync(pd.plen + n, 0, 4, stream));
 		// a round with few problems (the re-runs after the first) cannot fill the chip at 16 alignments per wavefront: its time would be one
 		// wavefront's strips x (qlen + 15) steps; a wavefront per alignment needs qlen + tlen steps
 		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200, dp_tiny_ok(dpP, true) ? 1 : 0, n >= kTeamMinProblems ? 1 : 0);
@@ -798,7 +798,9 @@ struct GpuBE {
 			if (team_cnt[cls]) ls.push_back(Launch3{PSVR_DP_KIND_STRIP, dp_lds_class_bytes(cls), acc, (long long)team_cnt[cls]});
 			for (int qb = 15; qb >= 0; --qb) bstart[256 + cls * 16 + qb] = acc, acc += (long long)hist[256 + cls * 16 + qb];
 		}
-		h2d(plan_bstart.p, bstart, 512 * 8);
+		// no wait for this upload: the staging slot (last 4 KB of the pinned buffer) is not written again before the round's later synchronisations
+		if (pinned()) { memcpy((char *)pin + kPin - 4096, bstart, 512 * 8); PSVR_HIP(hipMemcpyAsync(plan_bstart.p, (char *)pin + kPin - 4096, 512 * 8, hipMemcpyHostToDevice, stream)); }
+		else h2d(plan_bstart.p, bstart, 512 * 8);
 		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
 		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
 		t0("k_dp_fetch");
