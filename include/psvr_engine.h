@@ -35,6 +35,12 @@ extern "C" {
 const char *psvr_last_error(void);
 /* number of visible HIP devices; <0 on error.  Never falls back to a CPU path. */
 int psvr_device_count(void);
+/* Page-locked host memory for the buffers handed to psvr_engine_upload / psvr_engine_download / psvr_engine_align_batch
+ * (optional: any host memory works, page-locked memory moves at the link's rate instead of a third of it).  The reference
+ * side keeps its read / record buffers alive across batches (Classify_buff_pool, read_realignment.hpp:324-345): allocate
+ * them once with these.  NULL on failure (psvr_last_error says why). */
+void *psvr_host_alloc(size_t bytes);
+void psvr_host_free(void *p);
 
 /* ------------------------------------------------------------------------------------------
  * Seam B2: batched banded DP.  Field-for-field ksw_extz_t (src/kswlib/ksw2.h:26-35); the

@@ -318,9 +318,28 @@ int main(int argc, char **argv)
 	psvr_engine_t *eng = nullptr;
 	// classify_pipeline's three overlapped steps (rr.cpp:100-131, kt_pipeline): load_reads | align | output_results.  Three job
 	// slots cycle through the stages in input order, so the output order is the input order.
+	// The record buffers live as long as their job slot (like the reference's Classify_buff_pool) and are page-locked when the
+	// library can provide that: 1.3 GB of fixed-size records per 1 M pairs come back at the link's rate instead of a third of it.
+	struct HostBuf {
+		void *p = nullptr; size_t cap = 0; bool locked = false;
+		void *reserve(size_t bytes)
+		{
+			if (bytes <= cap) return p;
+			release();
+			const size_t want = bytes + bytes / 8;
+			if ((p = psvr_host_alloc(want))) locked = true;
+			else if (!(p = malloc(want))) { fprintf(stderr, "[panSVR-amd] out of host memory\n"); abort(); }
+			cap = want;
+			return p;
+		}
+		void release() { if (p) { if (locked) psvr_host_free(p); else free(p); } p = nullptr, cap = 0, locked = false; }
+		~HostBuf() { release(); }
+	};
 	struct Job {
 		std::vector<FqRec> recs; std::vector<char> bases; std::vector<long long> base_off; std::vector<psvr_ori_t> ori;
-		std::vector<psvr_read_result_t> res; std::vector<psvr_pair_result_t> pres; std::vector<uint32_t> cig;
+		HostBuf res_buf, cig_buf;
+		psvr_read_result_t *res = nullptr; uint32_t *cig = nullptr;
+		std::vector<psvr_pair_result_t> pres;
 		long long pair_base = 0;
 		int state = 0;              // 0 free, 1 loaded, 2 aligned
 		bool last = false;          // end-of-input marker travelling through the stages
@@ -363,7 +382,7 @@ int main(int argc, char **argv)
 		if (frec) {
 			for (long long p = 0; p < P; ++p) {
 				int lens[2] = {(int)J.recs[2 * p].seq.size(), (int)J.recs[2 * p + 1].seq.size()};
-				fprintf(frec, "%s\n", record_json(J.pair_base + p, &J.res[2 * p], J.pres[p], &J.ori[2 * p], lens, J.cig.data(), o.trace).c_str());
+				fprintf(frec, "%s\n", record_json(J.pair_base + p, &J.res[2 * p], J.pres[p], &J.ori[2 * p], lens, J.cig, o.trace).c_str());
 			}
 		}
 		// ---- step 2: records (output_BAM, rr.cpp:479-536), formatted for runs of pairs on -t threads and written in input order
@@ -390,7 +409,7 @@ int main(int argc, char **argv)
 				} else {
 					const psvr_cand_t &cd = rr.cand[rr.primary];
 					chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
-					cg = cigar_string(cd, J.cig.data());
+					cg = cigar_string(cd, J.cig);
 				}
 				if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
 				int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
@@ -488,13 +507,13 @@ int main(int argc, char **argv)
 			if (psvr_engine_create(idx, &par, &eng)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
 		}
 		const long long P = J.n_pairs(), R = 2 * P;
-		J.res.resize(R), J.pres.resize(P);
+		J.res = (psvr_read_result_t *)J.res_buf.reserve((size_t)R * sizeof(psvr_read_result_t)), J.pres.resize(P);
 		int rc = psvr_engine_upload(eng, P, J.bases.data(), (const int64_t *)J.base_off.data(), J.ori.data());
 		if (!rc) rc = psvr_engine_run(eng, o.trace ? 1 : 0, nullptr);
 		int64_t used = 0;
 		if (!rc) { rc = psvr_engine_download(eng, nullptr, nullptr, nullptr, 0, &used); if (rc == PSVR_ERR_OVERFLOW) rc = 0; }
-		J.cig.resize(used + 1);
-		if (!rc) rc = psvr_engine_download(eng, J.res.data(), J.pres.data(), J.cig.data(), (int64_t)J.cig.size(), &used);
+		J.cig = (uint32_t *)J.cig_buf.reserve((size_t)(used + 1) * 4);
+		if (!rc) rc = psvr_engine_download(eng, J.res, J.pres.data(), J.cig, used + 1, &used);
 		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
 		t_engine += walltime() - tw;
 		set_state(J, 2);

@@ -87,6 +87,14 @@ struct psvr_dp_plan {
 
 
 extern "C" const char *psvr_last_error(void) { return last_error_ref().c_str(); }
+extern "C" void *psvr_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+	if (e != hipSuccess) { set_error(PSVR_ERR_NOMEM, "psvr_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+	return p;
+}
+extern "C" void psvr_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int psvr_device_count(void)
 {
