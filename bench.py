@@ -143,6 +143,18 @@ def main():
             "h2d_bytes": int(bases.nbytes + base_off.nbytes + ori.nbytes), "d2h_bytes": int(sum(a.nbytes for a in out_host)),
             "note": "upload (pageable host memory) + run + download of one batch through psvr_engine_upload/run/download; not `value`"}
     del out_host
+    # the same with result buffers a pipeline slot keeps page-locked across batches (psvr_host_alloc; allocated before the clock starts)
+    hb = aln.HostBuffers()
+    eng.download_into(hb)
+    torch.cuda.synchronize()
+    tp = time.time()
+    eng.upload(bases, base_off, ori)
+    eng.set_stream_pos([2, 0, 0])
+    eng.run()
+    eng.download_into(hb)
+    tp = time.time() - tp
+    pcie["page_locked_results"] = {"reads_per_s": round(2 * args.pairs / tp, 1), "ms": round(tp * 1e3, 2)}
+    hb.close()
     roofline, cpu, parity = None, None, None
     if rank == 0:
         # algorithmic bytes per read, counted by the oracle on the CPU sample below

@@ -4,7 +4,7 @@ import json
 
 import numpy as np
 
-from ._lib import check, lib
+from ._lib import EngineError, check, lib
 
 ORI_DTYPE = np.dtype([("chr_id", "<i4"), ("ref_bg", "<u4"), ("read_bg", "<u4"), ("align_score", "<u4"),
                       ("mapq", "u1"), ("direction", "u1"), ("unmapped", "u1"), ("reserved", "u1")])
@@ -115,7 +115,55 @@ class Engine:
                                          C.c_int64(len(cig)), C.byref(used)))
         return reads, pairs, cig
 
+    def download_into(self, bufs):
+        """Like download(), into the caller's page-locked buffers (HostBuffers): the copies run at the link's rate."""
+        P = self.n_pairs
+        used = C.c_int64(0)
+        rc = lib().psvr_engine_download(self.h, None, None, None, C.c_int64(0), C.byref(used))
+        if rc not in (0, 6):
+            check(rc)
+        reads, pairs, cig = bufs.views(P, int(used.value) + 1)
+        check(lib().psvr_engine_download(self.h, reads.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p),
+                                         C.c_int64(len(cig)), C.byref(used)))
+        return reads, pairs, cig
+
     def close(self):
         if self.h:
             lib().psvr_engine_destroy(self.h)
             self.h = None
+
+
+class HostBuffers:
+    """Page-locked result buffers from psvr_host_alloc, kept across batches (what a pipeline slot of the reference would own)."""
+
+    def __init__(self):
+        self._p = [None, None, None]
+        self._cap = [0, 0, 0]
+
+    def _get(self, i, nbytes):
+        if nbytes > self._cap[i]:
+            L = lib()
+            L.psvr_host_alloc.restype = C.c_void_p
+            L.psvr_host_alloc.argtypes = [C.c_size_t]
+            L.psvr_host_free.argtypes = [C.c_void_p]
+            if self._p[i]:
+                L.psvr_host_free(self._p[i])
+            want = nbytes + nbytes // 8
+            self._p[i] = L.psvr_host_alloc(want)
+            if not self._p[i]:
+                raise EngineError("psvr_host_alloc(%d) failed" % want)
+            self._cap[i] = want
+        return (C.c_char * nbytes).from_address(self._p[i])
+
+    def views(self, n_pairs, n_cig):
+        reads = np.frombuffer(self._get(0, 2 * n_pairs * READ_DTYPE.itemsize), dtype=READ_DTYPE)
+        pairs = np.frombuffer(self._get(1, max(1, n_pairs) * PAIR_DTYPE.itemsize), dtype=PAIR_DTYPE)[:n_pairs]
+        cig = np.frombuffer(self._get(2, n_cig * 4), dtype=np.uint32)
+        return reads, pairs, cig
+
+    def close(self):
+        for i in range(3):
+            if self._p[i]:
+                lib().psvr_host_free.argtypes = [C.c_void_p]
+                lib().psvr_host_free(self._p[i])
+                self._p[i], self._cap[i] = None, 0
