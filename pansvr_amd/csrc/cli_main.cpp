@@ -20,6 +20,7 @@
 #include "host_io.h"
 #include "bam_writer.h"
 #include "index_build.h"
+#include "signal_step.h"
 
 using namespace psvr;
 
@@ -257,8 +258,9 @@ static int index_main(int argc, char **argv)
 int main(int argc, char **argv)
 {
 	if (argc >= 2 && !strcmp(argv[1], "index")) return index_main(argc, argv);
+	if (argc >= 2 && (!strcmp(argv[1], "signal") || !strcmp(argv[1], "fc_signal"))) return psvr::signal_main(argc, argv);
 	if (argc < 2 || (strcmp(argv[1], "aln") && strcmp(argv[1], "fc_aln"))) {
-		fprintf(stderr, "panSVR (MI355X engine): only the read re-alignment step is implemented here.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n");
+		fprintf(stderr, "panSVR (MI355X engine): the read re-alignment step and its two neighbours.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n         panSVR index [-k 22] <anchors.fa> <IndexDir>\n         panSVR signal -N [options] <name-sorted.bam> > reads.fq\n");
 		return 1;
 	}
 	Opt o;

@@ -1,0 +1,157 @@
+"""`panSVR signal -N` (pansvr_amd/csrc/signal_step.h) against the independent restatement
+oracle/signal_oracle.py on BAM files written here record by record.  PARITY UNPINNED: the reference's own build of this
+step needs htslib, which this image cannot build, and the reference has no fixture for it; both sides restate
+getSignalRead.cpp.  The FASTQ comments are also fed through the `aln` step's own parser (the wire-format contract)."""
+import os
+import struct
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "pansvr_amd", "bin", "panSVR")
+ORACLE = os.path.join(ROOT, "oracle", "signal_oracle.py")
+NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+OPS = {c: i for i, c in enumerate("MIDNSHP=X")}
+
+
+def bgzf(data):
+    out = b""
+    for o in range(0, len(data), 0xff00):
+        chunk = data[o:o + 0xff00]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return out + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def record(name, flag, tid, pos, mapq, cigar, mtid, mpos, isize, seq, qual, tags):
+    cg = b"".join(struct.pack("<I", n << 4 | OPS[op]) for n, op in cigar)
+    s4 = bytearray((len(seq) + 1) // 2)
+    for i, ch in enumerate(seq):
+        s4[i >> 1] |= NT16[ch] << (0 if i & 1 else 4)
+    aux = b""
+    for tag, t, v in tags:
+        aux += tag.encode() + t.encode()
+        aux += (v.encode() + b"\0") if t == "Z" else struct.pack({"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f", "A": "<c"}[t], v)
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(name) + 1, mapq, 4680, len(cigar), flag, len(seq), mtid, mpos, isize) + name.encode() + b"\0" + cg + bytes(s4) + np.asarray(qual, dtype=np.uint8).tobytes() + aux
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path, recs, refs):
+    text = "@HD\tVN:1.6\tSO:queryname\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    h = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for n, l in refs:
+        h += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    open(path, "wb").write(bgzf(h + b"".join(recs)))
+
+
+def make_pairs(seed, n):
+    rng = np.random.RandomState(seed)
+    refs = [("chr%d" % (i + 1), 50000000) for i in range(30)]
+    recs = []
+
+    def rseq(L):
+        s = "".join("ACGT"[x] for x in rng.randint(0, 4, L))
+        if rng.randint(10) == 0:
+            k = rng.randint(L)
+            s = s[:k] + "N" + s[k + 1:]
+        return s
+
+    def rcigar(L):
+        kind = rng.randint(6) if L >= 60 else rng.randint(2)
+        if kind == 0:
+            return [(L, "M")]
+        if kind == 1:
+            a = int(rng.randint(1, min(40, L - 1)))
+            return [(a, "S"), (L - a, "M")]
+        if kind == 2:
+            a, b = int(rng.randint(1, 12)), int(rng.randint(1, 30))
+            return [(a, "H"), (L - b, "M"), (b, "S")]
+        if kind == 3:
+            a, d = int(rng.randint(10, L - 20)), int(rng.randint(1, 12))
+            return [(a, "M"), (d, "D"), (L - a, "M")]
+        if kind == 4:
+            a, i = int(rng.randint(10, L - 30)), int(rng.randint(1, 12))
+            return [(a, "=" if rng.randint(4) == 0 else "M"), (i, "I"), (L - a - i, "M")]
+        a = int(rng.randint(5, 30))
+        return [(a, "S"), (20, "M"), (3, "I"), (L - a - 23 - 4, "M"), (2, "D"), (4, "S")] if L - a - 27 > 0 else [(L, "M")]
+
+    def rtags(mapq):
+        t = []
+        if rng.randint(3):
+            t.append(("NM", "CcSsiI"[rng.randint(6)], int(rng.randint(0, 25))))
+        if mapq == 0 and rng.randint(2):
+            t.append(("XA", "Z", "".join("chr2,+%d,100M,1;" % rng.randint(1, 10 ** 6) for _ in range(rng.randint(1, 5)))))
+        if rng.randint(4) == 0:
+            t.append(("SA", "Z", "chr3,%d,-,60S40M,60,0;" % rng.randint(1, 10 ** 6)))
+        if rng.randint(3) == 0:
+            t.append(("MC", "Z", "100M"))
+        if rng.randint(5) == 0:
+            t.insert(0, ("AS", "i", int(rng.randint(0, 200))))
+        if rng.randint(7) == 0:
+            t.append(("XX", "f", 1.5))
+        return t
+
+    for p in range(n):
+        name = "pair%05d" % p
+        L1, L2 = (int(rng.choice([100, 101, 150, 151, 36])) for _ in range(2))
+        tid = int(rng.choice([0, 0, 0, 1, 23, 24, 25, 29]))
+        tid2 = tid if rng.randint(5) else int(rng.randint(0, 30))
+        pos = int(rng.randint(1000, 10 ** 6))
+        ins = int(rng.choice([300, 400, 450, 520, 2000, L1, 0]))
+        pos2 = pos + max(0, ins - L2) if rng.randint(6) else max(1, pos - 200)
+        rev1 = bool(rng.randint(4) == 0)
+        f1, f2 = 0x41 | (0x10 if rev1 else 0x20), 0x81 | (0x20 if rev1 else 0x10)
+        if rng.randint(12) == 0:
+            f1 ^= 0x10
+        mq1, mq2 = (int(rng.choice([0, 0, 5, 20, 60, 60])) for _ in range(2))
+        unm = rng.randint(15)
+        if unm == 0:        # mate 2 unmapped
+            r2 = record(name, 0x85 | (f2 & 0x30), tid, pos, 0, [], tid, pos, 0, rseq(L2), rng.randint(2, 42, L2), [])
+            r1 = record(name, (f1 | 0x8) & ~0x2, tid, pos, mq1, rcigar(L1), tid, pos, 0, rseq(L1), rng.randint(2, 42, L1), rtags(mq1))
+        elif unm == 1:      # both unmapped
+            r1 = record(name, 0x4D, -1, -1, 0, [], -1, -1, 0, rseq(L1), rng.randint(2, 42, L1), [])
+            r2 = record(name, 0x8D, -1, -1, 0, [], -1, -1, 0, rseq(L2), rng.randint(2, 42, L2), [])
+        else:
+            q1 = rng.randint(2, 42, L1) if rng.randint(4) else rng.randint(40, 60, L1)      # some reads without "low-quality" bases (< '/')
+            q2 = rng.randint(2, 42, L2) if rng.randint(4) else rng.randint(47, 60, L2)
+            s1 = rseq(L1)
+            if rng.randint(40) == 0:
+                s1 = "=" + s1[1:]                                                          # a base code get_bam_seq does not print
+            r1 = record(name, f1, tid, pos, mq1, rcigar(L1), tid2, pos2, ins if tid == tid2 else 0, s1, q1, rtags(mq1))
+            r2 = record(name, f2, tid2, pos2, mq2, rcigar(L2), tid, pos, -ins if tid == tid2 else 0, rseq(L2), q2, rtags(mq2))
+        recs.append(r1)
+        if rng.randint(10) == 0:     # a supplementary and a secondary record between the mates: skipped
+            recs.append(record(name, 0x841, tid, pos + 5, 3, [(60, "H"), (40, "M")], tid2, pos2, 0, rseq(40), rng.randint(2, 42, 40), []))
+            recs.append(record(name, 0x181, tid, pos + 9, 0, [(L2, "M")], tid, pos, 0, rseq(L2), rng.randint(2, 42, L2), []))
+        recs.append(r2)
+    return recs, refs
+
+
+@pytest.mark.parametrize("flags", [[], ["-D"], ["-U"], ["-D", "-U", "-I", "22"]])
+def test_signal_step_matches_the_restatement(tmp_path, flags):
+    recs, refs = make_pairs(20240 + len(flags), 600)
+    bam = str(tmp_path / "in.bam")
+    write_bam(bam, recs, refs)
+    got = subprocess.run([CLI, "signal", "-N"] + flags + ["-H", str(tmp_path / "h1.sam"), "-S", str(tmp_path / "s1.txt"), bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()[-2000:]
+    want = subprocess.run([sys.executable, ORACLE] + flags + [bam, str(tmp_path / "s2.txt"), str(tmp_path / "h2.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0, want.stderr.decode()[-2000:]
+    a, b = got.stdout.split(b"\n"), want.stdout.split(b"\n")
+    assert len(a) == len(b) and len(a) > 400
+    bad = [i for i, (x, y) in enumerate(zip(a, b)) if x != y]
+    assert not bad, "line %d differs:\n%r\n%r" % (bad[0], a[bad[0]], b[bad[0]])
+    assert open(tmp_path / "h1.sam", "rb").read() == open(tmp_path / "h2.sam", "rb").read()
+    assert open(tmp_path / "s1.txt").read() == open(tmp_path / "s2.txt").read()
+    # the wire format: every comment starts with the nine numeric tokens and the two flag tokens `aln` parses
+    # (single_end_handler::parse_ori_mapping_rst, read_realignment.hpp:392-429), the first one carries STAT_
+    names = a[0:len(a) - 1:4]                                          # FASTQ: every fourth line is a header line
+    assert all(l.startswith(b"@pair") for l in names)
+    assert b"_STAT_" in names[0] and sum(b"_STAT_" in l for l in names) == 1
+    for l in names[:50]:
+        tok = l.split(b" ", 1)[1].split(b"_")
+        assert all(t.lstrip(b"-").isdigit() for t in tok[:9]) and len(tok[9]) == 4 and len(tok[10]) == 4
