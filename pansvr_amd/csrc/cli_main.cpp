@@ -15,6 +15,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <signal.h>
+#include <unistd.h>
 #include <vector>
 #include "../../include/psvr_engine.h"
 #include "host_io.h"
@@ -35,6 +37,7 @@ struct Opt {
 	bool trace = false;
 	int device = 0;
 	long long batch_pairs = 2000000;   // N_NEEDED, rr.cpp:24
+	bool sig_all = false, sig_discard = false;   // BAM input: fc_signal's -D / -U
 };
 
 static int usage()
@@ -43,7 +46,9 @@ static int usage()
 	        "\n  Usage:     panSVR  aln|fc_aln  [Options] <IndexDir> [ReadFiles.fa][ori_header_fn.sam]>\n"
 	        "  Basic:   \n"
 	        "    <IndexDir>      FOLDER   the directory contains index\n"
-	        "    [ReadFiles.fa]  FILES    reads files, FASTQ(A) format, read 1 and 2 of a pair stored together ('-' = stdin).\n"
+	        "    [ReadFiles.fa]  FILES    reads files, FASTQ(A) format, read 1 and 2 of a pair stored together ('-' = stdin),\n"
+	        "                             or a name-sorted *.bam: the signal step then runs in-process ([ori_header.sam] is written;\n"
+	        "                             -D / -U as in fc_signal: all pairs are signals / drop fully matching pairs)\n"
 	        "                             Using [signal] command to generate this type of file\n"
 	        "    [ori_header.sam]  FILES  Header file of original BAM/CRAM file\n"
 	        "  Options:\n"
@@ -267,10 +272,10 @@ int main(int argc, char **argv)
 	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
 	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
 	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
-	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {0, 0, 0, 0}};
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {0, 0, 0, 0}};
 	int c;
 	optind = 2;
-	while ((c = getopt_long(argc, argv, "t:O:P:E:F:M:m:z:w:o:p:QSR:", lo, NULL)) >= 0) {
+	while ((c = getopt_long(argc, argv, "t:O:P:E:F:M:m:z:w:o:p:QSR:DU", lo, NULL)) >= 0) {
 		switch (c) {
 		case 't': o.thread_n = atoi(optarg); break;
 		case 'O': o.gap_open = atoi(optarg); break;
@@ -290,6 +295,8 @@ int main(int argc, char **argv)
 		case 1001: o.records = optarg; break;
 		case 1002: o.trace = true; break;
 		case 1003: o.batch_pairs = atoll(optarg); break;
+		case 'D': o.sig_all = true; break;
+		case 'U': o.sig_discard = true; break;
 		default: return usage();
 		}
 	}
@@ -297,6 +304,17 @@ int main(int argc, char **argv)
 	if (!(o.thread_n >= 1 && o.thread_n <= 48)) { fprintf(stderr, "Input error: thread_n cannot be less than 1 or more than 48\n"); abort(); }   // xassert, rr.hpp:121
 	o.index_dir = argv[optind], o.reads = argv[optind + 1], o.header = argv[optind + 2];
 
+	// <reads> may be a name-sorted BAM (*.bam): the signal step then runs in this process (default options of fc_signal) and its
+	// FASTQ goes through a pipe to the reader below; <header.sam> is WRITTEN from the BAM's header in that case
+	const bool from_bam = o.reads.size() > 4 && o.reads.compare(o.reads.size() - 4, 4, ".bam") == 0;
+	if (from_bam) {
+		psvr::BamReader rd;
+		if (!rd.open(o.reads.c_str())) { fprintf(stderr, "[panSVR-amd] %s\n", rd.error().c_str()); abort(); }
+		FILE *h = fopen(o.header.c_str(), "w");
+		if (!h) { fprintf(stderr, "fail to open file '%s'\n", o.header.c_str()); abort(); }
+		fwrite(rd.header_text.data(), 1, rd.header_text.size(), h);
+		fclose(h);
+	}
 	HeaderInfo H;
 	fprintf(stderr, "Open original header file [%s]\n", o.header.c_str());
 	if (!load_header(o.header, &H)) { fprintf(stderr, "fail to open file '%s'\n", o.header.c_str()); abort(); }
@@ -307,7 +325,22 @@ int main(int argc, char **argv)
 
 	fprintf(stderr, "Start classify\n");
 	double cpu0 = cputime();
-	FILE *fq = o.reads == "-" ? stdin : fopen(o.reads.c_str(), "r");
+	FILE *fq = nullptr;
+	psvr::SignalStep sig;
+	std::thread sig_thread;
+	int sig_rc = 0;
+	if (from_bam) {
+		signal(SIGPIPE, SIG_IGN);            // if the reader stops early (-R), the signal step's writes fail quietly and it runs to its end
+		int fds[2];
+		if (pipe(fds)) { fprintf(stderr, "[panSVR-amd] pipe() failed\n"); abort(); }
+		sig.o.sort_by_name = true, sig.o.input = o.reads, sig.o.header_fn = o.header, sig.o.status_fn = o.header + ".status";
+		sig.o.not_use_filter = o.sig_all, sig.o.discard_full_match = o.sig_discard;
+		sig.o.match = o.match, sig.o.mismatch = o.mismatch, sig.o.gap_open = o.gap_open, sig.o.gap_ex = o.gap_ex, sig.o.gap_open2 = o.gap_open2, sig.o.gap_ex2 = o.gap_ex2;
+		FILE *w = fdopen(fds[1], "w");
+		sig.out = w;
+		sig_thread = std::thread([&sig, &sig_rc, w]() { sig_rc = sig.run(); fclose(w); });
+		fq = fdopen(fds[0], "r");
+	} else fq = o.reads == "-" ? stdin : fopen(o.reads.c_str(), "r");
 	if (!fq) { fprintf(stderr, "fail to open file '%s'\n", o.reads.c_str()); abort(); }
 	OutFile fo, fo_ori;
 	if (!fo.open(o.out, !o.sam, H, o.thread_n) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n)) { fprintf(stderr, "fail to open output file\n"); abort(); }
@@ -522,6 +555,10 @@ int main(int argc, char **argv)
 	}
 	reader.join(), writer.join();
 	if (fq != stdin) fclose(fq);
+	if (sig_thread.joinable()) {
+		sig_thread.join();
+		if (sig_rc) { fprintf(stderr, "[panSVR-amd] the signal step failed\n"); abort(); }
+	}
 	if (!fo.close() || !fo_ori.close()) { fprintf(stderr, "fail to write output file\n"); abort(); }
 	if (frec) fclose(frec);
 	if (eng) psvr_engine_destroy(eng);

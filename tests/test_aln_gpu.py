@@ -103,3 +103,48 @@ def test_gpu_cli_scoring_options_match_oracle(score):
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if a != b]
     assert not bad, "%d/%d pairs differ; first %d:\norc: %s\ngpu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
     assert got != [normalise(l) for l in ac.golden_lines(name, rname)]        # the options really changed the results
+
+
+def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
+    """`panSVR aln <idx> x.bam hdr` (signal step in-process, through a pipe) gives byte for byte what `panSVR signal -N x.bam | panSVR aln <idx> - hdr`
+    gives.  The BAM is rebuilt from the golden set's FASTQ comments (FLAG / CIGAR / MATE / TAG), so the reads do align to the index."""
+    import re
+    import test_signal as ts
+    w = ac.workdir("fx1")
+    tmp = tempfile.mkdtemp(prefix="psvr_bam_")
+    lines = open(os.path.join(w, "reads150.fq")).read().split("\n")
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    recs = []
+    for k in range(0, len(lines) - 3, 4):
+        name, comment = lines[k][1:].split(" ", 1)
+        m = re.search(r"FLAG_(\d+)_(\d+)_CIGAR_([^_]*)_MATE_(-?\d+)_(-?\d+)_(-?\d+)_TAG_(.*)$", comment)
+        tok = comment.split("_")
+        flag, mapq = int(m.group(1)), int(m.group(2))
+        cigar = [(int(n), op) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", m.group(3))]
+        tags = []
+        for t in m.group(7).split("_"):
+            if t.count(":") >= 2:
+                tg, ty, val = t.split(":", 2)
+                tags.append((tg, "i" if ty == "i" else "Z", int(val) if ty == "i" else val))
+        seq, qual = lines[k + 1], [ord(c) - 33 for c in lines[k + 3]]
+        if flag & 16 and not flag & 4:
+            seq, qual = "".join(comp[c] for c in reversed(seq)), qual[::-1]
+        recs.append(ts.record(name, flag, int(tok[0]), int(tok[1]), mapq, cigar, int(m.group(4)), int(m.group(5)), int(m.group(6)), seq, qual, tags))
+    bam = os.path.join(tmp, "x.bam")
+    ts.write_bam(bam, recs, [("chr1", 250000000), ("chr2", 250000000)])
+    # route 1: two commands
+    fq = os.path.join(tmp, "x.fq")
+    r = subprocess.run([CLI, "signal", "-N", "-D", "-H", os.path.join(tmp, "h1.sam"), "-S", os.path.join(tmp, "s1.txt"), bam], stdout=open(fq, "wb"), stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert os.path.getsize(fq) > 100000
+    idx = os.path.join(ac.golden_dir("fx1"), "idx")
+    outs = []
+    for tag, reads, hdr in (("a", fq, os.path.join(tmp, "h1.sam")), ("b", bam, os.path.join(tmp, "h2.sam"))):
+        o = os.path.join(tmp, tag)
+        r = subprocess.run([CLI, "aln", "-S", "-D", "-o", o + ".sam", "-p", o + ".ori.sam", "--records", o + ".jsonl", idx, reads, hdr], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(o)
+    for ext in (".sam", ".ori.sam", ".jsonl"):
+        assert open(outs[0] + ext, "rb").read() == open(outs[1] + ext, "rb").read(), ext
+    assert os.path.getsize(outs[0] + ".sam") > 10000
+    assert open(os.path.join(tmp, "h1.sam"), "rb").read() == open(os.path.join(tmp, "h2.sam"), "rb").read()
