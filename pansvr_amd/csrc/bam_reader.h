@@ -81,7 +81,7 @@ struct BamRecord {                     // one alignment, fields as in bam1_core_
 	uint8_t mapq = 0, l_qname = 0;
 	std::vector<uint8_t> data;         // qname | cigar | seq (4-bit) | qual | aux
 	const char *qname() const { return (const char *)data.data(); }
-	const uint32_t *cigar() const { return (const uint32_t *)(data.data() + l_qname); }
+	uint32_t cig(unsigned k) const { uint32_t v; memcpy(&v, data.data() + l_qname + 4 * (size_t)k, 4); return v; }   // the CIGAR words are not aligned (the name's length decides)
 	const uint8_t *seq() const { return data.data() + l_qname + 4 * (size_t)n_cigar; }
 	const uint8_t *qual() const { return seq() + (l_qseq + 1) / 2; }
 	const uint8_t *aux() const { return qual() + l_qseq; }

@@ -95,9 +95,8 @@ struct SignalStep {
 	int score_by_cigar(const BamRecord &b) const            // getScoreByCigar, getSignalRead.cpp:36-77
 	{
 		int score = 0, gap_len = 0;
-		const uint32_t *cg = b.cigar();
 		for (unsigned i = 0; i < b.n_cigar; ++i) {
-			const int op = (int)(cg[i] & 0xf), len = (int)(cg[i] >> 4);
+			const int op = (int)(b.cig(i) & 0xf), len = (int)(b.cig(i) >> 4);
 			if (op == 0 || op == 7) score += len * o.match;                    // M, =
 			else if (op == 1 || op == 2 || op == 4 || op == 5) {               // I, D, S, H
 				if (op == 1 || op == 2) gap_len += len;
@@ -163,13 +162,13 @@ struct SignalStep {
 			lowq[i] = 0;
 			for (int k = 0; k < x.l_qseq && k < 100000; ++k) lowq[i] += x.qual()[k] < (uint8_t)'/';      // get_bam_low_quality_num(0, 100000, '/')
 			if (x.n_cigar) {                                                                            // bam_has_SH_cigar, clib/bam_file.c:1031-1053
-				const uint32_t f = x.cigar()[0], l = x.cigar()[x.n_cigar - 1];
+				const uint32_t f = x.cig(0), l = x.cig(x.n_cigar - 1u);
 				if ((f & 0xf) == 4 || (f & 0xf) == 5) soft_l[i] = (int)(f >> 4);
 				if ((l & 0xf) == 4 || (l & 0xf) == 5) soft_r[i] = (int)(l >> 4);
 			}
 			clip[i] = soft_l[i] + soft_r[i];
 			int indel = 0;                                                                              // bam_has_INDEL_NM, :1056-1069
-			for (unsigned k = 0; k < x.n_cigar; ++k) if ((x.cigar()[k] & 0xf) == 1 || (x.cigar()[k] & 0xf) == 2) indel += (int)(x.cigar()[k] >> 4);
+			for (unsigned k = 0; k < x.n_cigar; ++k) if ((x.cig(k) & 0xf) == 1 || (x.cig(k) & 0xf) == 2) indel += (int)(x.cig(k) >> 4);
 			int32_t nm = 0;
 			x.num_tag("NM", &nm);
 			indel_nm[i] = indel + nm;
@@ -226,7 +225,7 @@ struct SignalStep {
 			const BamRecord &x = *b[i];
 			snprintf(buf, sizeof buf, "FLAG_%d_%d_CIGAR_", (int)x.flag, (int)x.mapq);
 			reason[i] += buf;
-			for (unsigned k = 0; k < x.n_cigar; ++k) { snprintf(buf, sizeof buf, "%d%c", (int)(x.cigar()[k] >> 4), "MIDNSHP=XB"[x.cigar()[k] & 0xf]); reason[i] += buf; }
+			for (unsigned k = 0; k < x.n_cigar; ++k) { snprintf(buf, sizeof buf, "%d%c", (int)(x.cig(k) >> 4), "MIDNSHP=XB"[x.cig(k) & 0xf]); reason[i] += buf; }
 			reason[i] += "_";
 			snprintf(buf, sizeof buf, "MATE_%d_%d_%d_", x.mtid, x.mpos, x.isize);
 			reason[i] += buf;
