@@ -501,6 +501,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	constexpr int SW = 4 * LANES, PB = 64 / LANES;                   // strip width, alignments per wavefront
 	constexpr int kNone = (int)0x80000000;                           // "no cell yet" in the per-diagonal maximum
 	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
+	// substitution scores of every (target, query) code pair, scaled and tagged like the other candidates (see below), written by
+	// all 64 lanes before any of them leaves
+	__shared__ int sc_lut[64];
+	{
+		const int tcode = lane >> 3, qcode = lane & 7;
+		sc_lut[lane] = 8 * ((tcode == P.m1 || qcode == P.m1) ? P.sc_N : (tcode == qcode ? P.sc_mch : P.sc_mis)) + 4;
+	}
+	__builtin_amdgcn_wave_barrier();
 	int cls = 0;
 	while (cls + 1 < T.n_classes && (int)blockIdx.x >= T.first_block[cls + 1]) ++cls;
 	const int n_strips16 = T.n_strips16[cls];
@@ -540,10 +548,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	// yields both z and the direction; x / y / x2 / y2 live with their tag added so that a candidate is a single add.
 	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
 	const int x_init = 8 * neg_qe + 3, y_init = 8 * neg_qe + 2, x2_init = 8 * neg_qe2 + 1, y2_init = 8 * neg_qe2;
-	const int mch_t = 8 * P.sc_mch + 4, mis_t = 8 * P.sc_mis + 4, scN_t = 8 * P.sc_N + 4, z_cap = 8 * P.sc_mch + 7;
+	const int z_cap = 8 * P.sc_mch + 7;                               // (the substitution scores, 8 * sc + 4, sit in sc_lut)
 	const int q_m8 = 8 * P.q - 8, q2_m8 = 8 * P.q2 - 8;               // a - (z - q) > 0  <=>  tagged difference - 8 >= 0
 	const int cx = 8 - 8 * s8(P.q + P.e), cx2 = 8 - 8 * s8(P.q2 + P.e2);
-	const int long_thres = P.long_thres, ur_short = s8(-P.e), ur_at = s8(P.long_diff), ur_long = s8(-P.e2), m1 = P.m1;
+	const int long_thres = P.long_thres, ur_short = s8(-P.e), ur_at = s8(P.long_diff), ur_long = s8(-P.e2);
 	auto ur_of = [=](int r) { return r == 0 ? neg_qe : r < long_thres ? ur_short : r == long_thres ? ur_at : ur_long; };
 	// H is tracked by vertical steps only, H(i,t) = H(i-1,t) + v(i,t).  The reference takes a horizontal step for the last
 	// in-band cell of a diagonal (:322), which is the same number: both deltas come from one z.  For the top row that needs the
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 			V[jj] = 8 * neg_qe, X[jj] = x_init, Y[jj] = y_init, X2[jj] = x2_init, Y2[jj] = y2_init;
 			H[jj] = h_above(c0 + jb + jj);
 			inr[jj] = jb + jj < ncols;
-			TC[jj] = inr[jj] ? (target[c0 + jb + jj] & 15) : 0;
+			TC[jj] = inr[jj] ? (target[c0 + jb + jj] & 7) * 32 : 0;     // row of the score table (codes are 0..4)
 		}
 		uint8_t *const Ein = (s & 1) ? uE0 : uE1, *const Eout = (s & 1) ? uE1 : uE0;
 		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
