@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_latest.json from the two rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 0 --cpu-pairs 0`
-(4 engine passes per process: timed, timing, stats, PCIe-inclusive).  usage: pmc_to_json.py <fetch.csv> <write.csv> <pairs_per_gpu> <out.json>"""
+(5 engine passes per process: timed, timing, stats, two PCIe-inclusive).  usage: pmc_to_json.py <fetch.csv> <write.csv> <pairs_per_gpu> <out.json>"""
 import collections
 import csv
 import json
@@ -15,7 +15,7 @@ def load(path):
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
-passes = 4.0
+passes = 5.0
 out = {"pairs_per_gpu": int(sys.argv[3]), "passes_per_process": passes, "unit": "KiB", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = {"fetch_KiB_per_step": round(fetch.get(k, 0.0) / passes, 1), "write_KiB_per_step": round(write.get(k, 0.0) / passes, 1)}
