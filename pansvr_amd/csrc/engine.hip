@@ -233,11 +233,30 @@ __global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *work, l
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < n) select_read(c, pair_of(work, i) * 2 + mate);
 }
-__global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *work, long long n)
+// the reads that have candidates, compacted (a third of the reads have none: their lanes would idle through the walk of the others)
+__global__ __launch_bounds__(kBlock) void k_walk_list(Ctx c, const int32_t *work, long long n, int32_t *list, unsigned int *cnt)
 {
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
-	if (i >= 2 * n) return;
-	walk_read(c, pair_of(work, i >> 1) * 2 + (i & 1));
+	__shared__ unsigned int n_blk, b_blk;
+	if (threadIdx.x == 0) n_blk = 0;
+	__syncthreads();
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	long long read = 0;
+	bool has = false;
+	if (i < 2 * n) { read = pair_of(work, i >> 1) * 2 + (i & 1); has = c.active[read] && c.n_ccand[read] > 0; }
+	const unsigned long long m = __ballot(has), below = (1ull << (threadIdx.x & 63)) - 1;
+	unsigned int w0 = 0;
+	if ((threadIdx.x & 63) == 0 && m) w0 = atomicAdd(&n_blk, (unsigned int)__popcll(m));
+	w0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w0);
+	__syncthreads();
+	if (threadIdx.x == 0 && n_blk) b_blk = atomicAdd(cnt, n_blk);
+	__syncthreads();
+	if (has) list[b_blk + w0 + (unsigned int)__popcll(m & below)] = (int32_t)read;
+}
+__global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
+{
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
+	if (i >= (long long)*cnt) return;
+	walk_read(c, list[i]);
 }
 __global__ __launch_bounds__(64) void k_assemble(Ctx c, long long begin, long long end)
 {
@@ -642,7 +661,20 @@ struct GpuBE {
 		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n, blk)), dim3(blk), 0, stream, c, w, n); t1(); } \
 		note(hipGetLastError());                                                                                   \
 	}
-	PSVR_STAGE(st_walk, k_walk, 2, kBlock)
+	DevBuf walk_list;
+	void st_walk(const Ctx &c, const int32_t *w, long long n)
+	{
+		if (n <= 0) return;
+		note(walk_list.ensure((size_t)(2 * n + 4) * 4));
+		int32_t *list = walk_list.as<int32_t>() + 4;
+		unsigned int *cnt = (unsigned int *)walk_list.p;
+		note(hipMemsetAsync(cnt, 0, 4, stream));
+		hipLaunchKernelGGL(k_walk_list, dim3(grid_for(2 * n)), dim3(kBlock), 0, stream, c, w, n, list, cnt);
+		t0("k_walk");
+		hipLaunchKernelGGL(k_walk, dim3(grid_for(2 * n)), dim3(kBlock), 0, stream, c, (const int32_t *)list, (const unsigned int *)cnt);
+		t1();
+		note(hipGetLastError());
+	}
 	PSVR_STAGE(st_finalize, k_finalize, 2, kBlock)
 	PSVR_STAGE(st_pair, k_pair, 1, kBlock)
 	PSVR_STAGE(st_finalize_pair, k_finalize_pair, 1, kBlock)
