@@ -223,15 +223,34 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	} else seed_strand_t<false>(c, rs, nullptr);
 }
 // K3 chain: merge, expand, sort, sparse chaining DP
-__global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *work, long long n, int mate)
+// the mate's reads that have MEMs, compacted: chaining and selection leave the others as k_prep initialised them
+__global__ __launch_bounds__(kBlock) void k_mem_list(Ctx c, const int32_t *work, long long n, int mate, int32_t *list, unsigned int *cnt)
 {
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < n) chain_read(c, pair_of(work, i) * 2 + mate);
+	__shared__ unsigned int n_blk, b_blk;
+	if (threadIdx.x == 0) n_blk = 0;
+	__syncthreads();
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	long long read = 0;
+	bool has = false;
+	if (i < n) { read = pair_of(work, i) * 2 + mate; has = c.active[read] && (c.strand[read * 2].mem_n | c.strand[read * 2 + 1].mem_n) != 0; }
+	const unsigned long long m = __ballot(has), below = (1ull << (threadIdx.x & 63)) - 1;
+	unsigned int w0 = 0;
+	if ((threadIdx.x & 63) == 0 && m) w0 = atomicAdd(&n_blk, (unsigned int)__popcll(m));
+	w0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w0);
+	__syncthreads();
+	if (threadIdx.x == 0 && n_blk) b_blk = atomicAdd(cnt, n_blk);
+	__syncthreads();
+	if (has) list[b_blk + w0 + (unsigned int)__popcll(m & below)] = (int32_t)read;
 }
-__global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *work, long long n, int mate)
+__global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < n) select_read(c, pair_of(work, i) * 2 + mate);
+	if (i < (long long)*cnt) chain_read(c, list[i]);
+}
+__global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *list, const unsigned int *cnt)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < (long long)*cnt) select_read(c, list[i]);
 }
 // the reads that have candidates, compacted (a third of the reads have none: their lanes would idle through the walk of the others)
 __global__ __launch_bounds__(kBlock) void k_walk_list(Ctx c, const int32_t *work, long long n, int32_t *list, unsigned int *cnt)
@@ -603,12 +622,6 @@ struct GpuBE {
 	{
 		if (n) hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, stride, off, v);
 	}
-#define PSVR_STAGE_M(name, kern, mult)                                                                             \
-	void name(const Ctx &c, const int32_t *w, long long n, int mate)                                               \
-	{                                                                                                              \
-		if (n > 0) { t0(#kern); hipLaunchKernelGGL(kern, dim3(grid_for((mult) * n)), dim3(kBlock), 0, stream, c, w, n, mate); t1(); } \
-		note(hipGetLastError());                                                                                   \
-	}
 	void st_seed(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n > 0) {
@@ -617,12 +630,26 @@ struct GpuBE {
 			t0("k_seed");
 			hipLaunchKernelGGL(k_seed, dim3(grid_for(2 * n)), dim3(kBlock), (size_t)pitch * 8 * kBlock, stream, c, w, n, mate, pitch);
 			t1();
+			// the list k_chain / k_select of this mate run on
+			note(mem_list.ensure((size_t)(n + 4) * 4));
+			note(hipMemsetAsync(mem_list.p, 0, 4, stream));
+			hipLaunchKernelGGL(k_mem_list, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, mate, mem_list.as<int32_t>() + 4, (unsigned int *)mem_list.p);
 		}
 		note(hipGetLastError());
 	}
-	PSVR_STAGE_M(st_chain, k_chain, 1)
-	PSVR_STAGE_M(st_select, k_select, 1)
-#undef PSVR_STAGE_M
+	DevBuf mem_list;
+	void st_chain(const Ctx &c, const int32_t *w, long long n, int mate)
+	{
+		(void)w, (void)mate;
+		if (n > 0) { t0("k_chain"); hipLaunchKernelGGL(k_chain, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, (const int32_t *)(mem_list.as<int32_t>() + 4), (const unsigned int *)mem_list.p); t1(); }
+		note(hipGetLastError());
+	}
+	void st_select(const Ctx &c, const int32_t *w, long long n, int mate)
+	{
+		(void)w, (void)mate;
+		if (n > 0) { t0("k_select"); hipLaunchKernelGGL(k_select, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, (const int32_t *)(mem_list.as<int32_t>() + 4), (const unsigned int *)mem_list.p); t1(); }
+		note(hipGetLastError());
+	}
 	static int str_tsize(const Ctx &c)
 	{
 		int tsize = 256;                                          // >= 2 x (L - 19) k-mers, power of two
