@@ -520,12 +520,15 @@ __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long l
 	}
 }
 // K5 ref_fetch: unpack the 2-bit reference window / slice the read for every queued DP problem
-__global__ __launch_bounds__(64) void k_dp_fetch(Ctx c, long long begin, const long long *q_off, const long long *t_off, uint8_t *qbuf, uint8_t *tbuf)
+// 16 lanes per problem (most are a few bases long: the end-to-end gap fills), four problems per wavefront
+__global__ __launch_bounds__(256) void k_dp_fetch(Ctx c, long long begin, long long np, const long long *q_off, const long long *t_off, uint8_t *qbuf, uint8_t *tbuf)
 {
-	const DpDesc &x = c.dp.base[begin + blockIdx.x];
-	uint8_t *q = qbuf + q_off[blockIdx.x], *t = tbuf + t_off[blockIdx.x];
+	const long long p = blockIdx.x * 16ll + (threadIdx.x >> 4);
+	if (p >= np) return;
+	const DpDesc &x = c.dp.base[begin + p];
+	uint8_t *q = qbuf + q_off[p], *t = tbuf + t_off[p];
 	const int n = x.qlen > x.tlen ? x.qlen : x.tlen;
-	for (int i = threadIdx.x; i < n; i += 64) dp_fetch_base(c, x, i, q, t);
+	for (int i = threadIdx.x & 15; i < n; i += 16) dp_fetch_base(c, x, i, q, t);
 }
 
 struct GpuBE {
@@ -863,7 +866,7 @@ struct GpuBE {
 		pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off, pd.ez = d.ez;
 		hipLaunchKernelGGL(k_dp_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, (const long long *)plan_bstart.p);
 		t0("k_dp_fetch");
-		hipLaunchKernelGGL(k_dp_fetch, dim3((unsigned)n), dim3(64), 0, stream, c, d.begin, (const long long *)d.q_off, (const long long *)d.t_off, d.qbuf, d.tbuf);
+		hipLaunchKernelGGL(k_dp_fetch, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, c, d.begin, n, (const long long *)d.q_off, (const long long *)d.t_off, d.qbuf, d.tbuf);
 		t1();
 		PSVR_HIP(hipGetLastError());
 		DpBatch B;
