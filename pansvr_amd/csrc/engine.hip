@@ -552,6 +552,18 @@ struct GpuBE {
 			if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
 		return side_ok = true;
 	}
+	// engine_core.h runs the pairing-only repeats on the first side stream: `stream` is switched, so the st_* launches follow
+	hipStream_t main_stream = nullptr;
+	bool side_begin()
+	{
+		if (timing || !side_streams()) return false;
+		note(hipEventRecord(ev_fork, stream));
+		note(hipStreamWaitEvent(side[0], ev_fork, 0));
+		main_stream = stream, stream = side[0];
+		return true;
+	}
+	void side_end() { note(hipEventRecord(ev_join[0], side[0])); stream = main_stream; }
+	void side_wait() { note(hipStreamWaitEvent(stream, ev_join[0], 0)); }
 
 	// live per-kernel timing with HIP events on the launch stream (bench.py's roofline figure)
 	bool timing = false;

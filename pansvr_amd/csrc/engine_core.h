@@ -449,14 +449,19 @@ template <class BE> struct EngineCore {
 			stats.rounds++;
 			if (work == nullptr) stats.pairs_run += P, stats.shadow_runs += V; else stats.pairs_run += nfull, stats.shadow_runs += nshadow;
 			stats.pair_only += npair_only;
+			// the pairs that only repeat their pairing stage are not among the slots that run in full: a backend with a second queue does
+			// them beside the stage chain
+			const bool beside = npair_only > 0 && be.side_begin();
+			if (beside) { be.st_pair(c, d_workp, npair_only); be.side_end(); }
 			rc = run_slots(work, nfull + nshadow, dp_done, cw_done);
+			if (beside) be.side_wait();
 			if (rc <= -1000) {
 				int32_t fl[8] = {0, 0, 0, ((-rc - 1000) & 1), ((-rc - 1000) & 2) >> 1, 0, 0, 0};
 				c.stats = stats_ptr;
 				return grow_and_rerun(fl, trace, want_stats, depth);
 			}
 			if (rc) break;
-			if (npair_only) be.st_pair(c, d_workp, npair_only);
+			if (npair_only && !beside) be.st_pair(c, d_workp, npair_only);
 			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
 			be.dzero(d_tops + 8, 16);
 			be.st_totals(c, work, nfull + nshadow, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);

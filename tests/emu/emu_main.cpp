@@ -80,6 +80,9 @@ struct CpuBE {
 		}
 	}
 	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff) { for (long long i = 0; i < n; ++i) adopt_variant(c, pairs[i], slots[i], noff, 0, 1); }
+	bool side_begin() { return false; }       // one queue
+	void side_end() {}
+	void side_wait() {}
 	template <class Core> int st_dp(Core &core)
 	{
 		const Ctx &c = core.c;
