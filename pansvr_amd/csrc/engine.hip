@@ -223,24 +223,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	} else seed_strand_t<false>(c, rs, nullptr);
 }
 // K3 chain: merge, expand, sort, sparse chaining DP
-// the mate's reads that have MEMs, compacted: chaining and selection leave the others as k_prep initialised them
-__global__ __launch_bounds__(kBlock) void k_mem_list(Ctx c, const int32_t *work, long long n, int mate, int32_t *list, unsigned int *cnt)
+// Compaction of the items a predicate keeps into list[0 .. *cnt): kListItems items per thread (item = block base + k * blockDim + thread,
+// so a wavefront's loads stay coalesced), ranks inside a wavefront from ballots, one LDS atomic per wavefront and ONE global atomic per
+// workgroup -- same-address global atomics cost ~10 ns each, a workgroup per 256 items made them the kernel's time.
+static const int kListItems = 4;
+template <class Pred> __device__ __forceinline__ void compact_list(long long n_items, int32_t *list, unsigned int *cnt, Pred pred)
 {
 	__shared__ unsigned int n_blk, b_blk;
 	if (threadIdx.x == 0) n_blk = 0;
 	__syncthreads();
-	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	long long read = 0;
-	bool has = false;
-	if (i < n) { read = pair_of(work, i) * 2 + mate; has = c.active[read] && (c.strand[read * 2].mem_n | c.strand[read * 2 + 1].mem_n) != 0; }
-	const unsigned long long m = __ballot(has), below = (1ull << (threadIdx.x & 63)) - 1;
-	unsigned int w0 = 0;
-	if ((threadIdx.x & 63) == 0 && m) w0 = atomicAdd(&n_blk, (unsigned int)__popcll(m));
-	w0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w0);
+	const long long base = blockIdx.x * (long long)(kBlock * kListItems);
+	int32_t val[kListItems];
+	unsigned int rank[kListItems];
+	bool has[kListItems];
+#pragma unroll
+	for (int k = 0; k < kListItems; ++k) {
+		const long long i = base + (long long)k * kBlock + threadIdx.x;
+		has[k] = i < n_items && pred(i, val[k]);
+		const unsigned long long m = __ballot(has[k]);
+		unsigned int w0 = 0;
+		if ((threadIdx.x & 63) == 0 && m) w0 = atomicAdd(&n_blk, (unsigned int)__popcll(m));
+		rank[k] = (unsigned int)__builtin_amdgcn_readfirstlane((int)w0) + (unsigned int)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
+	}
 	__syncthreads();
 	if (threadIdx.x == 0 && n_blk) b_blk = atomicAdd(cnt, n_blk);
 	__syncthreads();
-	if (has) list[b_blk + w0 + (unsigned int)__popcll(m & below)] = (int32_t)read;
+#pragma unroll
+	for (int k = 0; k < kListItems; ++k) if (has[k]) list[b_blk + rank[k]] = val[k];
+}
+// the mate's reads that have MEMs: chaining and selection leave the others as k_prep initialised them
+__global__ __launch_bounds__(kBlock) void k_mem_list(Ctx c, const int32_t *work, long long n, int mate, int32_t *list, unsigned int *cnt)
+{
+	compact_list(n, list, cnt, [&](long long i, int32_t &read) {
+		const long long r = pair_of(work, i) * 2 + mate;
+		read = (int32_t)r;
+		return c.active[r] && (c.strand[r * 2].mem_n | c.strand[r * 2 + 1].mem_n) != 0;
+	});
 }
 __global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
@@ -252,24 +270,14 @@ __global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *list, c
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < (long long)*cnt) select_read(c, list[i]);
 }
-// the reads that have candidates, compacted (a third of the reads have none: their lanes would idle through the walk of the others)
+// the reads that have candidates (a third of the reads have none: their lanes would idle through the walk of the others)
 __global__ __launch_bounds__(kBlock) void k_walk_list(Ctx c, const int32_t *work, long long n, int32_t *list, unsigned int *cnt)
 {
-	__shared__ unsigned int n_blk, b_blk;
-	if (threadIdx.x == 0) n_blk = 0;
-	__syncthreads();
-	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	long long read = 0;
-	bool has = false;
-	if (i < 2 * n) { read = pair_of(work, i >> 1) * 2 + (i & 1); has = c.active[read] && c.n_ccand[read] > 0; }
-	const unsigned long long m = __ballot(has), below = (1ull << (threadIdx.x & 63)) - 1;
-	unsigned int w0 = 0;
-	if ((threadIdx.x & 63) == 0 && m) w0 = atomicAdd(&n_blk, (unsigned int)__popcll(m));
-	w0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w0);
-	__syncthreads();
-	if (threadIdx.x == 0 && n_blk) b_blk = atomicAdd(cnt, n_blk);
-	__syncthreads();
-	if (has) list[b_blk + w0 + (unsigned int)__popcll(m & below)] = (int32_t)read;
+	compact_list(2 * n, list, cnt, [&](long long i, int32_t &read) {
+		const long long r = pair_of(work, i >> 1) * 2 + (i & 1);
+		read = (int32_t)r;
+		return c.active[r] && c.n_ccand[r] > 0;
+	});
 }
 __global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
@@ -648,7 +656,7 @@ struct GpuBE {
 			// the list k_chain / k_select of this mate run on
 			note(mem_list.ensure((size_t)(n + 4) * 4));
 			note(hipMemsetAsync(mem_list.p, 0, 4, stream));
-			hipLaunchKernelGGL(k_mem_list, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, mate, mem_list.as<int32_t>() + 4, (unsigned int *)mem_list.p);
+			hipLaunchKernelGGL(k_mem_list, dim3(grid_for(n, kBlock * kListItems)), dim3(kBlock), 0, stream, c, w, n, mate, mem_list.as<int32_t>() + 4, (unsigned int *)mem_list.p);
 		}
 		note(hipGetLastError());
 	}
@@ -711,7 +719,7 @@ struct GpuBE {
 		int32_t *list = walk_list.as<int32_t>() + 4;
 		unsigned int *cnt = (unsigned int *)walk_list.p;
 		note(hipMemsetAsync(cnt, 0, 4, stream));
-		hipLaunchKernelGGL(k_walk_list, dim3(grid_for(2 * n)), dim3(kBlock), 0, stream, c, w, n, list, cnt);
+		hipLaunchKernelGGL(k_walk_list, dim3(grid_for(2 * n, kBlock * kListItems)), dim3(kBlock), 0, stream, c, w, n, list, cnt);
 		t0("k_walk");
 		hipLaunchKernelGGL(k_walk, dim3(grid_for(2 * n)), dim3(kBlock), 0, stream, c, (const int32_t *)list, (const unsigned int *)cnt);
 		t1();
