@@ -151,6 +151,7 @@ struct Ctx {
 	const uint8_t *force;
 	// per read
 	uint8_t *active; uint8_t *unmapped; uint8_t *is_str; uint8_t *has_n4;
+	uint8_t *has_mem;            // per read: a strand found MEMs (set by the seeding stage; the GPU backend compacts its chain / select work by it)
 	int32_t *str_list; unsigned int *str_cnt;   // GPU backend: reads whose STR screen was inconclusive (is_str == 2), for the exact count
 	int32_t *read_l;
 	uint8_t *bin;                // [read][2][lmax]
@@ -256,7 +257,7 @@ PSVR_HDN inline void prep_read(const Ctx &c, long long read)
 	bool unm = o.unmapped != 0;
 	if ((uint32_t)o.chr_id > 24u) unm = true;                          // rr.cpp:413
 	c.unmapped[read] = unm;
-	c.is_str[read] = 0;
+	c.is_str[read] = 0, c.has_mem[read] = 0;
 	long long item = (read >> 1) * 3 + (read & 1);
 	c.rcnt[item] = 0;
 	c.hcnt[read] = 0;
@@ -507,6 +508,7 @@ template <bool LOCAL> PSVR_HD void seed_strand_t(const Ctx &c, long long rs, con
 	}
 	Strand &st = c.strand[rs];
 	st.mem_off = base, st.mem_n = total;
+	if (total) c.has_mem[read] = 1;
 	if (c.stats) { stat_add(c, ST_PROBES, probes); stat_add(c, ST_HITS, total); }
 }
 PSVR_HDN inline void seed_strand(const Ctx &c, long long rs) { seed_strand_t<false>(c, rs, nullptr); }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	bool unm = o_unm != 0 || o_chr > 24u;
 	bool act = !(L > kMaxReadLen || L < kLenKmer) && !(!unm && o_score == (uint32_t)(L * c.par.match));
 	if (lane == 0) {
-		c.read_l[read] = L, c.unmapped[read] = unm, c.is_str[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
+		c.read_l[read] = L, c.unmapped[read] = unm, c.is_str[read] = 0, c.has_mem[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
 		if (L > kMaxReadLen) *c.err = 1;
 	}
 	if (lane < 2) { Strand &st = c.strand[read * 2 + lane]; st.mem_n = st.us_n = 0; st.mem_off = st.us_off = 0; st.seed_hash = st.chain_hash = 1469598103934665603ULL; }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_mem_list(Ctx c, const int32_t *work,
 	compact_list(n, list, cnt, [&](long long i, int32_t &read) {
 		const long long r = pair_of(work, i) * 2 + mate;
 		read = (int32_t)r;
-		return c.active[r] && (c.strand[r * 2].mem_n | c.strand[r * 2 + 1].mem_n) != 0;
+		return c.active[r] && c.has_mem[r];
 	});
 }
 __global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *list, const unsigned int *cnt)

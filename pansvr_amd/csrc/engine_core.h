@@ -236,6 +236,7 @@ template <class BE> struct EngineCore {
 		c.poff = alloc<long long>(S), c.rcnt = alloc<int32_t>(3 * S), d_noff = alloc<long long>(S);
 		c.hoff = alloc<long long>(RS), c.hcnt = alloc<int32_t>(RS), d_nhoff = alloc<long long>(RS);
 		c.active = alloc<uint8_t>(RS), c.unmapped = alloc<uint8_t>(RS), c.is_str = alloc<uint8_t>(RS), c.has_n4 = alloc<uint8_t>(RS);
+		c.has_mem = alloc<uint8_t>(RS);
 		c.str_list = alloc<int32_t>(RS / 2), c.str_cnt = alloc<unsigned int>(4);
 		c.read_l = alloc<int32_t>(RS);
 		c.bin = alloc<uint8_t>((unsigned long long)RS * 2 * c.lmax);
