@@ -56,6 +56,9 @@ struct DevIndex {
 	// 1 bit per first-level bucket (32 MiB, stays resident in the 256 MiB Infinity Cache): set iff the bucket holds a k-mer.
 	// ~85 % of all probes (wrong strand, unrelated reads, mismatching positions) end here without touching the 2 GiB table.
 	const uint32_t *occ;
+	// optional: uid_hint[b] = last unipath that starts at or before position b << uid_shift, so the unipath of a position is found by
+	// bisecting between two neighbouring hints (a couple of loads) instead of over all n_seqf starts (14+ dependent loads per MEM)
+	const uint32_t *uid_hint; uint32_t uid_shift;
 	// tests/emu only (PSVR_EMU_SPARSE_HASH): non-empty first-level buckets instead of the dense 2 GiB table
 	const uint32_t *sp_id; const uint64_t *sp_start; uint64_t sp_n, n_kmer;
 };
@@ -425,6 +428,10 @@ PSVR_HD uint32_t mem_for_hit(const DevIndex &ix, uint64_t hit, const uint64_t *r
 {
 	const uint64_t kp = ix.off[hit];
 	long long lo2 = 0, hi2 = (long long)ix.n_seqf - 1, uid = -1;
+	if (ix.uid_hint) {                                      // same search, started from a bracket that is known to hold the answer
+		const uint64_t b = kp >> ix.uid_shift;
+		lo2 = (long long)ix.uid_hint[b], hi2 = (long long)ix.uid_hint[b + 1];
+	}
 	while (lo2 <= hi2) {                                    // binsearch_interval_unipath64 (binarys_qsort.c:162-187)
 		long long mid = (lo2 + hi2) >> 1;
 		uint64_t sv = ix.seqf[mid];

@@ -951,7 +951,7 @@ __global__ void k_build_occupancy(const uint64_t *hash, uint32_t *occ, long long
 struct psvr_index {
 	int device = 0;
 	HostIndex host;          // small tables + strings stay on the host too (SAM formatting)
-	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ;
+	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, uid_hint;
 	DevIndex dev;
 	int64_t bytes = 0;
 };
@@ -992,6 +992,20 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v)
 	PSVR_HIP(hipGetLastError());
 	PSVR_HIP(hipDeviceSynchronize());
 	d.occ = ix->occ.as<uint32_t>();
+	// bracket table for the unipath-of-position search (aln_device.h mem_for_hit): one entry per 1024 positions
+	{
+		const uint32_t sh = 10;
+		const uint64_t last = v->n_seqf ? v->seqf[v->n_seqf - 1] : 0;
+		std::vector<uint32_t> hint((size_t)(last >> sh) + 3);
+		uint64_t u = 0;
+		for (size_t b = 0; b < hint.size(); ++b) {
+			const uint64_t p = (uint64_t)b << sh;
+			while (u + 1 < v->n_seqf && v->seqf[u + 1] <= p) ++u;
+			hint[b] = (uint32_t)u;
+		}
+		PSVR_HIP(up(ix->uid_hint, hint.data(), hint.size() * 4, 0));
+		d.uid_hint = ix->uid_hint.as<uint32_t>(), d.uid_shift = sh;
+	}
 	return PSVR_OK;
 }
 

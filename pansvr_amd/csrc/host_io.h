@@ -158,7 +158,7 @@ struct HostIndex {
 
 	DevIndex view() const      // pointers into THIS object's memory (host); the GPU engine builds its own from device copies
 	{
-		DevIndex d;
+		DevIndex d = DevIndex();    // everything not set below (occupancy bitmap, bracket table) stays null
 		d.ref_seq = ref_seq.data(), d.seq = seq.data(), d.seqf = seqf.data(), d.pos = pos.data(), d.posp = posp.data();
 		d.hash = hash.data(), d.off = off.data(), d.kmer = kmer.data(), d.n_seqf = seqf.size();
 		d.chr_end_n = chr_end_n.data(), d.chr_search_index = chr_search_index.data(), d.sv = sv.data(), d.chr_file_n = chr_file_n;
