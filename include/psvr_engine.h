@@ -8,8 +8,9 @@
  *
  * Seam B2 (kernel):  psvr_extd2_batch*  replaces  ksw_extd2_sse   (src/kswlib/ksw2.h:63-64)
  *                    psvr_extz2_batch   replaces  ksw_extz2_sse   (src/kswlib/ksw2.h:57-58)
- * Seam B3 (seeding): psvr_seed_*        replaces  deBGA_INDEX::search_kmer / UNITIG_MEM_search
- *                                                 (src/deBGA_index.hpp:198-201)
+ * Seam B3 (seeding): psvr_seed_batch    replaces  deBGA_INDEX::search_kmer / UNITIG_MEM_search
+ *                                                 (src/deBGA_index.hpp:205-208; built copy
+ *                                                  src/PanSVgenerateVCF/deBGA_index.hpp:198-201)
  * Seam B1 (batch):   psvr_engine_*      replaces  kt_for(worker_for -> align_read_pair)
  *                                                 (src/jlra_aln.cpp:115,140-147;
  *                                                  src/PanSVgenerateVCF/read_realignment.cpp:114,154-161,745-803)
@@ -102,8 +103,9 @@ int psvr_extz2_batch(int device, int64_t n,
 /*
  * Device-pointer form (all pointers are HIP device memory, `stream` is a hipStream_t or NULL):
  * nothing is copied and nothing synchronises; `work` is a device workspace of at least
- * psvr_extd2_workspace_bytes(...) bytes.  ez[i].cigar_off must be pre-set by the caller
- * (e.g. an exclusive scan of psvr_cigar_bound).  This is what bench.py times.
+ * psvr_dp_plan_workspace_bytes(plan) bytes.  ez[i].cigar_off must be pre-set by the caller
+ * (e.g. an exclusive scan of psvr_cigar_bound).  tools/dp_bench.py times this form; bench.py times
+ * psvr_engine_run (the whole path).
  */
 typedef struct psvr_dp_plan psvr_dp_plan_t;   /* opaque: size classes + index lists for one batch shape */
 int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen_host, const int32_t *tlen_host,
@@ -143,6 +145,9 @@ typedef struct psvr_index_view {           /* host pointers, element counts (not
 int psvr_index_create(const psvr_index_view_t *view, int device, psvr_index_t **out);
 /* reads the nine files from `index_dir` and the @SQ lines of `header_sam` */
 int psvr_index_load(const char *index_dir, const char *header_sam, int device, psvr_index_t **out);
+/* Multi-GPU: a second copy of an index that is already resident on another device, moved device to device (xGMI peer
+ * copies instead of N host uploads; SURVEY 8(e) "broadcast index").  `src` stays valid. */
+int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_t **out);
 void psvr_index_destroy(psvr_index_t *idx);
 int64_t psvr_index_device_bytes(const psvr_index_t *idx);
 int32_t psvr_index_n_anchor(const psvr_index_t *idx);
@@ -196,6 +201,20 @@ typedef struct psvr_read_result {
 	psvr_cand_t cand[PSVR_MAX_RESULT];
 } psvr_read_result_t;
 
+/* The same results in the form the engine keeps them in HBM: one 48-byte header per read and a dense list of only the
+ * candidates that exist (the fixed 12-slot psvr_read_result_t is materialised from these on request).  A pipeline that
+ * formats SAM records needs nothing else; a 1 M-pair batch comes back as ~0.2 GB instead of 1.35 GB. */
+typedef struct psvr_read_hdr {
+	int32_t n_result;
+	uint8_t unmapped, early_out, is_str, reserved;
+	int32_t primary, secondary;             /* -1 none, -2 the original alignment, k>=0 = cands[cand_off + k] */
+	int32_t has_mate, mate_chr_id;
+	uint32_t mate_ref_bg;
+	int32_t prim_sv_id, mate_sv_id;
+	int32_t reserved2;
+	int64_t cand_off;                       /* first of this read's n_result candidates in the candidate list */
+} psvr_read_hdr_t;
+
 typedef struct psvr_pair_result {           /* PE_score, read_realignment.hpp:434-628 */
 	int32_t max_score, cur_isize;
 	int32_t proper, gain;
@@ -219,6 +238,12 @@ int psvr_engine_upload(psvr_engine_t *eng, int64_t n_pairs, const char *bases, c
 int psvr_engine_run(psvr_engine_t *eng, int trace, void *stream);
 int psvr_engine_download(psvr_engine_t *eng, psvr_read_result_t *reads, psvr_pair_result_t *pairs,
                          uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used);
+/* Compact form of the same results: hdr[2*n_pairs], pairs[n_pairs], then only the candidates and CIGAR words that exist,
+ * densely packed in read order (cands[k].cigar_off indexes `cigar`).  Call with cands == NULL (or cigar == NULL) to learn
+ * cand_used / cigar_used first; PSVR_ERR_OVERFLOW if a capacity is too small (the counts are still returned). */
+int psvr_engine_download_compact(psvr_engine_t *eng, psvr_read_hdr_t *hdr, psvr_pair_result_t *pairs,
+                                 psvr_cand_t *cands, int64_t cand_cap, int64_t *cand_used,
+                                 uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used);
 /*
  * Multi-GPU: read pairs are independent given the index, except that the reference consumes ONE rand()/random_r draw
  * sequence in input order.  When consecutive shards of a batch run on different GPUs, shard r starts at the stream

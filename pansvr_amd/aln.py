@@ -14,6 +14,9 @@ READ_DTYPE = np.dtype([("n_result", "<i4"), ("unmapped", "u1"), ("early_out", "u
                        ("primary", "<i4"), ("secondary", "<i4"), ("has_mate", "<i4"), ("mate_chr_id", "<i4"), ("mate_ref_bg", "<u4"),
                        ("prim_sv_id", "<i4"), ("mate_sv_id", "<i4"), ("n_seed", "<u4", 2), ("seed_hash", "<u8", 2), ("chain_hash", "<u8", 2),
                        ("cand", CAND_DTYPE, 12)], align=True)
+HDR_DTYPE = np.dtype([("n_result", "<i4"), ("unmapped", "u1"), ("early_out", "u1"), ("is_str", "u1"), ("reserved", "u1"),
+                      ("primary", "<i4"), ("secondary", "<i4"), ("has_mate", "<i4"), ("mate_chr_id", "<i4"), ("mate_ref_bg", "<u4"),
+                      ("prim_sv_id", "<i4"), ("mate_sv_id", "<i4"), ("reserved2", "<i4"), ("cand_off", "<i8")], align=True)
 PAIR_DTYPE = np.dtype([("max_score", "<i4"), ("cur_isize", "<i4"), ("proper", "<i4"), ("gain", "<i4"), ("max1", "<i4"), ("max2", "<i4")])
 
 
@@ -115,6 +118,24 @@ class Engine:
                                          C.c_int64(len(cig)), C.byref(used)))
         return reads, pairs, cig
 
+    def download_compact(self, bufs=None):
+        """psvr_engine_download_compact: (hdr[2P], pairs[P], cands[sum n_result], cigar words) -- the form a record writer needs.
+        bufs: optional HostBuffers (page-locked)."""
+        P = self.n_pairs
+        L = lib()
+        nc, nw = C.c_int64(0), C.c_int64(0)
+        rc = L.psvr_engine_download_compact(self.h, None, None, None, C.c_int64(0), C.byref(nc), None, C.c_int64(0), C.byref(nw))
+        if rc not in (0, 6):
+            check(rc)
+        if bufs is None:
+            hdr, pairs = np.zeros(2 * P, dtype=HDR_DTYPE), np.zeros(P, dtype=PAIR_DTYPE)
+            cands, cig = np.zeros(int(nc.value) + 1, dtype=CAND_DTYPE), np.zeros(int(nw.value) + 1, dtype=np.uint32)
+        else:
+            hdr, pairs, cands, cig = bufs.compact_views(P, int(nc.value) + 1, int(nw.value) + 1)
+        check(L.psvr_engine_download_compact(self.h, hdr.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p), cands.ctypes.data_as(C.c_void_p),
+                                             C.c_int64(len(cands)), C.byref(nc), cig.ctypes.data_as(C.c_void_p), C.c_int64(len(cig)), C.byref(nw)))
+        return hdr, pairs, cands[:int(nc.value)], cig[:int(nw.value)]
+
     def download_into(self, bufs):
         """Like download(), into the caller's page-locked buffers (HostBuffers): the copies run at the link's rate."""
         P = self.n_pairs
@@ -137,8 +158,8 @@ class HostBuffers:
     """Page-locked result buffers from psvr_host_alloc, kept across batches (what a pipeline slot of the reference would own)."""
 
     def __init__(self):
-        self._p = [None, None, None]
-        self._cap = [0, 0, 0]
+        self._p = [None, None, None, None]
+        self._cap = [0, 0, 0, 0]
 
     def _get(self, i, nbytes):
         if nbytes > self._cap[i]:
@@ -161,8 +182,15 @@ class HostBuffers:
         cig = np.frombuffer(self._get(2, n_cig * 4), dtype=np.uint32)
         return reads, pairs, cig
 
+    def compact_views(self, n_pairs, n_cand, n_cig):
+        hdr = np.frombuffer(self._get(0, 2 * n_pairs * HDR_DTYPE.itemsize), dtype=HDR_DTYPE)
+        pairs = np.frombuffer(self._get(1, max(1, n_pairs) * PAIR_DTYPE.itemsize), dtype=PAIR_DTYPE)[:n_pairs]
+        cands = np.frombuffer(self._get(3, n_cand * CAND_DTYPE.itemsize), dtype=CAND_DTYPE)
+        cig = np.frombuffer(self._get(2, n_cig * 4), dtype=np.uint32)
+        return hdr, pairs, cands, cig
+
     def close(self):
-        for i in range(3):
+        for i in range(4):
             if self._p[i]:
                 lib().psvr_host_free.argtypes = [C.c_void_p]
                 lib().psvr_host_free(self._p[i])

@@ -162,7 +162,8 @@ struct Ctx {
 	uint8_t *seed_list;          // [read][lmax]
 	Strand *strand;              // [read][2]
 	ChainCand *ccand; int32_t *n_ccand;      // [read][12]
-	psvr_read_result_t *res; psvr_pair_result_t *pres;
+	psvr_read_hdr_t *rh; psvr_pair_result_t *pres;   // per read: compact header; per slot: pairing result
+	psvr_cand_t *cand;           // candidate records, parallel to the CandWork arena (a read's candidates are contiguous: rh.cand_off)
 	// arenas
 	Arena<VMem> mem; Arena<USeed> us; PathN *path;   // path shares the us arena's offsets
 	Arena<Seg> seg; Arena<DpDesc> dp; Arena<CandWork> cw; Arena<uint32_t> cig;
@@ -1004,6 +1005,7 @@ PSVR_HDN inline void walk_read(const Ctx &c, long long read)
 	const long long cw0 = arena_alloc(c.cw, (unsigned long long)nc);
 	long long so = arena_alloc(c.seg, (unsigned long long)total);
 	if (cw0 < 0 || so < 0) return;
+	c.rh[read].cand_off = cw0;                       // candidate k of this read lives at cand[cw0 + k]
 	int n_dp = 0;
 	const long long so0 = so;
 	for (int k = 0; k < nc; ++k) {
@@ -1092,8 +1094,7 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	if (have) { if (n < kCigMax) out[n++] = back; else bad = 1; }
 	int first = 0;
 	if (n > 0 && out[0].size == 0) first = 1;                      // cigar.erase(cigar.begin())
-	psvr_read_result_t &rr = c.res[cw.read];
-	psvr_cand_t &pc = rr.cand[cw.k];
+	psvr_cand_t &pc = c.cand[cwi];                   // == cand[rh.cand_off + cw.k]
 	const ChainCand &cc = c.ccand[(long long)cw.read * 12 + cw.k];
 	pc.align_score = score > 0 ? (uint32_t)score : 0;
 	pc.chain_score = cc.chain_score;
@@ -1116,15 +1117,12 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 // rest of single_end_handler::align (rr.cpp:453-475)
 PSVR_HDN inline void finalize_read(const Ctx &c, long long read)
 {
-	psvr_read_result_t &rr = c.res[read];
-	rr.unmapped = c.unmapped[read], rr.early_out = !c.active[read], rr.is_str = c.is_str[read], rr.reserved = 0;
+	psvr_read_hdr_t &rr = c.rh[read];
+	rr.unmapped = c.unmapped[read], rr.early_out = !c.active[read], rr.is_str = c.is_str[read], rr.reserved = 0, rr.reserved2 = 0;
 	rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
-	for (int s = 0; s < 2; ++s) {
-		const Strand &st = c.strand[read * 2 + s];
-		rr.n_seed[s] = st.us_n, rr.seed_hash[s] = st.seed_hash, rr.chain_hash[s] = st.chain_hash;
-	}
 	int n = c.active[read] ? c.n_ccand[read] : 0;
-	psvr_cand_t *cd = rr.cand;
+	if (n <= 0) rr.cand_off = 0;                      // walk_read set it for the reads that have candidates
+	psvr_cand_t *cd = c.cand + rr.cand_off;
 	for (int i = 1; i < n; ++i) {                                        // cmp_align_score (rr.hpp:310-315), stable
 		psvr_cand_t x = cd[i];
 		int j = i;
@@ -1153,10 +1151,10 @@ struct PeItem { uint32_t align_score, chr_id, ref_bg; int32_t direction, is_ori,
 
 PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i)
 {
-	const psvr_read_result_t &rr = c.res[read];
+	const psvr_read_hdr_t &rr = c.rh[read];
 	PeItem p;
 	if (i < rr.n_result) {
-		const psvr_cand_t &d = rr.cand[i];
+		const psvr_cand_t &d = c.cand[rr.cand_off + i];
 		p.align_score = d.align_score, p.chr_id = (uint32_t)d.chr_id, p.ref_bg = d.ref_bg, p.direction = d.direction, p.is_ori = 0, p.sv_id = d.sv_id;
 		p.end_offset = c.idx.sv[d.sv_id].end_offset;
 	} else {
@@ -1171,7 +1169,7 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 	const long long r0 = pair * 2, r1 = r0 + 1;
 	const long long item = pair * 3 + 2;
 	for (int e = 0; e < 2; ++e) {       // re-runnable: the pairing stage alone is repeated when only its draw offset moved
-		psvr_read_result_t &rr = c.res[r0 + e];
+		psvr_read_hdr_t &rr = c.rh[r0 + e];
 		rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
 	}
 	const long long ro = c.poff[pair] + c.rcnt[pair * 3] + c.rcnt[pair * 3 + 1];
@@ -1182,7 +1180,7 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 	const int nrl = c.par.normal_read_length;
 	int max_same = 1, max_score = 0, cur_isize = 0, m1 = -1, m2 = -1;   // -1 NULL, else item index
 	bool proper = false;
-	int n0 = c.res[r0].n_result, n1 = c.res[r1].n_result;
+	int n0 = c.rh[r0].n_result, n1 = c.rh[r1].n_result;
 	const int nr0 = n0, nr1 = n1;
 	if (!c.unmapped[r0]) n0++;
 	if (!c.unmapped[r1]) n1++;
@@ -1237,7 +1235,7 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 		const int mine = e == 0 ? m1 : m2, other = e == 0 ? m2 : m1;
 		const int nmine = e == 0 ? nr0 : nr1, nother = e == 0 ? nr1 : nr0;
 		if (mine < 0) continue;
-		psvr_read_result_t &rr = c.res[rd];
+		psvr_read_hdr_t &rr = c.rh[rd];
 		const bool is_ori = mine >= nmine;
 		rr.primary = is_ori ? -2 : mine;
 		rr.secondary = -1;
@@ -1249,13 +1247,36 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 			PeItem mt = pe_item(c, e == 0 ? r1 : r0, other);
 			(void)nother;
 			if (mt.chr_id != 0xffffffffu) {
-				rr.has_mate = 1, rr.mate_chr_id = (int32_t)mt.chr_id, rr.mate_ref_bg = mt.ref_bg, rr.mate_sv_id = mt.sv_id;
-				if (is_ori) rr.prim_sv_id = mt.sv_id;
+				// The reference handles read 0 first and stores the SV of an ORIGINAL primary in the shared `ori` object
+				// (`c_rst->sv_info_p = c_rst->mate_sv_info_p`, rr.hpp:524-526), so when read 1's turn comes an original mate already
+				// carries the SV it inherited -- from read 1 itself.  Read 0 looks at read 1's original before that assignment.
+				const int32_t mate_sv = (e == 1 && mt.is_ori) ? c.rh[r0].prim_sv_id : mt.sv_id;
+				rr.has_mate = 1, rr.mate_chr_id = (int32_t)mt.chr_id, rr.mate_ref_bg = mt.ref_bg, rr.mate_sv_id = mate_sv;
+				if (is_ori) rr.prim_sv_id = mate_sv;
 				continue;
 			}
 		}
 		rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_sv_id = -1;
 	}
+}
+
+// the fixed-size ABI record of one read (psvr_read_result_t) from the compact header, the candidate list and the strand
+// bookkeeping; `out` is written completely (unused candidate slots are zero)
+PSVR_HD void materialize_read(const Ctx &c, long long read, psvr_read_result_t *out)
+{
+	const psvr_read_hdr_t &h = c.rh[read];
+	psvr_read_result_t &o = *out;
+	o.n_result = h.n_result, o.unmapped = h.unmapped, o.early_out = h.early_out, o.is_str = h.is_str, o.reserved = 0;
+	o.primary = h.primary, o.secondary = h.secondary, o.has_mate = h.has_mate, o.mate_chr_id = h.mate_chr_id, o.mate_ref_bg = h.mate_ref_bg;
+	o.prim_sv_id = h.prim_sv_id, o.mate_sv_id = h.mate_sv_id;
+	for (int s = 0; s < 2; ++s) {
+		const Strand &st = c.strand[read * 2 + s];
+		o.n_seed[s] = st.us_n, o.seed_hash[s] = st.seed_hash, o.chain_hash[s] = st.chain_hash;
+	}
+	uint32_t *w = (uint32_t *)o.cand;
+	const uint32_t *src = (const uint32_t *)(c.cand + h.cand_off);
+	const int nw = (int)(sizeof(psvr_cand_t) / 4), have = h.n_result * nw;
+	for (int i = 0; i < PSVR_MAX_RESULT * nw; ++i) w[i] = i < have ? src[i] : 0u;
 }
 
 // which pairs consumed draws from an offset that the scan of the actual draw counts has since moved?
@@ -1283,12 +1304,14 @@ PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, cons
 PSVR_HD void adopt_variant(const Ctx &c, long long pair, long long slot, const long long *noff, int part, int parts)
 {
 	if (c.hcnt[2 * slot] != 0 || c.hcnt[2 * slot + 1] != 0) return;
-	const uint32_t *src = (const uint32_t *)(c.res + 2 * slot);
-	uint32_t *dst = (uint32_t *)(c.res + 2 * pair);
-	const int nw = (int)(2 * sizeof(psvr_read_result_t) / 4);
+	// the two headers (cand_off keeps pointing at the variant slot's candidates: they are this pair's now) and the trace hashes
+	const uint32_t *src = (const uint32_t *)(c.rh + 2 * slot);
+	uint32_t *dst = (uint32_t *)(c.rh + 2 * pair);
+	const int nw = (int)(2 * sizeof(psvr_read_hdr_t) / 4);
 	for (int i = part; i < nw; i += parts) dst[i] = src[i];
 	if (part == 0) {
 		c.pres[pair] = c.pres[slot];
+		for (int k = 0; k < 4; ++k) c.strand[4 * pair + k] = c.strand[4 * slot + k];      // seed counts / trace hashes travel with the records
 		for (int k = 0; k < 3; ++k) c.rcnt[3 * pair + k] = c.rcnt[3 * slot + k];
 		c.hcnt[2 * pair] = c.hcnt[2 * pair + 1] = 0;
 		c.poff[pair] = noff[pair];                                       // mark_dirty then finds the pair where it belongs

@@ -86,34 +86,43 @@ struct BamRecord {                     // one alignment, fields as in bam1_core_
 	const uint8_t *qual() const { return seq() + (l_qseq + 1) / 2; }
 	const uint8_t *aux() const { return qual() + l_qseq; }
 	const uint8_t *aux_end() const { return data.data() + data.size(); }
-	// bam_aux_get: pointer to the type byte of the tag, or null
+	// bam_aux_get: pointer to the type byte of the tag, or null.  A tag is only returned when its whole value lies inside the
+	// record (Z/H: including the terminating NUL), so num_tag()/string_tag() and their callers never read past the end of a
+	// malformed record.
 	const uint8_t *aux_get(const char tag[2]) const
 	{
 		const uint8_t *p = aux(), *e = aux_end();
 		while (p + 3 <= e) {
 			const bool hit = p[0] == (uint8_t)tag[0] && p[1] == (uint8_t)tag[1];
 			const uint8_t *v = p + 2;
-			if (hit) return v;
 			const char t = (char)v[0];
-			++v;
+			const uint8_t *val = v + 1;
 			size_t sz = 0;
 			switch (t) {
 			case 'A': case 'c': case 'C': sz = 1; break;
 			case 's': case 'S': sz = 2; break;
 			case 'i': case 'I': case 'f': sz = 4; break;
 			case 'd': sz = 8; break;
-			case 'Z': case 'H': { const uint8_t *q = v; while (q < e && *q) ++q; sz = (size_t)(q - v) + 1; break; }
+			case 'Z': case 'H': {
+				const uint8_t *q = val;
+				while (q < e && *q) ++q;
+				if (q >= e) return nullptr;                      // no terminator inside the record
+				sz = (size_t)(q - val) + 1;
+				break;
+			}
 			case 'B': {
-				if (v + 5 > e) return nullptr;
-				const char st = (char)v[0];
-				const uint32_t cnt = v[1] | (uint32_t)v[2] << 8 | (uint32_t)v[3] << 16 | (uint32_t)v[4] << 24;
+				if (val + 5 > e) return nullptr;
+				const char st = (char)val[0];
+				const uint32_t cnt = val[1] | (uint32_t)val[2] << 8 | (uint32_t)val[3] << 16 | (uint32_t)val[4] << 24;
 				const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
-				sz = 5 + es * cnt;
+				sz = 5 + es * (size_t)cnt;
 				break;
 			}
 			default: return nullptr;
 			}
-			p = v + sz;
+			if (sz > (size_t)(e - val)) return nullptr;          // the value runs past the record
+			if (hit) return v;
+			p = val + sz;
 		}
 		return nullptr;
 	}
@@ -183,7 +192,8 @@ public:
 		r.l_qseq = i32(16), r.mtid = i32(20), r.mpos = i32(24), r.isize = i32(28);
 		r.data.resize((size_t)block - 32);
 		if (block > 32 && !z.read(r.data.data(), (size_t)block - 32)) { err = "truncated BAM record"; return false; }
-		if ((size_t)r.l_qname + 4 * (size_t)r.n_cigar + (size_t)(r.l_qseq + 1) / 2 + (size_t)r.l_qseq > r.data.size() || r.l_qseq < 0) { err = "bad BAM record"; return false; }
+		if (r.l_qseq < 0 || (size_t)r.l_qname + 4 * (size_t)r.n_cigar + (size_t)((size_t)r.l_qseq + 1) / 2 + (size_t)r.l_qseq > r.data.size()) { err = "bad BAM record"; return false; }
+		if (r.l_qname == 0 || r.data[(size_t)r.l_qname - 1] != 0) { err = "bad BAM record (read name not NUL-terminated)"; return false; }   // qname() is used as a C string
 		return true;
 	}
 };

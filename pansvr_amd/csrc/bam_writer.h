@@ -95,6 +95,18 @@ public:
 	}
 };
 
+// htslib's seq_nt16_table (hts.c:62-80): the 4-bit code a SEQ character is stored as -- IUPAC letters in either case, '=' and
+// the digits 0-3 (A, C, G, T); everything else is N.  A record that went through BAM comes back as "=ACMGRSVTWYHKDBN"[code].
+inline int nt16_code(char ch)
+{
+	static const char *nt16 = "=ACMGRSVTWYHKDBN";
+	if (ch >= '0' && ch <= '3') return 1 << (ch - '0');
+	if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+	const char *q = ch ? strchr(nt16, ch) : nullptr;
+	return q ? (int)(q - nt16) : 15;
+}
+inline char nt16_char(char ch) { return "=ACMGRSVTWYHKDBN"[nt16_code(ch)]; }
+
 struct BamRef { std::string name; uint32_t len; };
 
 // one alignment record in SAM terms (what the CLI's emit_record prints)
@@ -219,10 +231,8 @@ public:
 		rec_.insert(rec_.end(), s.qname.begin(), s.qname.end());
 		rec_.push_back(0);
 		for (uint32_t c : cig) put32(rec_, c);
-		static const char *nt16 = "=ACMGRSVTWYHKDBN";
 		for (uint32_t i = 0; i < l_seq; i += 2) {
-			auto code = [&](char ch) { const char *q = strchr(nt16, ch >= 'a' && ch <= 'z' ? ch - 32 : ch); return q && ch ? (int)(q - nt16) : 15; };
-			const int hi = code(s.seq[i]), lo = i + 1 < l_seq ? code(s.seq[i + 1]) : 0;
+			const int hi = nt16_code(s.seq[i]), lo = i + 1 < l_seq ? nt16_code(s.seq[i + 1]) : 0;
 			rec_.push_back((uint8_t)(hi << 4 | lo));
 		}
 		if (s.qual.empty() || s.qual == "*" || s.qual.size() != l_seq) rec_.insert(rec_.end(), l_seq, 0xff);

@@ -1,25 +1,33 @@
 // cli_main.cpp -- `panSVR aln` / `panSVR fc_aln` on the MI355X engine: the host side of the reference's
 // three-stage pipeline (load_reads -> [engine] -> output_results; src/PanSVgenerateVCF/read_realignment.cpp:26-176)
 // above the C ABI of include/psvr_engine.h.  Same options, positional arguments, stderr progress
-// lines and SAM records as the reference; every other sub-command of panSVR is out of scope.
+// lines and SAM/BAM records as the reference; every other sub-command of panSVR is out of scope.
 //
-// It links libpsvr_engine.so only through psvr_engine.h; host_io.h is host-side parsing/formatting.
+// It links libpsvr_engine.so only through psvr_engine.h.  Host-side pieces: fastq_batch.h (step 0: batches parsed straight
+// into page-locked upload buffers), sam_emit.h + bam_writer.h (step 2: records of the pairs that are written).
+//
+// Multi-GPU (`--devices 0,1,...`): the index is resident on every device (one host upload, then device-to-device copies),
+// every batch is cut into contiguous blocks -- pair i of n goes to device floor(i * D / n), kt_for's contract of independent
+// items (clib/kthread.c:43-86) with the order kept -- and because the reference draws from ONE rand()/random_r sequence in input
+// order, block d is moved to start where block d-1 ended (psvr_engine_rebase) before the ordered gather into step 2.
 #include <getopt.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
 #include <time.h>
+#include <unistd.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
-#include <signal.h>
-#include <unistd.h>
 #include <vector>
 #include "../../include/psvr_engine.h"
 #include "host_io.h"
+#include "fastq_batch.h"
+#include "sam_emit.h"
 #include "bam_writer.h"
 #include "index_build.h"
 #include "signal_step.h"
@@ -35,8 +43,9 @@ struct Opt {
 	std::string index_dir, reads, header;
 	std::string records;      // --records FILE: one JSON line per pair (what the parity tests compare)
 	bool trace = false;
-	int device = 0;
-	long long batch_pairs = 2000000;   // N_NEEDED, rr.cpp:24
+	std::vector<int> devices = {0};
+	long long batch_pairs = 2000000;       // N_NEEDED, rr.cpp:24
+	long long batch_bases = 100000000;     // MAX_read_size, rr.cpp:109 (333 334 pairs of 150 bp: the limit that actually binds)
 	bool sig_all = false, sig_discard = false;   // BAM input: fc_signal's -D / -U
 };
 
@@ -46,13 +55,13 @@ static int usage()
 	        "\n  Usage:     panSVR  aln|fc_aln  [Options] <IndexDir> [ReadFiles.fa][ori_header_fn.sam]>\n"
 	        "  Basic:   \n"
 	        "    <IndexDir>      FOLDER   the directory contains index\n"
-	        "    [ReadFiles.fa]  FILES    reads files, FASTQ(A) format, read 1 and 2 of a pair stored together ('-' = stdin),\n"
-	        "                             or a name-sorted *.bam: the signal step then runs in-process ([ori_header.sam] is written;\n"
-	        "                             -D / -U as in fc_signal: all pairs are signals / drop fully matching pairs)\n"
+	        "    [ReadFiles.fa]  FILES    reads files, FASTQ(A) format (or fq.gz), read 1 and 2 of a pair stored together ('-' = stdin),\n"
+	        "                             or a *.bam: the signal step then runs in-process ([ori_header.sam] is written;\n"
+	        "                             -N / -D / -U as in fc_signal: name-sorted input / all pairs are signals / drop fully matching pairs)\n"
 	        "                             Using [signal] command to generate this type of file\n"
 	        "    [ori_header.sam]  FILES  Header file of original BAM/CRAM file\n"
 	        "  Options:\n"
-	        "    -t, --thread            INT  accepted for compatibility (the engine runs on the GPU) [4]\n"
+	        "    -t, --thread            INT  host threads for parsing / formatting / compression (the alignment runs on the GPU) [4]\n"
 	        "    -O, --gap-open1         INT  Gap open penalty 1 [16]\n"
 	        "    -P, --gap-open2         INT  Gap open penalty 2 [32]\n"
 	        "    -E, --gap-extension1    INT  Gap extension penalty 1 [1]\n"
@@ -66,73 +75,21 @@ static int usage()
 	        "    -Q, --not-ori                NOT output original result when score of ORI is bigger\n"
 	        "    -S, --SAM                    Output as SAM, default is BAM\n"
 	        "    -R, --max_use_read      INT  Max number of read pairs to align\n"
-	        "        --device            INT  HIP device [0]\n"
+	        "        --devices           LIST HIP devices, e.g. 0,1,2,3 or 0-7: every batch is split over them in input order [0]\n"
+	        "        --device            INT  the same for one device\n"
+	        "        --batch             INT  read pairs per batch [2000000]\n"
+	        "        --batch-bases       INT  bases per batch (the reference stops a batch at 100 MB of bases) [100000000]\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
 	        "        --trace                  add per-strand seed/chain hashes to --records\n\n");
 	return 1;
 }
 
-static double cputime()
-{
-	return (double)clock() / CLOCKS_PER_SEC;
-}
-
+static double cputime() { return (double)clock() / CLOCKS_PER_SEC; }
 static double walltime()
 {
 	struct timeval tv;
 	gettimeofday(&tv, nullptr);
 	return tv.tv_sec + 1e-6 * tv.tv_usec;
-}
-
-static char rc_char(char c)   // getReverseChar, clib/bam_file.c:316-327
-{
-	switch (c) {
-	case 'A': case 'a': return 'T';
-	case 'C': case 'c': return 'G';
-	case 'G': case 'g': return 'C';
-	case 'T': case 't': return 'A';
-	}
-	return 'N';
-}
-static void rev_seq(std::string &s)   // getReverseStr_char, clib/bam_file.c:329-339
-{
-	int len = (int)s.size(), half = len >> 1;
-	for (int i = 0; i < half; i++) { char t = s[i]; s[i] = rc_char(s[len - 1 - i]); s[len - 1 - i] = rc_char(t); }
-	if (len & 1) s[half] = rc_char(s[half]);
-}
-static void rev_qual(std::string &q)  // getReverseStr_qual_char, clib/bam_file.c:351-359: loop bound len/2 + 1 (even len: middle pair swapped back)
-{
-	int len = (int)q.size(), half = len >> 1;
-	for (int i = 0; i < half + 1; i++) { int ri = len - 1 - i; if (ri < 0 || i >= len) break; char t = q[i]; q[i] = q[ri]; q[ri] = t; }
-}
-
-struct HeaderInfo {
-	std::string text;
-	std::vector<std::string> names;
-	std::vector<uint32_t> lens;
-	const char *name(int id) const { return id >= 0 && id < (int)names.size() ? names[id].c_str() : "*"; }
-};
-
-static bool load_header(const std::string &fn, HeaderInfo *h)
-{
-	FILE *f = fopen(fn.c_str(), "r");
-	if (!f) return false;
-	char buf[65536];
-	while (fgets(buf, sizeof buf, f)) {
-		if (buf[0] != '@') continue;
-		h->text += buf;
-		if (strncmp(buf, "@SQ", 3)) continue;
-		char *p = strstr(buf, "SN:");
-		if (!p) continue;
-		p += 3;
-		char *e = p;
-		while (*e && *e != '\t' && *e != '\n') ++e;
-		h->names.emplace_back(p, e - p);
-		const char *ln = strstr(buf, "LN:");
-		h->lens.push_back(ln ? (uint32_t)strtoul(ln + 3, nullptr, 10) : 0u);
-	}
-	fclose(f);
-	return true;
 }
 
 // one output file: SAM text (-S) or BAM (default, like the reference's init_run)
@@ -143,7 +100,7 @@ struct OutFile {
 	bool open(const std::string &fn, bool as_bam, const HeaderInfo &H, int threads)
 	{
 		is_bam = as_bam;
-		if (!as_bam) { sam = fopen(fn.c_str(), "w"); if (sam) fputs(H.text.c_str(), sam); return sam != nullptr; }
+		if (!as_bam) { sam = fopen(fn.c_str(), "w"); if (sam) { setvbuf(sam, nullptr, _IOFBF, 1 << 22); fputs(H.text.c_str(), sam); } return sam != nullptr; }
 		std::vector<psvr::BamRef> refs;
 		for (size_t i = 0; i < H.names.size(); ++i) refs.push_back({H.names[i], H.lens[i]});
 		return bam.open(fn.c_str(), H.text, refs, threads);
@@ -153,90 +110,11 @@ struct OutFile {
 	bool close() { if (is_bam) return bam.close(); return fclose(sam) == 0; }
 };
 
-// what survives sam_parse1 -> sam_write1 (htslib 1.9 sam.c:1197-1424, sam_format1) for the text built by
-// single_end_handler::output_BAM (rr.cpp:479-536): POS <= 0 drops the record, RNEXT collapses to '=' ...
-static bool emit_record(const OutFile &out, std::vector<uint8_t> &dst, const HeaderInfo &H, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar,
-                        bool has_mate, int mate_chr, uint32_t mate_pos, int isize, const std::string &seq, const std::string &qual, const std::string &tags)
-{
-	int pos = (int)ref_bg;                               // printed with %d
-	if (chr_id < 0 || chr_id >= (int)H.names.size()) return false;   // target_name[] would be out of range in the reference
-	if (pos - 1 < 0) return false;                       // "mapped query cannot have zero coordinate; treated as unmapped" -> tid = -1 -> not written
-	std::string rnext = "*";
-	long pnext = 0;
-	int mtid = -1;
-	if (has_mate) {
-		int mp = (int)mate_pos;
-		bool mate_ok = mate_chr >= 0 && mate_chr < (int)H.names.size() && !(mp - 1 < 0);
-		if (mate_ok) rnext = mate_chr == chr_id ? "=" : H.name(mate_chr), mtid = mate_chr;
-		pnext = mp;
-	}
-	if (out.is_bam) {
-		psvr::SamFields f;
-		f.qname = name, f.flag = flag, f.tid = chr_id, f.pos1 = pos, f.mapq = mapq, f.cigar = cigar.empty() ? "*" : cigar;
-		f.mtid = mtid, f.mpos1 = pnext, f.isize = isize, f.seq = seq, f.qual = qual, f.tags = tags;
-		return psvr::BamWriter::encode(f, dst);
-	}
-	char head[512];
-	int n = snprintf(head, sizeof head, "\t%d\t%s\t%d\t%d\t", flag, H.name(chr_id), pos, mapq);
-	auto put = [&](const char *p, size_t m) { dst.insert(dst.end(), (const uint8_t *)p, (const uint8_t *)p + m); };
-	put(name.data(), name.size()), put(head, (size_t)n);
-	if (cigar.empty()) put("*", 1); else put(cigar.data(), cigar.size());
-	n = snprintf(head, sizeof head, "\t%s\t%ld\t%d\t", rnext.c_str(), pnext, isize);
-	put(head, (size_t)n), put(seq.data(), seq.size()), put("\t", 1), put(qual.data(), qual.size()), put(tags.data(), tags.size()), put("\n", 1);
-	return true;
-}
-
-// single_end_handler::output_ori_bam (rr.cpp:656-717): the ORIGINAL alignment re-assembled from the comment's
-// FLAG_/CIGAR_/MATE_/TAG_ sections (+ MS:i:max_score); returns false when the record would not be written
-struct OriRecord { int flag = 0, mapq = 0, mate_chr = -1, mate_pos = 0, isize = 0; std::string cigar, tags; };
-static bool parse_ori_record(const std::string &comment, OriRecord *r)
-{
-	const char *c = comment.c_str();
-	const char *f = strstr(c, "FLAG_");
-	if (!f) return false;
-	unsigned fl = 0, q = 0;
-	if (sscanf(f + 5, "%u_%u_", &fl, &q) < 2) return false;
-	r->flag = (int)fl, r->mapq = (int)q;
-	const char *cg = strstr(f + 5, "CIGAR_");
-	if (!cg) return false;
-	cg += 6;
-	const char *ce = strchr(cg, '_');
-	if (!ce) return false;
-	r->cigar.assign(cg, ce - cg);
-	const char *mate = ce + 1 + 5;                           // skips "MATE_"
-	if (strlen(ce) < 6 || sscanf(mate, "%d_%d_%d_", &r->mate_chr, &r->mate_pos, &r->isize) < 3) return false;
-	r->mate_pos += 1;
-	const char *tg = strstr(mate, "TAG_");
-	if (!tg) return false;
-	std::string tags = tg + 4;
-	const int tl = (int)tags.size();
-	for (int i = 0; i < tl - 5; i++) if (tags[i] == '_' && tags[i + 3] == ':' && tags[i + 5] == ':') tags[i] = '\t';
-	if (tl > 0) tags.resize(tl - 1);
-	r->tags = tags;
-	return true;
-}
-
-// bam_has_clip_or_unmapped_ori (rr.cpp:721-733) on the CIGAR text
-static bool ori_has_clip(const std::string &cigar, int min_clip)
-{
-	if (cigar.empty() || cigar == "*") return true;
-	std::vector<std::pair<int, char>> ops;
-	int n = 0;
-	for (char ch : cigar) { if (ch >= '0' && ch <= '9') n = n * 10 + (ch - '0'); else { ops.push_back({n, ch}); n = 0; } }
-	if (ops.empty()) return true;
-	int tot = 0;
-	if (ops.front().second == 'S' || ops.front().second == 'H') tot += ops.front().first;
-	if (ops.back().second == 'S' || ops.back().second == 'H') tot += ops.back().first;
-	return tot >= min_clip;
-}
-
-static std::string cigar_string(const psvr_cand_t &c, const uint32_t *cig)
-{
-	std::string s;
-	char b[32];
-	for (uint32_t j = 0; j < c.n_cigar; ++j) { uint32_t w = cig[c.cigar_off + j]; snprintf(b, sizeof b, "%d%c", (int)(int16_t)(w >> 4), "MIDNSHP=XB"[w & 0xf]); s += b; }
-	return s;
-}
+struct IndexSvNames : SvNames {
+	const psvr_index_t *idx = nullptr;
+	const char *print_string(int sv) const override { return psvr_index_sv_print_string(idx, sv); }
+	const char *vcf_id(int sv) const override { return psvr_index_sv_vcf_id(idx, sv); }
+};
 
 // `panSVR index [-k 22] [--sparse-hash] <anchors.fa> <IndexDir>`: what `deBGA index -k 22 <anchors.fa> <IndexDir>` builds
 // (panSVR_run.sh runs it on the SV anchor reference before `aln`).  Host only.
@@ -260,22 +138,46 @@ static int index_main(int argc, char **argv)
 	return 0;
 }
 
+static bool parse_devices(const char *s, std::vector<int> *out)
+{
+	out->clear();
+	const char *p = s;
+	while (*p) {
+		char *e;
+		long a = strtol(p, &e, 10), b = a;
+		if (e == p || a < 0) return false;
+		if (*e == '-') { const char *q = e + 1; b = strtol(q, &e, 10); if (e == q || b < a) return false; }
+		for (long d = a; d <= b; ++d) out->push_back((int)d);
+		if (*e == ',') ++e; else if (*e) return false;
+		p = e;
+	}
+	return !out->empty() && out->size() <= 64;
+}
+
+[[noreturn]] static void die(const char *what)
+{
+	fprintf(stderr, "[panSVR-amd] %s: %s\n", what, psvr_last_error());
+	abort();                                                // the reference's xassert / xopen end the same way
+}
+
 int main(int argc, char **argv)
 {
 	if (argc >= 2 && !strcmp(argv[1], "index")) return index_main(argc, argv);
 	if (argc >= 2 && (!strcmp(argv[1], "signal") || !strcmp(argv[1], "fc_signal"))) return psvr::signal_main(argc, argv);
 	if (argc < 2 || (strcmp(argv[1], "aln") && strcmp(argv[1], "fc_aln"))) {
-		fprintf(stderr, "panSVR (MI355X engine): the read re-alignment step and its two neighbours.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n         panSVR index [-k 22] <anchors.fa> <IndexDir>\n         panSVR signal -N [options] <name-sorted.bam> > reads.fq\n");
+		fprintf(stderr, "panSVR (MI355X engine): the read re-alignment step and its two neighbours.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n         panSVR index [-k 22] <anchors.fa> <IndexDir>\n         panSVR signal [-N] [options] <in.bam> > reads.fq\n");
 		return 1;
 	}
 	Opt o;
 	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
 	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
 	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
-	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {0, 0, 0, 0}};
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005},
+	                             {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {"sort-by-name", 0, 0, 'N'}, {0, 0, 0, 0}};
 	int c;
+	bool sig_by_name = false;
 	optind = 2;
-	while ((c = getopt_long(argc, argv, "t:O:P:E:F:M:m:z:w:o:p:QSR:DU", lo, NULL)) >= 0) {
+	while ((c = getopt_long(argc, argv, "t:O:P:E:F:M:m:z:w:o:p:QSR:DUN", lo, NULL)) >= 0) {
 		switch (c) {
 		case 't': o.thread_n = atoi(optarg); break;
 		case 'O': o.gap_open = atoi(optarg); break;
@@ -291,21 +193,25 @@ int main(int argc, char **argv)
 		case 'Q': o.not_ori = true; break;
 		case 'S': o.sam = true; break;
 		case 'R': o.max_use_read = atoll(optarg); break;
-		case 1000: o.device = atoi(optarg); break;
+		case 1000: o.devices = {atoi(optarg)}; break;
 		case 1001: o.records = optarg; break;
 		case 1002: o.trace = true; break;
 		case 1003: o.batch_pairs = atoll(optarg); break;
+		case 1004: if (!parse_devices(optarg, &o.devices)) { fprintf(stderr, "bad --devices list '%s'\n", optarg); return 1; } break;
+		case 1005: o.batch_bases = atoll(optarg); break;
 		case 'D': o.sig_all = true; break;
 		case 'U': o.sig_discard = true; break;
+		case 'N': sig_by_name = true; break;
 		default: return usage();
 		}
 	}
 	if (argc - optind < 3) return usage();
 	if (!(o.thread_n >= 1 && o.thread_n <= 48)) { fprintf(stderr, "Input error: thread_n cannot be less than 1 or more than 48\n"); abort(); }   // xassert, rr.hpp:121
+	if (o.batch_pairs < 1) o.batch_pairs = 1;
 	o.index_dir = argv[optind], o.reads = argv[optind + 1], o.header = argv[optind + 2];
 
-	// <reads> may be a name-sorted BAM (*.bam): the signal step then runs in this process (default options of fc_signal) and its
-	// FASTQ goes through a pipe to the reader below; <header.sam> is WRITTEN from the BAM's header in that case
+	// <reads> may be a BAM (*.bam): the signal step then runs in this process (options of fc_signal: -N for name-sorted input,
+	// position-sorted otherwise) and hands its FASTQ text through a pipe to the reader below; <header.sam> is WRITTEN from the BAM's header
 	const bool from_bam = o.reads.size() > 4 && o.reads.compare(o.reads.size() - 4, 4, ".bam") == 0;
 	if (from_bam) {
 		psvr::BamReader rd;
@@ -317,15 +223,28 @@ int main(int argc, char **argv)
 	}
 	HeaderInfo H;
 	fprintf(stderr, "Open original header file [%s]\n", o.header.c_str());
-	if (!load_header(o.header, &H)) { fprintf(stderr, "fail to open file '%s'\n", o.header.c_str()); abort(); }
+	if (!H.load(o.header)) { fprintf(stderr, "fail to open file '%s'\n", o.header.c_str()); abort(); }
 	fprintf(stderr, "Begin loading index @%s\n", o.index_dir.c_str());
-	psvr_index_t *idx = nullptr;
-	if (psvr_index_load(o.index_dir.c_str(), o.header.c_str(), o.device, &idx)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
+	const double t_idx0 = walltime();
+	const int D = (int)o.devices.size();
+	// one index per DISTINCT device: the first comes from the files, the others from it, device to device
+	std::vector<psvr_index_t *> idx((size_t)D, nullptr);
+	double t_idx_first = 0, t_idx_clone = 0;
+	for (int d = 0; d < D; ++d) {
+		int same = -1;
+		for (int q = 0; q < d; ++q) if (o.devices[(size_t)q] == o.devices[(size_t)d]) { same = q; break; }
+		if (same >= 0) { idx[(size_t)d] = idx[(size_t)same]; continue; }
+		const double t0 = walltime();
+		if (d == 0) { if (psvr_index_load(o.index_dir.c_str(), o.header.c_str(), o.devices[0], &idx[0])) die("index"); t_idx_first = walltime() - t0; }
+		else { if (psvr_index_clone(idx[0], o.devices[(size_t)d], &idx[(size_t)d])) die("index clone"); t_idx_clone += walltime() - t0; }
+	}
+	const double t_index = walltime() - t_idx0;
 	fprintf(stderr, "End loading index\n");
 
 	fprintf(stderr, "Start classify\n");
 	double cpu0 = cputime();
-	FILE *fq = nullptr;
+	const double wall0 = walltime();
+	std::string fq_path = o.reads;
 	psvr::SignalStep sig;
 	std::thread sig_thread;
 	int sig_rc = 0;
@@ -339,9 +258,12 @@ int main(int argc, char **argv)
 		FILE *w = fdopen(fds[1], "w");
 		sig.out = w;
 		sig_thread = std::thread([&sig, &sig_rc, w]() { sig_rc = sig.run(); fclose(w); });
-		fq = fdopen(fds[0], "r");
-	} else fq = o.reads == "-" ? stdin : fopen(o.reads.c_str(), "r");
-	if (!fq) { fprintf(stderr, "fail to open file '%s'\n", o.reads.c_str()); abort(); }
+		char b[64];
+		snprintf(b, sizeof b, "/dev/fd/%d", fds[0]);
+		fq_path = b;
+	}
+	FastqReader fq;
+	if (!fq.open(fq_path.c_str())) { fprintf(stderr, "%s\n", fq.error().c_str()); abort(); }
 	OutFile fo, fo_ori;
 	if (!fo.open(o.out, !o.sam, H, o.thread_n) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n)) { fprintf(stderr, "fail to open output file\n"); abort(); }
 	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
@@ -350,45 +272,36 @@ int main(int argc, char **argv)
 	psvr_aln_params_t par;
 	psvr_aln_params_default(&par);
 	par.match = o.match, par.mismatch = o.mismatch, par.gap_open = o.gap_open, par.gap_ex = o.gap_ex, par.gap_open2 = o.gap_open2, par.gap_ex2 = o.gap_ex2, par.zdrop = o.zdrop;
-	psvr_engine_t *eng = nullptr;
+	std::vector<psvr_engine_t *> eng((size_t)D, nullptr);
 	// classify_pipeline's three overlapped steps (rr.cpp:100-131, kt_pipeline): load_reads | align | output_results.  Three job
-	// slots cycle through the stages in input order, so the output order is the input order.
-	// The record buffers live as long as their job slot (like the reference's Classify_buff_pool) and are page-locked when the
-	// library can provide that: 1.3 GB of fixed-size records per 1 M pairs come back at the link's rate instead of a third of it.
-	struct HostBuf {
-		void *p = nullptr; size_t cap = 0; bool locked = false;
-		void *reserve(size_t bytes)
-		{
-			if (bytes <= cap) return p;
-			release();
-			const size_t want = bytes + bytes / 8;
-			if ((p = psvr_host_alloc(want))) locked = true;
-			else if (!(p = malloc(want))) { fprintf(stderr, "[panSVR-amd] out of host memory\n"); abort(); }
-			cap = want;
-			return p;
-		}
-		void release() { if (p) { if (locked) psvr_host_free(p); else free(p); } p = nullptr, cap = 0, locked = false; }
-		~HostBuf() { release(); }
+	// slots cycle through the stages in input order, so the output order is the input order.  A slot keeps its buffers (like the
+	// reference's Classify_buff_pool): the raw text + line index of its batch, the page-locked upload arrays, and per device the
+	// page-locked compact results.
+	struct Block {                       // the share of one device
+		long long lo = 0, hi = 0;
+		HostBuf hdr_buf, pair_buf, cand_buf, cig_buf;
+		ResultView V;
+		std::vector<psvr_read_result_t> full; std::vector<uint32_t> full_cig;   // --records only (the fixed-size ABI form)
 	};
 	struct Job {
-		std::vector<FqRec> recs; std::vector<char> bases; std::vector<long long> base_off; std::vector<psvr_ori_t> ori;
-		HostBuf res_buf, cig_buf;
-		psvr_read_result_t *res = nullptr; uint32_t *cig = nullptr;
-		std::vector<psvr_pair_result_t> pres;
+		FastqBatch fb;
+		std::vector<Block> blk;
 		long long pair_base = 0;
 		int state = 0;              // 0 free, 1 loaded, 2 aligned
 		bool last = false;          // end-of-input marker travelling through the stages
-		long long n_pairs() const { return (long long)recs.size() / 2; }
 	};
 	Job jobs[3];
+	for (Job &J : jobs) J.blk = std::vector<Block>((size_t)D);
 	std::mutex mu;
 	std::condition_variable cv;
 	auto wait_state = [&](Job &J, int st) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return J.state == st; }); };
 	auto set_state = [&](Job &J, int st) { { std::lock_guard<std::mutex> lk(mu); J.state = st; } cv.notify_all(); };
 	int block = 0;
-	double t_read = 0, t_engine = 0, t_format = 0, t_write = 0;
+	double t_read = 0, t_engine = 0, t_format = 0, t_write = 0, t_exchange = 0;
+	long long n_batches = 0, total_pairs = 0, rebase_iters = 0, d2h_bytes = 0;
+	size_t hbm_first = 0, hbm_last = 0;
+	EmitStats emit_stats;
 	std::thread reader([&]() {
-		FastqBatch fb;
 		long long loaded = 0, pair_base = 0;
 		for (int slot = 0;; slot = (slot + 1) % 3) {
 			Job &J = jobs[slot];
@@ -396,128 +309,48 @@ int main(int argc, char **argv)
 			long long want = o.batch_pairs;
 			if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
 			double tw = walltime();
-			const bool ok = want > 0 && fb.read(fq, want, o.thread_n);
+			const bool ok = want > 0 && fq.read(J.fb, want, o.batch_bases, o.thread_n);
 			t_read += walltime() - tw;
 			if (!ok) { J.last = true; set_state(J, 1); return; }
-			if (loaded == 0) fb.stat_params(&par);          // STAT_ of the very first read (rr.cpp:134-148), before the first batch is aligned
-			loaded += fb.n_pairs();
-			J.recs.swap(fb.recs), J.bases.swap(fb.bases), J.base_off.swap(fb.base_off), J.ori.swap(fb.ori);
-			J.pair_base = pair_base, pair_base += J.n_pairs();
+			if (loaded == 0) fq.stat_params(&par);          // STAT_ of the very first read (rr.cpp:134-148), before the first batch is aligned
+			loaded += J.fb.n_pairs();
+			J.pair_base = pair_base, pair_base += J.fb.n_pairs();
 			set_state(J, 1);
 		}
 	});
+	IndexSvNames svn;
+	svn.idx = idx[0];
+	SamEmitter em;
+	em.H = &H, em.sv = &svn, em.as_bam = !o.sam, em.not_ori = o.not_ori, em.stats = &emit_stats;
 	std::thread writer([&]() {
 		for (int slot = 0;; slot = (slot + 1) % 3) {
 			Job &J = jobs[slot];
 			wait_state(J, 2);
 			if (J.last) return;
-			const long long P = J.n_pairs();
-		double tw = walltime();
-		fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
-		if (frec) {
-			for (long long p = 0; p < P; ++p) {
-				int lens[2] = {(int)J.recs[2 * p].seq.size(), (int)J.recs[2 * p + 1].seq.size()};
-				fprintf(frec, "%s\n", record_json(J.pair_base + p, &J.res[2 * p], J.pres[p], &J.ori[2 * p], lens, J.cig, o.trace).c_str());
+			const long long P = J.fb.n_pairs();
+			double tw = walltime();
+			fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
+			em.min_filter_score = par.min_filter_score;
+			if (frec) {
+				for (const Block &bk : J.blk)
+					for (long long p = bk.lo; p < bk.hi; ++p) {
+						const char *t; int lens[2];
+						J.fb.seq(2 * p, t, lens[0]), J.fb.seq(2 * p + 1, t, lens[1]);
+						fprintf(frec, "%s\n", record_json(J.pair_base + p, &bk.full[(size_t)(2 * (p - bk.lo))], bk.V.pairs[p - bk.lo], &J.fb.ori[2 * p], lens, bk.full_cig.data(), o.trace).c_str());
+					}
 			}
-		}
-		// ---- step 2: records (output_BAM, rr.cpp:479-536), formatted for runs of pairs on -t threads and written in input order
-		auto format_main = [&](long long p0, long long p1, std::vector<uint8_t> &dst) {
-		for (long long p = p0; p < p1; ++p) {
-			const psvr_pair_result_t &pr = J.pres[p];
-			if (!pr.gain) continue;
-			for (int k = 0; k < 2; ++k) {
-				const psvr_read_result_t &rr = J.res[2 * p + k];
-				const FqRec &rec = J.recs[2 * p + k];
-				const psvr_ori_t &ori = J.ori[2 * p + k];
-				if (rr.primary == -1) continue;                          // primary_result == NULL
-				const bool is_ori = rr.primary == -2;
-				if (o.not_ori && is_ori) continue;
-				int chr_id, direction, mapq;
-				uint32_t ref_bg, align_score, chain_score = 0;
-				std::string cg;
-				char b[256];
-				if (is_ori) {
-					chr_id = ori.chr_id, direction = ori.direction, mapq = ori.mapq, ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg, align_score = ori.align_score;
-					if (ori.read_bg > 0) { snprintf(b, sizeof b, "%dS", (int)(int16_t)(uint16_t)ori.read_bg); cg += b; }
-					snprintf(b, sizeof b, "%dM", (int)(int16_t)(uint16_t)((int)rec.seq.size() - (int)ori.read_bg));
-					cg += b;
-				} else {
-					const psvr_cand_t &cd = rr.cand[rr.primary];
-					chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
-					cg = cigar_string(cd, J.cig);
-				}
-				if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
-				int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
-				int isize = direction == 1 ? pr.cur_isize : -pr.cur_isize;
-				std::string seq = rec.seq, qual = rec.qual;
-				if (direction == 0) rev_seq(seq), rev_qual(qual);
-				std::string tags;
-				snprintf(b, sizeof b, "\tAS:i:%d", (int)align_score); tags += b;
-				snprintf(b, sizeof b, "\tOS:i:%d\tOA:Z:%d,%d,%d,%d,%c;", (int)ori.align_score, ori.chr_id, (int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg), (int)ori.read_bg, (int)ori.mapq,
-				         rr.unmapped ? 'U' : 'M');
-				tags += b;
-				if (!is_ori) { snprintf(b, sizeof b, "\tCS:i:%d", (int)chain_score); tags += b; }
-				const char *svs = psvr_index_sv_print_string(idx, rr.prim_sv_id);
-				if (svs) tags += std::string("\tSV:Z:") + svs;
-				const char *mvs = rr.has_mate ? psvr_index_sv_print_string(idx, rr.mate_sv_id) : nullptr;
-				if (mvs) tags += std::string("\tMV:Z:") + mvs;
-				if (rr.secondary >= 0) {
-					const psvr_cand_t &sc = rr.cand[rr.secondary];
-					const char *vid = psvr_index_sv_vcf_id(idx, sc.sv_id);
-					snprintf(b, sizeof b, "\tXA:Z:%d,%d,%d,%d,%c,", sc.chr_id, (int)sc.ref_bg, (int)sc.read_bg, (int)sc.align_score, sc.direction == 1 ? 'F' : 'R');
-					tags += b;
-					tags += vid ? vid : "*";
-					tags += ";";
-				}
-				tags += "\tRC:Z:" + rec.comment;
-				emit_record(fo, dst, H, rec.name, flag, chr_id, ref_bg, mapq, cg, rr.has_mate != 0, rr.mate_chr_id, rr.mate_ref_bg, isize, seq, qual, tags);
-			}
-		}
-		};
-		// ---- second file (rr.cpp:776-797): pairs neither the original aligner nor the re-aligner placed well
-		auto format_ori = [&](long long p0, long long p1, std::vector<uint8_t> &dst) {
-		for (long long p = p0; p < p1; ++p) {
-			const psvr_pair_result_t &pr = J.pres[p];
-			if (!(pr.max_score <= par.min_filter_score && J.ori[2 * p].chr_id != -1 && J.ori[2 * p + 1].chr_id != -1)) continue;
-			OriRecord orr[2];
-			bool ok = parse_ori_record(J.recs[2 * p].comment, &orr[0]) && parse_ori_record(J.recs[2 * p + 1].comment, &orr[1]);
-			if (!ok) continue;
-			bool proper = pr.proper != 0;
-			for (int k = 0; proper && k < 2; ++k) {
-				const int mx = k == 0 ? pr.max1 : pr.max2;
-				if (mx == -1) { proper = false; break; }
-				if (mx == -2) { if (ori_has_clip(orr[k].cigar, 25)) proper = false; }
-				else {                                               // bam_has_clip_or_unmapped_new (rr.cpp:735-743): sums the 'I' ops
-					const psvr_cand_t &cd = J.res[2 * p + k].cand[mx];
-					int tot = 0;
-					for (uint32_t j = 0; j < cd.n_cigar; ++j) { uint32_t wv = J.cig[cd.cigar_off + j]; if ((wv & 0xf) == 1) tot += (int)(int16_t)(wv >> 4); }
-					if (cd.n_cigar == 0 || tot >= 25) proper = false;
-				}
-			}
-			if (proper) continue;
-			for (int k = 0; k < 2; ++k) {
-				const FqRec &rec = J.recs[2 * p + k];
-				const psvr_ori_t &ori = J.ori[2 * p + k];
-				std::string seq = rec.seq, qual = rec.qual;
-				if (orr[k].flag & 0x10) rev_seq(seq), rev_qual(qual);
-				std::string tags;
-				if (!orr[k].tags.empty()) tags += "\t" + orr[k].tags;
-				char b[64];
-				snprintf(b, sizeof b, "\tMS:i:%d", pr.max_score);
-				tags += b;
-				const uint32_t ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg;
-				emit_record(fo_ori, dst, H, rec.name, orr[k].flag, ori.chr_id, ref_bg + 1, orr[k].mapq, orr[k].cigar, true, orr[k].mate_chr, (uint32_t)orr[k].mate_pos, orr[k].isize, seq, qual, tags);
-			}
-		}
-		};
-		{
+			// ---- step 2: records of both files, formatted for runs of pairs on -t threads and written in input order
 			const long long chunk = 4096, nchunk = (P + chunk - 1) / chunk;
-			std::vector<std::vector<uint8_t>> mb(nchunk), ob(nchunk);
+			std::vector<std::vector<uint8_t>> mb((size_t)nchunk), ob((size_t)nchunk);
 			std::atomic<long long> next(0);
 			auto work = [&]() {
 				for (long long ci = next++; ci < nchunk; ci = next++) {
 					const long long p0 = ci * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
-					format_main(p0, p1, mb[ci]), format_ori(p0, p1, ob[ci]);
+					size_t bi = 0;
+					for (long long p = p0; p < p1; ++p) {
+						while (p >= J.blk[bi].hi) ++bi;
+						em.main_pair(J.fb, J.blk[bi].V, p, mb[(size_t)ci]), em.ori_pair(J.fb, J.blk[bi].V, p, ob[(size_t)ci]);
+					}
 				}
 			};
 			std::vector<std::thread> th;
@@ -525,45 +358,125 @@ int main(int argc, char **argv)
 			work();
 			for (std::thread &t : th) t.join();
 			t_format += walltime() - tw, tw = walltime();
-			for (long long ci = 0; ci < nchunk; ++ci) fo.write_raw(mb[ci]), fo_ori.write_raw(ob[ci]);
+			for (long long ci = 0; ci < nchunk; ++ci) fo.write_raw(mb[(size_t)ci]), fo_ori.write_raw(ob[(size_t)ci]);
 			t_write += walltime() - tw;
-		}
 			set_state(J, 0);
 		}
 	});
+	// ---- step 1: the engine(s)
+	int64_t pos[3] = {0, 0, 0};                          // where the next batch starts in the three draw streams
 	for (int slot = 0;; slot = (slot + 1) % 3) {
 		Job &J = jobs[slot];
 		wait_state(J, 1);
 		if (J.last) { set_state(J, 2); break; }
 		double tw = walltime();
-		if (!eng) {
+		if (!eng[0]) {
 			fprintf(stderr, "Current used read status: READ_LEN=%d; ISIZE_MIN=%d; ISIZE_MID=%d; ISIZE_MAX=%d; filter_score_full_match=%d\n", par.normal_read_length, par.isize_min, 0,
 			        par.isize_max, par.min_filter_score);
-			if (psvr_engine_create(idx, &par, &eng)) { fprintf(stderr, "[panSVR-amd] %s\n", psvr_last_error()); abort(); }
+			for (int d = 0; d < D; ++d) if (psvr_engine_create(idx[(size_t)d], &par, &eng[(size_t)d])) die("engine");
+			if (psvr_engine_stream_end(eng[0], pos)) die("engine");      // a fresh engine stands where the reference's generators stand after init_run
 		}
-		const long long P = J.n_pairs(), R = 2 * P;
-		J.res = (psvr_read_result_t *)J.res_buf.reserve((size_t)R * sizeof(psvr_read_result_t)), J.pres.resize(P);
-		int rc = psvr_engine_upload(eng, P, J.bases.data(), (const int64_t *)J.base_off.data(), J.ori.data());
-		if (!rc) rc = psvr_engine_run(eng, o.trace ? 1 : 0, nullptr);
-		int64_t used = 0;
-		if (!rc) { rc = psvr_engine_download(eng, nullptr, nullptr, nullptr, 0, &used); if (rc == PSVR_ERR_OVERFLOW) rc = 0; }
-		J.cig = (uint32_t *)J.cig_buf.reserve((size_t)(used + 1) * 4);
-		if (!rc) rc = psvr_engine_download(eng, J.res, J.pres.data(), J.cig, used + 1, &used);
-		if (rc) { fprintf(stderr, "[panSVR-amd] engine error %d: %s\n", rc, psvr_last_error()); abort(); }
+		const long long P = J.fb.n_pairs();
+		for (int d = 0; d < D; ++d) { J.blk[(size_t)d].lo = (P * d + D - 1) / D, J.blk[(size_t)d].hi = (P * (d + 1) + D - 1) / D; }
+		auto each_device = [&](auto &&fn) {                 // one host thread per device (the engine API is single-owner per engine)
+			std::vector<std::thread> th;
+			for (int d = 1; d < D; ++d) th.emplace_back(fn, d);
+			fn(0);
+			for (std::thread &t : th) t.join();
+		};
+		std::vector<int> rcs((size_t)D, 0);
+		std::vector<std::string> errs((size_t)D);
+		auto fail_check = [&]() { for (int d = 0; d < D; ++d) if (rcs[(size_t)d]) { fprintf(stderr, "[panSVR-amd] engine error %d on device %d: %s\n", rcs[(size_t)d], o.devices[(size_t)d], errs[(size_t)d].c_str()); abort(); } };
+		each_device([&](int d) {
+			Block &bk = J.blk[(size_t)d];
+			const long long n = bk.hi - bk.lo;
+			int rc = psvr_engine_set_stream_pos(eng[(size_t)d], pos);        // block 0 starts there; the others are moved below
+			if (!rc) rc = psvr_engine_upload(eng[(size_t)d], n, J.fb.bases, J.fb.base_off + 2 * bk.lo, J.fb.ori + 2 * bk.lo);
+			if (!rc) rc = psvr_engine_run(eng[(size_t)d], o.trace ? 1 : 0, nullptr);
+			if (rc) rcs[(size_t)d] = rc, errs[(size_t)d] = psvr_last_error();
+		});
+		fail_check();
+		// the draw-order exchange: block d starts where block d-1 ended.  A block's draw count almost never depends on where it
+		// starts, so one pass of moves normally settles it; the loop covers the rest.
+		if (D > 1) {
+			const double tx = walltime();
+			std::vector<int64_t> start((size_t)D * 3), end((size_t)D * 3);
+			for (int d = 0; d < D; ++d) for (int k = 0; k < 3; ++k) start[(size_t)d * 3 + k] = pos[k];
+			for (int it = 0;; ++it) {
+				for (int d = 0; d < D; ++d) if (psvr_engine_stream_end(eng[(size_t)d], &end[(size_t)d * 3])) die("engine");
+				std::vector<int> moved;
+				int64_t acc[3] = {pos[0], pos[1], pos[2]};
+				for (int d = 0; d < D; ++d) {
+					int64_t used[3];
+					for (int k = 0; k < 3; ++k) used[k] = end[(size_t)d * 3 + k] - start[(size_t)d * 3 + k];
+					bool mv = false;
+					for (int k = 0; k < 3; ++k) if (start[(size_t)d * 3 + k] != acc[k]) mv = true, start[(size_t)d * 3 + k] = acc[k];
+					if (mv) moved.push_back(d);
+					for (int k = 0; k < 3; ++k) acc[k] += used[k];
+				}
+				if (moved.empty()) break;
+				if (it > 64) { fprintf(stderr, "[panSVR-amd] draw-order exchange did not converge\n"); abort(); }
+				std::vector<std::thread> th;
+				for (int d : moved) th.emplace_back([&, d]() { if (psvr_engine_rebase(eng[(size_t)d], &start[(size_t)d * 3], nullptr)) rcs[(size_t)d] = 1, errs[(size_t)d] = psvr_last_error(); });
+				for (std::thread &t : th) t.join();
+				fail_check();
+				++rebase_iters;
+			}
+			t_exchange += walltime() - tx;
+		}
+		if (psvr_engine_stream_end(eng[(size_t)D - 1], pos)) die("engine");
+		each_device([&](int d) {
+			Block &bk = J.blk[(size_t)d];
+			const long long n = bk.hi - bk.lo;
+			int64_t nc = 0, nw = 0;
+			int rc = psvr_engine_download_compact(eng[(size_t)d], nullptr, nullptr, nullptr, 0, &nc, nullptr, 0, &nw);
+			if (rc == PSVR_ERR_OVERFLOW) rc = 0;
+			psvr_read_hdr_t *hdr = (psvr_read_hdr_t *)bk.hdr_buf.reserve((size_t)(2 * n + 1) * sizeof(psvr_read_hdr_t));
+			psvr_pair_result_t *prs = (psvr_pair_result_t *)bk.pair_buf.reserve((size_t)(n + 1) * sizeof(psvr_pair_result_t));
+			psvr_cand_t *cands = (psvr_cand_t *)bk.cand_buf.reserve((size_t)(nc + 1) * sizeof(psvr_cand_t));
+			uint32_t *cig = (uint32_t *)bk.cig_buf.reserve((size_t)(nw + 1) * 4);
+			if (!rc) rc = psvr_engine_download_compact(eng[(size_t)d], hdr, prs, cands, nc + 1, &nc, cig, nw + 1, &nw);
+			bk.V.hdr = hdr, bk.V.pairs = prs, bk.V.cands = cands, bk.V.cig = cig, bk.V.pair0 = bk.lo;
+			if (!rc && frec) {                               // the parity tests read the fixed-size ABI records
+				int64_t used = 0;
+				rc = psvr_engine_download(eng[(size_t)d], nullptr, nullptr, nullptr, 0, &used);
+				if (rc == PSVR_ERR_OVERFLOW) rc = 0;
+				bk.full.resize((size_t)(2 * n)), bk.full_cig.resize((size_t)used + 1);
+				if (!rc) rc = psvr_engine_download(eng[(size_t)d], bk.full.data(), nullptr, bk.full_cig.data(), used + 1, &used);
+			}
+			if (rc) rcs[(size_t)d] = rc, errs[(size_t)d] = psvr_last_error();
+			else { std::lock_guard<std::mutex> lk(mu); d2h_bytes += (long long)(2 * n * sizeof(psvr_read_hdr_t) + n * sizeof(psvr_pair_result_t) + nc * sizeof(psvr_cand_t) + nw * 4); }
+		});
+		fail_check();
+		{   // steady footprint: HBM in use on the first device after the first and after the latest batch
+			char sb[8192];
+			if (!psvr_engine_stats(eng[0], sb, sizeof sb)) { const char *q = strstr(sb, "\"hbm_used_bytes\":"); if (q) { hbm_last = strtoull(q + 17, nullptr, 10); if (!n_batches) hbm_first = hbm_last; } }
+		}
+		++n_batches, total_pairs += P;
 		t_engine += walltime() - tw;
 		set_state(J, 2);
 	}
 	reader.join(), writer.join();
-	if (fq != stdin) fclose(fq);
 	if (sig_thread.joinable()) {
 		sig_thread.join();
 		if (sig_rc) { fprintf(stderr, "[panSVR-amd] the signal step failed\n"); abort(); }
 	}
 	if (!fo.close() || !fo_ori.close()) { fprintf(stderr, "fail to write output file\n"); abort(); }
 	if (frec) fclose(frec);
-	if (eng) psvr_engine_destroy(eng);
-	psvr_index_destroy(idx);
+	for (int d = 0; d < D; ++d) if (eng[(size_t)d]) psvr_engine_destroy(eng[(size_t)d]);
+	for (int d = 0; d < D; ++d) {
+		bool dup = false;
+		for (int q = 0; q < d; ++q) if (idx[(size_t)q] == idx[(size_t)d]) dup = true;
+		if (!dup) psvr_index_destroy(idx[(size_t)d]);
+	}
+	const double wall = walltime() - wall0;
 	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
+	if (emit_stats.dropped) fprintf(stderr, "[panSVR-amd] %lld records were refused by the record rules of sam_parse1 and not written (see the ERROR lines above)\n", (long long)emit_stats.dropped);
 	fprintf(stderr, "[panSVR-amd] wall: read+parse %.3f s, engine (upload+run+download) %.3f s, format %.3f s, write%s %.3f s\n", t_read, t_engine, t_format, o.sam ? "" : "+compress", t_write);
+	fprintf(stderr,
+	        "[panSVR-amd] e2e_json {\"pairs\":%lld,\"batches\":%lld,\"devices\":%d,\"threads\":%d,\"wall_s\":%.4f,\"index_s\":%.4f,\"index_first_s\":%.4f,\"index_clone_s\":%.4f,\"read_parse_s\":%.4f,"
+	        "\"engine_s\":%.4f,\"exchange_s\":%.4f,\"rebase_iterations\":%lld,\"format_s\":%.4f,\"write_s\":%.4f,\"d2h_bytes\":%lld,\"hbm_used_first\":%zu,\"hbm_used_last\":%zu,\"dropped\":%lld}\n",
+	        total_pairs, n_batches, D, o.thread_n, wall, t_index, t_idx_first, t_idx_clone, t_read, t_engine, t_exchange, rebase_iters, t_format, t_write, d2h_bytes, hbm_first, hbm_last,
+	        (long long)emit_stats.dropped);
 	return 0;
 }

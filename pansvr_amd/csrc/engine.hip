@@ -343,6 +343,52 @@ __global__ __launch_bounds__(kBlock) void k_adopt(Ctx c, const int32_t *pairs, c
 	const long long i = blockIdx.x * (long long)(kBlock / 64) + (threadIdx.x >> 6);
 	if (i < n) adopt_variant(c, pairs[i], slots[i], noff, threadIdx.x & 63, 64);
 }
+// ---- result hand-over -------------------------------------------------------------------------
+// the fixed-size ABI records (psvr_engine_download): one thread per read
+__global__ __launch_bounds__(kBlock) void k_materialize(Ctx c, long long R, psvr_read_result_t *out)
+{
+	const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (r < R) materialize_read(c, r, out + r);
+}
+// compact form (psvr_engine_download_compact): per read the number of candidates and of CIGAR words that exist ...
+__global__ __launch_bounds__(kBlock) void k_compact_count(Ctx c, long long R, int32_t *cnt_c, int32_t *cnt_w)
+{
+	const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (r > R) return;
+	int nc = 0, nw = 0;
+	if (r < R) {
+		const psvr_read_hdr_t &h = c.rh[r];
+		nc = h.n_result;
+		for (int i = 0; i < nc; ++i) nw += (int)c.cand[h.cand_off + i].n_cigar;
+	}
+	cnt_c[r] = nc, cnt_w[r] = nw;                     // entry R is the scans' scratch element
+}
+// ... and, after the two scans, the dense copies: 16 lanes per read (header words, candidate words, CIGAR words)
+__global__ __launch_bounds__(kBlock) void k_compact_copy(Ctx c, long long R, const long long *off_c, const long long *off_w, psvr_read_hdr_t *hdr, psvr_cand_t *cands, uint32_t *cig)
+{
+	const long long r = blockIdx.x * (long long)(kBlock / 16) + (threadIdx.x >> 4);
+	const int lane = threadIdx.x & 15;
+	if (r >= R) return;
+	const psvr_read_hdr_t &h = c.rh[r];
+	const long long oc = off_c[r];
+	long long ow = off_w[r];
+	const int hw = (int)(sizeof(psvr_read_hdr_t) / 4), cwn = (int)(sizeof(psvr_cand_t) / 4);
+	const int ho = (int)(offsetof(psvr_read_hdr_t, cand_off) / 4);
+	if (lane < hw && lane != ho && lane != ho + 1) ((uint32_t *)(hdr + r))[lane] = ((const uint32_t *)&h)[lane];
+	if (lane == 0) hdr[r].cand_off = oc;
+	const int n = h.n_result;
+	const uint32_t *src = (const uint32_t *)(c.cand + h.cand_off);
+	uint32_t *dst = (uint32_t *)(cands + oc);
+	const int co = (int)(offsetof(psvr_cand_t, cigar_off) / 4);          // the two words of cigar_off are written by lane 0 below, not copied
+	for (int i = lane; i < n * cwn; i += 16) { const int w = i % cwn; if (w != co && w != co + 1) dst[i] = src[i]; }
+	for (int k = 0; k < n; ++k) {
+		const psvr_cand_t &cd = c.cand[h.cand_off + k];
+		const int m = (int)cd.n_cigar;
+		for (int i = lane; i < m; i += 16) cig[ow + i] = c.cig.base[cd.cigar_off + i];
+		if (lane == 0) cands[oc + k].cigar_off = ow;
+		ow += m;
+	}
+}
 __global__ void k_fill_i64(long long *p, long long n, int stride, int off, long long v)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -1048,6 +1094,34 @@ extern "C" int psvr_index_load(const char *dir, const char *header_sam, int devi
 	return PSVR_OK;
 }
 
+// every buffer of `src` copied device to device (hipMemcpyPeer: xGMI between GPUs of one node), then the derived pointers
+extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_t **out)
+{
+	if (!src || !out) return set_error(PSVR_ERR_ARG, "psvr_index_clone: null argument");
+	psvr_index *ix = new psvr_index;
+	ix->device = device;
+	ix->host = src->host;
+	hipError_t he = hipSetDevice(device);
+	auto cp = [&](DevBuf &d, const DevBuf &s0) {
+		if (he != hipSuccess || !s0.p) return;
+		he = d.alloc(s0.bytes);
+		if (he == hipSuccess) he = hipMemcpyPeer(d.p, device, s0.p, src->device, s0.bytes);
+		ix->bytes += (int64_t)s0.bytes;
+	};
+	cp(ix->ref_seq, src->ref_seq), cp(ix->seq, src->seq), cp(ix->seqf, src->seqf), cp(ix->pos, src->pos), cp(ix->posp, src->posp), cp(ix->hash, src->hash);
+	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->uid_hint, src->uid_hint);
+	if (he == hipSuccess) he = hipDeviceSynchronize();
+	if (he != hipSuccess) { delete ix; return set_error(PSVR_ERR_DEVICE, "psvr_index_clone: %s", hipGetErrorString(he)); }
+	DevIndex &d = ix->dev;
+	d = src->dev;
+	d.ref_seq = ix->ref_seq.as<uint64_t>(), d.seq = ix->seq.as<uint64_t>(), d.seqf = ix->seqf.as<uint64_t>(), d.pos = ix->pos.as<uint64_t>();
+	d.posp = ix->posp.as<uint64_t>(), d.hash = ix->hash.as<uint64_t>(), d.off = ix->off.as<uint64_t>(), d.kmer = ix->kmer.as<uint32_t>();
+	d.chr_end_n = ix->chr_end.as<uint32_t>(), d.chr_search_index = ix->chr_idx.as<uint32_t>(), d.sv = ix->sv.as<SvDev>();
+	d.occ = ix->occ.as<uint32_t>(), d.uid_hint = ix->uid_hint.as<uint32_t>();
+	*out = ix;
+	return PSVR_OK;
+}
+
 extern "C" void psvr_index_destroy(psvr_index_t *ix) { delete ix; }
 extern "C" int64_t psvr_index_device_bytes(const psvr_index_t *ix) { return ix ? ix->bytes : 0; }
 extern "C" int32_t psvr_index_n_anchor(const psvr_index_t *ix) { return ix ? ix->host.chr_file_n : 0; }
@@ -1068,6 +1142,10 @@ struct psvr_engine {
 	GpuBE be;
 	EngineCore<GpuBE> core;
 	bool committed = true;
+	// hand-over buffers: the materialised ABI records, or the compact form (valid until the next upload / run / rebase)
+	DevBuf full_out, cmp_cnt_c, cmp_cnt_w, cmp_off_c, cmp_off_w, cmp_hdr, cmp_cand, cmp_cig;
+	bool compact_valid = false;
+	long long compact_nc = 0, compact_nw = 0;
 	explicit psvr_engine(const psvr_index *i) : ix(i), core(be) {}
 };
 
@@ -1103,6 +1181,7 @@ extern "C" int psvr_engine_upload(psvr_engine_t *e, int64_t n_pairs, const char 
 	if (!e || n_pairs < 0 || (n_pairs && (!bases || !base_off || !ori))) return set_error(PSVR_ERR_ARG, "psvr_engine_upload: bad argument");
 	PSVR_HIP(hipSetDevice(e->ix->device));
 	if (!e->committed) { e->core.commit(); e->committed = true; }
+	e->compact_valid = false;
 	int rc = e->core.upload(n_pairs, bases, base_off, ori);
 	return engine_status(e, rc);
 }
@@ -1114,17 +1193,19 @@ extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
 	e->be.stream = (hipStream_t)stream;
 	e->be.timing = (trace & 4) != 0;
 	e->be.timed.clear();
+	e->compact_valid = false;
 	int rc = e->core.run(trace & 1, (trace & 2) != 0);
 	hipError_t s = hipStreamSynchronize(e->be.stream);
 	if (s != hipSuccess) e->be.note(s);
 	e->be.collect_timing();
-	e->committed = false;       // the rand streams advance when the next batch is uploaded (or on download)
+	e->committed = false;       // the rand streams advance when the next batch is uploaded (or a stream position is set)
 	return engine_status(e, rc);
 }
 
 extern "C" int psvr_engine_set_stream_pos(psvr_engine_t *e, const int64_t pos[3])
 {
 	if (!e || !pos) return set_error(PSVR_ERR_ARG, "psvr_engine_set_stream_pos: null argument");
+	PSVR_HIP(hipSetDevice(e->ix->device));            // commit() reads device memory
 	if (!e->committed) { e->core.commit(); e->committed = true; }
 	e->core.grand_pos = pos[0], e->core.hrand_pos[0] = pos[1], e->core.hrand_pos[1] = pos[2];
 	e->core.grand_dev_n = e->core.hrand_dev_n = 0;
@@ -1146,6 +1227,7 @@ extern "C" int psvr_engine_rebase(psvr_engine_t *e, const int64_t pos[3], void *
 	if (!e || !pos) return set_error(PSVR_ERR_ARG, "psvr_engine_rebase: null argument");
 	PSVR_HIP(hipSetDevice(e->ix->device));
 	e->be.stream = (hipStream_t)stream;
+	e->compact_valid = false;
 	int rc = e->core.rebase(pos[0], pos[1], pos[2], e->core.c.trace, false);
 	hipError_t s = hipStreamSynchronize(e->be.stream);
 	if (s != hipSuccess) e->be.note(s);
@@ -1162,9 +1244,54 @@ extern "C" int psvr_engine_download(psvr_engine_t *e, psvr_read_result_t *reads,
 	PSVR_HIP(hipMemcpy(&top, c.c.cig.top, 8, hipMemcpyDeviceToHost));
 	if (cigar_used) *cigar_used = (int64_t)top;
 	if ((int64_t)top > cigar_cap) return set_error(PSVR_ERR_OVERFLOW, "cigar arena too small: need %llu uint32, have %lld", top, (long long)cigar_cap);
-	if (reads) PSVR_HIP(hipMemcpy(reads, c.c.res, c.R * sizeof(psvr_read_result_t), hipMemcpyDeviceToHost));
+	if (reads) {
+		// the engine keeps compact headers + a candidate list; the fixed 12-slot records are built here, on request
+		PSVR_HIP(e->full_out.ensure((size_t)c.R * sizeof(psvr_read_result_t)));
+		hipLaunchKernelGGL(k_materialize, dim3(grid_for(c.R)), dim3(kBlock), 0, nullptr, c.c, c.R, e->full_out.as<psvr_read_result_t>());
+		PSVR_HIP(hipGetLastError());
+		PSVR_HIP(hipMemcpy(reads, e->full_out.p, c.R * sizeof(psvr_read_result_t), hipMemcpyDeviceToHost));
+	}
 	if (pairs) PSVR_HIP(hipMemcpy(pairs, c.c.pres, c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost));
 	if (cigar && top) PSVR_HIP(hipMemcpy(cigar, c.c.cig.base, top * 4, hipMemcpyDeviceToHost));
+	return PSVR_OK;
+}
+
+extern "C" int psvr_engine_download_compact(psvr_engine_t *e, psvr_read_hdr_t *hdr, psvr_pair_result_t *pairs, psvr_cand_t *cands, int64_t cand_cap, int64_t *cand_used,
+                                            uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used)
+{
+	if (!e) return set_error(PSVR_ERR_ARG, "psvr_engine_download_compact: null engine");
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	auto &c = e->core;
+	if (c.P == 0) { if (cand_used) *cand_used = 0; if (cigar_used) *cigar_used = 0; return PSVR_OK; }
+	const long long R = c.R;
+	if (!e->compact_valid) {
+		e->be.stream = nullptr;
+		PSVR_HIP(e->cmp_cnt_c.ensure((size_t)(R + 1) * 4)); PSVR_HIP(e->cmp_cnt_w.ensure((size_t)(R + 1) * 4));
+		PSVR_HIP(e->cmp_off_c.ensure((size_t)(R + 2) * 8)); PSVR_HIP(e->cmp_off_w.ensure((size_t)(R + 2) * 8));
+		hipLaunchKernelGGL(k_compact_count, dim3(grid_for(R + 1)), dim3(kBlock), 0, nullptr, c.c, R, e->cmp_cnt_c.as<int32_t>(), e->cmp_cnt_w.as<int32_t>());
+		e->be.st_scan(e->cmp_cnt_c.as<int32_t>(), R + 1, 1, 0, 0ll, e->cmp_off_c.as<long long>());
+		e->be.st_scan(e->cmp_cnt_w.as<int32_t>(), R + 1, 1, 0, 0ll, e->cmp_off_w.as<long long>());
+		PSVR_HIP(hipGetLastError());
+		long long tot[2] = {0, 0};
+		PSVR_HIP(hipMemcpy(&tot[0], e->cmp_off_c.as<long long>() + R, 8, hipMemcpyDeviceToHost));
+		PSVR_HIP(hipMemcpy(&tot[1], e->cmp_off_w.as<long long>() + R, 8, hipMemcpyDeviceToHost));
+		PSVR_HIP(e->cmp_hdr.ensure((size_t)R * sizeof(psvr_read_hdr_t)));
+		PSVR_HIP(e->cmp_cand.ensure((size_t)(tot[0] + 1) * sizeof(psvr_cand_t)));
+		PSVR_HIP(e->cmp_cig.ensure((size_t)(tot[1] + 1) * 4));
+		hipLaunchKernelGGL(k_compact_copy, dim3(grid_for(R, kBlock / 16)), dim3(kBlock), 0, nullptr, c.c, R, (const long long *)e->cmp_off_c.p, (const long long *)e->cmp_off_w.p,
+		                   e->cmp_hdr.as<psvr_read_hdr_t>(), e->cmp_cand.as<psvr_cand_t>(), e->cmp_cig.as<uint32_t>());
+		PSVR_HIP(hipGetLastError());
+		e->compact_nc = tot[0], e->compact_nw = tot[1], e->compact_valid = true;
+	}
+	if (cand_used) *cand_used = e->compact_nc;
+	if (cigar_used) *cigar_used = e->compact_nw;
+	if ((cands && e->compact_nc > cand_cap) || (cigar && e->compact_nw > cigar_cap))
+		return set_error(PSVR_ERR_OVERFLOW, "compact download: need %lld candidates / %lld cigar words", e->compact_nc, e->compact_nw);
+	if (hdr) PSVR_HIP(hipMemcpyAsync(hdr, e->cmp_hdr.p, (size_t)R * sizeof(psvr_read_hdr_t), hipMemcpyDeviceToHost, nullptr));
+	if (pairs) PSVR_HIP(hipMemcpyAsync(pairs, c.c.pres, (size_t)c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost, nullptr));
+	if (cands && e->compact_nc) PSVR_HIP(hipMemcpyAsync(cands, e->cmp_cand.p, (size_t)e->compact_nc * sizeof(psvr_cand_t), hipMemcpyDeviceToHost, nullptr));
+	if (cigar && e->compact_nw) PSVR_HIP(hipMemcpyAsync(cigar, e->cmp_cig.p, (size_t)e->compact_nw * 4, hipMemcpyDeviceToHost, nullptr));
+	PSVR_HIP(hipStreamSynchronize(nullptr));
 	return PSVR_OK;
 }
 
@@ -1189,6 +1316,11 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();
+	{
+		size_t fr = 0, tot = 0;
+		char b[96];
+		if (hipSetDevice(e->ix->device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) { snprintf(b, sizeof b, ",\"hbm_used_bytes\":%zu", tot - fr); t += b; }
+	}
 	t += ",\"kernels\":{";
 	bool first = true;
 	for (auto &k : e->be.timed) {

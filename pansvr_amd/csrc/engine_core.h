@@ -184,7 +184,9 @@ template <class BE> struct EngineCore {
 	int upload(long long n_pairs, const char *bases, const int64_t *base_off, const psvr_ori_t *ori)
 	{
 		P = n_pairs, R = 2 * n_pairs;
-		total_bases = R ? base_off[R] : 0;
+		// a block of a larger batch may be handed over as a window of the batch's arrays: offsets then start at base_off[0] > 0
+		const long long b0 = R ? base_off[0] : 0;
+		total_bases = R ? base_off[R] - b0 : 0;
 		int lmax = 0;
 		for (long long r = 0; r < R; ++r) { long long l = base_off[r + 1] - base_off[r]; if (l > lmax) lmax = (int)l; }
 		if (lmax > kMaxReadLen) { err = "read longer than MAX_READ_LEN 1600"; return PSVR_ERR_UNSUPPORTED; }
@@ -218,9 +220,10 @@ template <class BE> struct EngineCore {
 		// a pipeline feeds batch after batch of similar size: keep every per-batch buffer (and the arenas) while the new batch fits
 		const bool fits = !owned.empty() && S <= cap_S && lm <= cap_lm && total_bases <= cap_bases && P <= cap_P;
 		if (fits) {
-			be.h2d(d_bases, bases, total_bases);
+			be.h2d(d_bases, bases + b0, total_bases);
 			be.h2d(d_off, base_off, (R + 1) * 8);
 			be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
+			c.bases = d_bases - b0;
 			upload_variants();
 			return PSVR_OK;
 		}
@@ -244,7 +247,7 @@ template <class BE> struct EngineCore {
 		c.seed_list = alloc<uint8_t>((unsigned long long)RS * c.lmax);
 		c.strand = alloc<Strand>(2 * RS);
 		c.ccand = alloc<ChainCand>(12 * RS), c.n_ccand = alloc<int32_t>(RS);
-		c.res = alloc<psvr_read_result_t>(RS), c.pres = alloc<psvr_pair_result_t>(S);
+		c.rh = alloc<psvr_read_hdr_t>(RS), c.pres = alloc<psvr_pair_result_t>(S);
 		d_work = alloc<int32_t>(S), d_workp = alloc<int32_t>(P);
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
 		d_hprev = alloc<int32_t>(2 * S);
@@ -262,10 +265,10 @@ template <class BE> struct EngineCore {
 		free_arenas();
 		if (!alloc_arenas()) { err = "device allocation failed (arenas)"; return PSVR_ERR_NOMEM; }
 		c.err = d_flags + 6;
-		be.h2d(d_bases, bases, total_bases);
+		be.h2d(d_bases, bases + b0, total_bases);
 		be.h2d(d_off, base_off, (R + 1) * 8);
 		be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
-		c.bases = d_bases, c.base_off = d_off, c.ori = d_ori;
+		c.bases = d_bases - b0, c.base_off = d_off, c.ori = d_ori;
 		upload_variants();
 		return PSVR_OK;
 	}
@@ -299,19 +302,20 @@ template <class BE> struct EngineCore {
 
 	void free_arenas()
 	{
-		for (void *p : {(void *)c.mem.base, (void *)c.us.base, (void *)c.path, (void *)c.seg.base, (void *)c.dp.base, (void *)c.cw.base, (void *)c.cig.base})
+		for (void *p : {(void *)c.mem.base, (void *)c.us.base, (void *)c.path, (void *)c.seg.base, (void *)c.dp.base, (void *)c.cw.base, (void *)c.cig.base, (void *)c.cand})
 			if (p) be.dfree(p);
-		c.mem.base = nullptr, c.us.base = nullptr, c.path = nullptr, c.seg.base = nullptr, c.dp.base = nullptr, c.cw.base = nullptr, c.cig.base = nullptr;
+		c.mem.base = nullptr, c.us.base = nullptr, c.path = nullptr, c.seg.base = nullptr, c.dp.base = nullptr, c.cw.base = nullptr, c.cig.base = nullptr, c.cand = nullptr;
 	}
 	bool alloc_arenas()
 	{
 		c.mem.base = (VMem *)be.dalloc(cap_mem * sizeof(VMem)), c.us.base = (USeed *)be.dalloc(cap_us * sizeof(USeed)), c.path = (PathN *)be.dalloc(cap_us * sizeof(PathN));
 		c.seg.base = (Seg *)be.dalloc(cap_seg * sizeof(Seg)), c.dp.base = (DpDesc *)be.dalloc(cap_dp * sizeof(DpDesc));
 		c.cw.base = (CandWork *)be.dalloc(cap_cw * sizeof(CandWork)), c.cig.base = (uint32_t *)be.dalloc(cap_cig * 4);
+		c.cand = (psvr_cand_t *)be.dalloc(cap_cw * sizeof(psvr_cand_t));       // candidate records share the CandWork arena's indices
 		c.mem.top = d_tops + 0, c.us.top = d_tops + 1, c.seg.top = d_tops + 2, c.dp.top = d_tops + 3, c.cw.top = d_tops + 4, c.cig.top = d_tops + 5;
 		c.mem.cap = cap_mem, c.us.cap = cap_us, c.seg.cap = cap_seg, c.dp.cap = cap_dp, c.cw.cap = cap_cw, c.cig.cap = cap_cig;
 		c.mem.overflow = d_flags + 0, c.us.overflow = d_flags + 1, c.seg.overflow = d_flags + 2, c.dp.overflow = d_flags + 3, c.cw.overflow = d_flags + 4, c.cig.overflow = d_flags + 5;
-		return c.mem.base && c.us.base && c.path && c.seg.base && c.dp.base && c.cw.base && c.cig.base;
+		return c.mem.base && c.us.base && c.path && c.seg.base && c.dp.base && c.cw.base && c.cig.base && c.cand;
 	}
 	// a scratch arena overflowed (repeat-rich reads expand to many seeds): grow it 4x and run the batch again
 	int grow_and_rerun(const int32_t *flags, int trace, bool want_stats, int depth)

@@ -1,5 +1,5 @@
-// host_io.h -- host-side C++ of the `aln` step that sits above the C ABI: index files, the
-// interleaved FASTQ with fc_signal's comment wire format, and record formatting.
+// host_io.h -- host-side C++ of the `aln` step that sits above the C ABI: the index files and the per-pair decision
+// record the parity tests compare (the FASTQ reader is fastq_batch.h, the SAM/BAM records sam_emit.h).
 // Mirrors (does not copy) the reference's host behaviour; citations inline.
 #pragma once
 #include <stdint.h>
@@ -114,8 +114,9 @@ struct HostIndex {
 	{
 		FILE *h = fopen(path.c_str(), "r");
 		if (!h) return false;
-		char buf[65536];
-		while (fgets(buf, sizeof buf, h)) {
+		char *buf = nullptr;
+		size_t cap = 0;
+		while (getline(&buf, &cap, h) > 0) {                   // header lines of any length
 			if (strncmp(buf, "@SQ", 3)) continue;
 			char *p = strstr(buf, "SN:");
 			if (!p) continue;
@@ -124,6 +125,7 @@ struct HostIndex {
 			while (*e && *e != '\t' && *e != '\n') ++e;
 			names->emplace_back(p, e - p);
 		}
+		free(buf);
 		fclose(h);
 		return true;
 	}
@@ -164,129 +166,6 @@ struct HostIndex {
 		d.chr_end_n = chr_end_n.data(), d.chr_search_index = chr_search_index.data(), d.sv = sv.data(), d.chr_file_n = chr_file_n;
 		d.sp_id = sp_id.data(), d.sp_start = sp_start.data(), d.sp_n = sp_id.size(), d.n_kmer = kmer.size();
 		return d;
-	}
-};
-
-// one FASTQ record of the interleaved signal file
-struct FqRec { std::string name, comment, seq, qual; };
-
-// single_end_handler::parse_ori_mapping_rst (rr.hpp:392-429): first five tokens + the signal-flag token (10th).
-// Like the reference it rewrites the separators it consumed as ',' (the comment is echoed in RC:Z).
-inline psvr_ori_t parse_ori(std::string &cm)
-{
-	psvr_ori_t o;
-	memset(&o, 0, sizeof o);
-	std::vector<char> buf(cm.begin(), cm.end());
-	buf.push_back(0);
-	const int L = (int)cm.size();
-	char *save = nullptr;
-	auto ai = [](const char *s) { return s ? atoi(s) : 0; };
-	char *tok = strtok_r(buf.data(), "_", &save);
-	o.chr_id = ai(tok);
-	tok = strtok_r(NULL, "_", &save); o.ref_bg = (uint32_t)ai(tok);
-	tok = strtok_r(NULL, "_", &save); o.read_bg = (uint32_t)ai(tok);
-	tok = strtok_r(NULL, "_", &save); o.align_score = (uint32_t)ai(tok);
-	tok = strtok_r(NULL, "_", &save); o.mapq = (uint8_t)ai(tok);
-	for (int k = 0; k < 4; ++k) tok = strtok_r(NULL, "_", &save);
-	tok = strtok_r(NULL, "_", &save);
-	o.direction = (tok && tok[0] == 'F') ? 1 : 0;
-	o.unmapped = (tok && tok[1] == 'Y') ? 1 : 0;
-	for (int i = 0; i < L - 1; i++) if (buf[i] == 0) buf[i] = ',';
-	cm.assign(buf.data(), L);
-	return o;
-}
-
-struct FastqBatch {
-	std::vector<FqRec> recs;
-	std::vector<char> bases;
-	std::vector<long long> base_off;
-	std::vector<psvr_ori_t> ori;
-	std::string first_comment;          // of the very first read: carries STAT_ (rr.cpp:134-148)
-	bool have_first = false;
-	long long n_pairs() const { return (long long)recs.size() / 2; }
-
-	// raw text carried between batches: lines are located with memchr in one pass, records are then built on `threads`
-	// threads (the per-record string work dominates a serial reader)
-	std::vector<char> raw;
-	size_t raw_pos = 0, raw_len = 0;
-	bool raw_eof = false;
-	// up to max_pairs pairs, or 100 MB of bases like load_reads (rr.cpp:109,126)
-	bool read(FILE *f, long long max_pairs, int threads = 1)
-	{
-		recs.clear(), bases.clear(), base_off.assign(1, 0), ori.clear();
-		if (raw_pos) { memmove(raw.data(), raw.data() + raw_pos, raw_len - raw_pos); raw_len -= raw_pos, raw_pos = 0; }
-		std::vector<size_t> ls;                  // start offset of every line of the batch, plus the end of the last one
-		size_t scan = 0, pair_end = 0;
-		long long total = 0, npairs = 0;
-		while (npairs < max_pairs && total < 100000000) {
-			const char *nl = scan < raw_len ? (const char *)memchr(raw.data() + scan, '\n', raw_len - scan) : nullptr;
-			size_t line_end;
-			if (nl) line_end = (size_t)(nl - raw.data());
-			else if (!raw_eof) {
-				if (raw.size() - raw_len < ((size_t)16 << 20)) raw.resize(raw.size() + ((size_t)64 << 20));
-				const size_t got = fread(raw.data() + raw_len, 1, raw.size() - raw_len, f);
-				raw_len += got;
-				if (got == 0) raw_eof = true;
-				continue;
-			} else if (scan < raw_len) line_end = raw_len;      // last line without a newline
-			else break;
-			ls.push_back(scan);
-			if ((ls.size() & 3) == 2) total += (long long)(line_end - scan);
-			scan = line_end + (nl ? 1 : 0);
-			if ((ls.size() & 7) == 0) ++npairs, pair_end = scan;
-		}
-		ls.resize((size_t)npairs * 8);
-		ls.push_back(pair_end);
-		raw_pos = pair_end;
-		if (npairs == 0) { bases.push_back(0); return false; }
-		const long long R = 2 * npairs;
-		recs.resize(R), ori.resize(R), base_off.resize(R + 1);
-		auto line = [&](size_t li, const char *&b, size_t &n) {
-			b = raw.data() + ls[li];
-			n = ls[li + 1] - ls[li];
-			while (n > 0 && (b[n - 1] == '\n' || b[n - 1] == '\r')) --n;
-		};
-		std::string first_before_parse;
-		auto build = [&](long long r0, long long r1) {
-			for (long long r = r0; r < r1; ++r) {
-				const char *b; size_t n;
-				FqRec &rec = recs[r];
-				line((size_t)r * 4, b, n);
-				size_t sp = 1;
-				while (sp < n && b[sp] != ' ' && b[sp] != '\t') ++sp;
-				rec.name.assign(n ? b + 1 : b, n ? sp - 1 : 0);
-				if (sp < n) rec.comment.assign(b + sp + 1, n - sp - 1); else rec.comment.clear();
-				if (r == 0) first_before_parse = rec.comment;
-				line((size_t)r * 4 + 1, b, n), rec.seq.assign(b, n);
-				line((size_t)r * 4 + 3, b, n), rec.qual.assign(b, n);
-				ori[r] = parse_ori(rec.comment);
-			}
-		};
-		auto parallel = [&](auto &&fn) {
-			const int nt = threads < 1 ? 1 : threads;
-			const long long per = (R + nt - 1) / nt;
-			std::vector<std::thread> th;
-			for (int t = 1; t < nt; ++t) if (t * per < R) th.emplace_back(fn, t * per, (t + 1) * per < R ? (t + 1) * per : R);
-			fn(0, per < R ? per : R);
-			for (std::thread &t : th) t.join();
-		};
-		parallel(build);
-		if (!have_first) first_comment = first_before_parse, have_first = true;
-		base_off[0] = 0;
-		for (long long r = 0; r < R; ++r) base_off[r + 1] = base_off[r] + (long long)recs[r].seq.size();
-		bases.resize((size_t)base_off[R] + 1);
-		parallel([&](long long r0, long long r1) { for (long long r = r0; r < r1; ++r) memcpy(bases.data() + base_off[r], recs[r].seq.data(), recs[r].seq.size()); });
-		bases[(size_t)base_off[R]] = 0;
-		return true;
-	}
-	void stat_params(psvr_aln_params_t *p) const   // load_reads, rr.cpp:134-148
-	{
-		int rl = 150, mn = 100, mid = 500, mx = 900;
-		const char *st = strstr(first_comment.c_str(), "STAT_");
-		if (!st || sscanf(st + 5, "%d_%d_%d_%d_", &rl, &mn, &mid, &mx) == -1) rl = 150, mn = 100, mid = 500, mx = 900;
-		p->normal_read_length = rl, p->isize_min = mn, p->isize_max = mx;
-		int mfs = rl * p->match * 2 - 80;
-		p->min_filter_score = mfs > 50 ? mfs : 50;
 	}
 };
 

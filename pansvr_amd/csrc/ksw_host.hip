@@ -90,7 +90,7 @@ extern "C" const char *psvr_last_error(void) { return last_error_ref().c_str(); 
 extern "C" void *psvr_host_alloc(size_t bytes)
 {
 	void *p = nullptr;
-	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable);   // page-locked for every device of the process
 	if (e != hipSuccess) { set_error(PSVR_ERR_NOMEM, "psvr_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
 	return p;
 }
@@ -113,7 +113,10 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	pl->device = device, pl->variant = variant, pl->n = n;
 	int rc = make_dp_params(par, variant, &pl->P);
 	if (rc) { delete pl; return rc; }
-	PSVR_HIP(hipSetDevice(device));
+	{
+		hipError_t he = hipSetDevice(device);
+		if (he != hipSuccess) { delete pl; return set_error(PSVR_ERR_DEVICE, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(he)); }
+	}
 	const int fast_flags = PSVR_EZ_EXTZ_ONLY | PSVR_EZ_REV_CIGAR | PSVR_EZ_SCORE_ONLY;
 	const bool fast_ok = variant == 0 && (par->flag & ~fast_flags) == 0;
 	// bucket = kind * classes + lds class

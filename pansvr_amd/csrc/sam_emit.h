@@ -1,0 +1,316 @@
+// sam_emit.h -- step 2 of the reference's pipeline for the MI355X engine: the two output files' records from the engine's
+// compact results.  Mirrors single_end_handler::output_BAM / output_ori_bam and the filter of align_read_pair
+// (src/PanSVgenerateVCF/read_realignment.cpp:479-536, 656-719, 776-797) as they come out of htslib 1.9's
+// sam_parse1 -> sam_format1 round trip (POS <= 0 drops the record, RNEXT collapses to '=', a trailing tab is ignored ...).
+// Pinned against the reference's own output: tests/golden/*/<reads>.sam.gz and .ori.sam.gz are `fc_aln -t 1 -S` files
+// written by the reference objects (oracle/ref_harness); tests/test_sam_golden.py compares byte for byte.
+// Only the pairs that are written are looked at: names, comments and qualities stay in the batch's raw text until here.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <atomic>
+#include <string>
+#include <vector>
+#include "../../include/psvr_engine.h"
+#include "bam_writer.h"
+#include "fastq_batch.h"
+
+namespace psvr {
+
+struct HeaderInfo {
+	std::string text;
+	std::vector<std::string> names;
+	std::vector<uint32_t> lens;
+	const char *name(int id) const { return id >= 0 && id < (int)names.size() ? names[(size_t)id].c_str() : "*"; }
+	bool load(const std::string &fn)
+	{
+		FILE *f = fopen(fn.c_str(), "r");
+		if (!f) return false;
+		char *buf = nullptr;
+		size_t cap = 0;
+		while (getline(&buf, &cap, f) > 0) {                 // header lines of any length
+			if (buf[0] != '@') continue;
+			text += buf;
+			if (strncmp(buf, "@SQ", 3)) continue;
+			char *p = strstr(buf, "SN:");
+			if (!p) continue;
+			p += 3;
+			char *e = p;
+			while (*e && *e != '\t' && *e != '\n') ++e;
+			names.emplace_back(p, e - p);
+			const char *ln = strstr(buf, "LN:");
+			lens.push_back(ln ? (uint32_t)strtoul(ln + 3, nullptr, 10) : 0u);
+		}
+		free(buf);
+		fclose(f);
+		return true;
+	}
+};
+
+// the results of a run of pairs, in the engine's compact form (psvr_engine_download_compact, or the emulation's arrays)
+struct ResultView {
+	const psvr_read_hdr_t *hdr = nullptr;            // [2 * pairs]
+	const psvr_pair_result_t *pairs = nullptr;       // [pairs]
+	const psvr_cand_t *cands = nullptr;              // hdr.cand_off indexes this
+	const uint32_t *cig = nullptr;                   // cand.cigar_off indexes this
+	long long pair0 = 0;                             // batch-local index of pairs[0] (a device's block of the batch)
+};
+
+struct SvNames {                                     // SV_chr_info::vcf_print_string / vcf_id per anchor (deBGA_index.hpp:116-119)
+	virtual const char *print_string(int sv) const = 0;
+	virtual const char *vcf_id(int sv) const = 0;
+	virtual ~SvNames() {}
+};
+
+inline char sam_rc_char(char c)                      // getReverseChar, clib/bam_file.c:316-327
+{
+	switch (c) {
+	case 'A': case 'a': return 'T';
+	case 'C': case 'c': return 'G';
+	case 'G': case 'g': return 'C';
+	case 'T': case 't': return 'A';
+	}
+	return 'N';
+}
+inline void sam_rev_seq(std::string &s)              // getReverseStr_char, clib/bam_file.c:329-339
+{
+	const int len = (int)s.size(), half = len >> 1;
+	for (int i = 0; i < half; i++) { const char t = s[(size_t)i]; s[(size_t)i] = sam_rc_char(s[(size_t)(len - 1 - i)]); s[(size_t)(len - 1 - i)] = sam_rc_char(t); }
+	if (len & 1) s[(size_t)half] = sam_rc_char(s[(size_t)half]);
+}
+inline void sam_rev_qual(std::string &q)             // getReverseStr_qual_char, clib/bam_file.c:351-359: bound len/2 + 1 (even len: the middle pair is swapped back)
+{
+	const int len = (int)q.size(), half = len >> 1;
+	for (int i = 0; i < half + 1; i++) { const int ri = len - 1 - i; if (ri < 0 || i >= len) break; const char t = q[(size_t)i]; q[(size_t)i] = q[(size_t)ri]; q[(size_t)ri] = t; }
+}
+
+struct EmitStats { std::atomic<long long> dropped{0}; };
+
+class SamEmitter {
+public:
+	const HeaderInfo *H = nullptr;
+	const SvNames *sv = nullptr;
+	bool as_bam = false, not_ori = false;
+	int min_filter_score = 520;
+	EmitStats *stats = nullptr;
+
+private:
+	static void put(std::vector<uint8_t> &d, const char *p, size_t n) { d.insert(d.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
+	static void put(std::vector<uint8_t> &d, const std::string &s) { put(d, s.data(), s.size()); }
+	static void put_int(std::vector<uint8_t> &d, long long v) { char b[24]; const int n = snprintf(b, sizeof b, "%lld", v); put(d, b, (size_t)n); }
+	static void cigar_text(const psvr_cand_t &c, const uint32_t *cig, std::string &s)
+	{
+		char b[32];
+		for (uint32_t j = 0; j < c.n_cigar; ++j) { const uint32_t w = cig[c.cigar_off + j]; const int n = snprintf(b, sizeof b, "%d%c", (int)(int16_t)(w >> 4), "MIDNSHP=XB"[w & 0xf]); s.append(b, (size_t)n); }
+	}
+	void drop(const char *what) const
+	{
+		if (stats) stats->dropped++;
+		fprintf(stderr, "%s\n", what);                // the reference reports a record sam_parse1 refuses the same way (rr.cpp:532,716)
+	}
+	// what sam_parse1 refuses (htslib 1.9 sam.c:1197-1424) among the texts this step can produce.  One rule for both output
+	// modes, so the BAM and the SAM file of the same input hold the same records.
+	static bool acceptable(const std::string &qname, const std::string &cigar, const std::string &seq, const std::string &qual)
+	{
+		if (qname.empty() || qname.size() > 254) return false;                    // "query name too long"
+		if (!cigar.empty() && cigar != "*") {
+			bool digit = false;
+			for (char ch : cigar) {
+				if (ch >= '0' && ch <= '9') { digit = true; continue; }
+				if (ch == '-' && !digit) continue;                                   // strtol takes a sign (the reference can print negative lengths)
+				if (!digit || !strchr("MIDNSHP=XB", ch)) return false;               // "unrecognized CIGAR operator"
+				digit = false;
+			}
+			if (digit) return false;
+		}
+		if (seq != "*" && qual != "*" && seq.size() != qual.size()) return false;  // "SEQ and QUAL are of different length"
+		return true;
+	}
+	// one record after the sam_parse1 -> sam_format1 round trip
+	bool emit(std::vector<uint8_t> &dst, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar, bool has_mate, int mate_chr, uint32_t mate_pos,
+	          int isize, const std::string &seq, const std::string &qual, const std::string &tags, const char *err_line) const
+	{
+		const int pos = (int)ref_bg;                               // printed with %d
+		if (chr_id < 0 || chr_id >= (int)H->names.size()) return false;   // target_name[] would be indexed out of range in the reference
+		if (pos - 1 < 0) return false;                             // "mapped query cannot have zero coordinate; treated as unmapped" -> tid = -1 -> not written
+		if (!acceptable(name, cigar, seq, qual)) { drop(err_line); return false; }
+		const char *rnext = "*";
+		long pnext = 0;
+		int mtid = -1;
+		if (has_mate) {
+			const int mp = (int)mate_pos;
+			const bool mate_ok = mate_chr >= 0 && mate_chr < (int)H->names.size() && !(mp - 1 < 0);
+			if (mate_ok) rnext = mate_chr == chr_id ? "=" : H->name(mate_chr), mtid = mate_chr;
+			pnext = mp;
+		}
+		if (as_bam) {
+			SamFields f;
+			f.qname = name, f.flag = flag, f.tid = chr_id, f.pos1 = pos, f.mapq = mapq, f.cigar = cigar.empty() ? "*" : cigar;
+			f.mtid = mtid, f.mpos1 = pnext, f.isize = isize, f.seq = seq, f.qual = qual, f.tags = tags;
+			if (!BamWriter::encode(f, dst)) { drop(err_line); return false; }
+			return true;
+		}
+		put(dst, name), put(dst, "\t", 1), put_int(dst, flag), put(dst, "\t", 1), put(dst, H->name(chr_id), strlen(H->name(chr_id))), put(dst, "\t", 1);
+		put_int(dst, pos), put(dst, "\t", 1), put_int(dst, mapq), put(dst, "\t", 1);
+		if (cigar.empty()) put(dst, "*", 1); else put(dst, cigar);
+		put(dst, "\t", 1), put(dst, rnext, strlen(rnext)), put(dst, "\t", 1), put_int(dst, pnext), put(dst, "\t", 1), put_int(dst, isize), put(dst, "\t", 1);
+		// SEQ as it comes back from the 4-bit BAM encoding sam_parse1 stores it in (lower case -> upper, non-IUPAC -> N)
+		const size_t at = dst.size();
+		put(dst, seq);
+		if (seq != "*") for (size_t i = at; i < dst.size(); ++i) dst[i] = (uint8_t)nt16_char((char)dst[i]);
+		put(dst, "\t", 1), put(dst, qual), put(dst, tags), put(dst, "\n", 1);
+		return true;
+	}
+
+	struct OriRecord { int flag = 0, mapq = 0, mate_chr = -1, mate_pos = 0, isize = 0; std::string cigar, tags; };
+	// single_end_handler::output_ori_bam (rr.cpp:656-717): the ORIGINAL alignment from the comment's FLAG_/CIGAR_/MATE_/TAG_ sections
+	static bool parse_ori_record(const std::string &comment, OriRecord *r)
+	{
+		const char *c = comment.c_str();
+		const char *f = strstr(c, "FLAG_");
+		if (!f) return false;
+		unsigned fl = 0, q = 0;
+		if (sscanf(f + 5, "%u_%u_", &fl, &q) < 2) return false;
+		r->flag = (int)fl, r->mapq = (int)q;
+		const char *cg = strstr(f + 5, "CIGAR_");
+		if (!cg) return false;
+		cg += 6;
+		const char *ce = strchr(cg, '_');
+		if (!ce) return false;
+		r->cigar.assign(cg, ce - cg);
+		const char *mate = ce + 1 + 5;                           // skips "MATE_"
+		if (strlen(ce) < 6 || sscanf(mate, "%d_%d_%d_", &r->mate_chr, &r->mate_pos, &r->isize) < 3) return false;
+		r->mate_pos += 1;
+		const char *tg = strstr(mate, "TAG_");
+		if (!tg) return false;
+		std::string tags = tg + 4;
+		const int tl = (int)tags.size();
+		for (int i = 0; i < tl - 5; i++) if (tags[(size_t)i] == '_' && tags[(size_t)i + 3] == ':' && tags[(size_t)i + 5] == ':') tags[(size_t)i] = '\t';
+		if (tl > 0) tags.resize((size_t)tl - 1);
+		r->tags = tags;
+		return true;
+	}
+	// bam_has_clip_or_unmapped_ori (rr.cpp:721-733) on the CIGAR text
+	static bool ori_has_clip(const std::string &cigar, int min_clip)
+	{
+		if (cigar.empty() || cigar == "*") return true;
+		int first_len = 0, last_len = 0, n = 0, ops = 0;
+		char first_op = 0, last_op = 0;
+		for (char ch : cigar) {
+			if (ch >= '0' && ch <= '9') { n = n * 10 + (ch - '0'); continue; }
+			if (ops++ == 0) first_op = ch, first_len = n;
+			last_op = ch, last_len = n, n = 0;
+		}
+		if (!ops) return true;
+		int tot = 0;
+		if (first_op == 'S' || first_op == 'H') tot += first_len;
+		if (last_op == 'S' || last_op == 'H') tot += last_len;
+		return tot >= min_clip;
+	}
+
+public:
+	// output_BAM for both reads of pair p (batch-local index); r = local read index base 2 * p
+	void main_pair(const FastqBatch &B, const ResultView &V, long long p, std::vector<uint8_t> &dst) const
+	{
+		const psvr_pair_result_t &pr = V.pairs[p - V.pair0];
+		if (!pr.gain) return;
+		std::string name, cm, seq, qual, cg, tags;
+		char b[256];
+		for (int k = 0; k < 2; ++k) {
+			const long long r = 2 * p + k;
+			const psvr_read_hdr_t &rr = V.hdr[r - 2 * V.pair0];
+			const psvr_ori_t &ori = B.ori[r];
+			if (rr.primary == -1) continue;                          // primary_result == NULL
+			const bool is_ori = rr.primary == -2;
+			if (not_ori && is_ori) continue;
+			int chr_id, direction, mapq;
+			uint32_t ref_bg, align_score, chain_score = 0;
+			const char *t; int n;
+			B.seq(r, t, n);
+			const int read_l = n;
+			cg.clear();
+			if (is_ori) {
+				chr_id = ori.chr_id, direction = ori.direction, mapq = ori.mapq, ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg, align_score = ori.align_score;
+				if (ori.read_bg > 0) { snprintf(b, sizeof b, "%dS", (int)(int16_t)(uint16_t)ori.read_bg); cg += b; }
+				snprintf(b, sizeof b, "%dM", (int)(int16_t)(uint16_t)(read_l - (int)ori.read_bg));
+				cg += b;
+			} else {
+				const psvr_cand_t &cd = V.cands[rr.cand_off + rr.primary];
+				chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
+				cigar_text(cd, V.cig, cg);
+			}
+			if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
+			const int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
+			const int isize = direction == 1 ? pr.cur_isize : -pr.cur_isize;
+			seq.assign(t, (size_t)n);
+			B.qual(r, t, n), qual.assign(t, (size_t)n);
+			if (direction == 0) sam_rev_seq(seq), sam_rev_qual(qual);
+			B.name(r, t, n), name.assign(t, (size_t)n);
+			B.comment(r, t, n), rewrite_comment(t, n, cm);
+			tags.clear();
+			snprintf(b, sizeof b, "\tAS:i:%d", (int)align_score), tags += b;
+			snprintf(b, sizeof b, "\tOS:i:%d\tOA:Z:%d,%d,%d,%d,%c;", (int)ori.align_score, ori.chr_id, (int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg), (int)ori.read_bg, (int)ori.mapq,
+			         rr.unmapped ? 'U' : 'M');
+			tags += b;
+			if (!is_ori) { snprintf(b, sizeof b, "\tCS:i:%d", (int)chain_score); tags += b; }
+			const char *svs = sv->print_string(rr.prim_sv_id);
+			if (svs) tags += "\tSV:Z:", tags += svs;
+			const char *mvs = rr.has_mate ? sv->print_string(rr.mate_sv_id) : nullptr;
+			if (mvs) tags += "\tMV:Z:", tags += mvs;
+			if (rr.secondary >= 0) {
+				const psvr_cand_t &sc = V.cands[rr.cand_off + rr.secondary];
+				const char *vid = sv->vcf_id(sc.sv_id);
+				snprintf(b, sizeof b, "\tXA:Z:%d,%d,%d,%d,%c,", sc.chr_id, (int)sc.ref_bg, (int)sc.read_bg, (int)sc.align_score, sc.direction == 1 ? 'F' : 'R');
+				tags += b;
+				tags += vid ? vid : "*";
+				tags += ";";
+			}
+			tags += "\tRC:Z:", tags += cm.c_str();                   // %s: up to a NUL the rewrite may have left
+			emit(dst, name, flag, chr_id, ref_bg, mapq, cg, rr.has_mate != 0, rr.mate_chr_id, rr.mate_ref_bg, isize, seq, qual, tags, "@sam_parse1 ERROR");
+		}
+	}
+	// the second file (rr.cpp:776-797): pairs neither the original aligner nor the re-aligner placed well
+	void ori_pair(const FastqBatch &B, const ResultView &V, long long p, std::vector<uint8_t> &dst) const
+	{
+		const psvr_pair_result_t &pr = V.pairs[p - V.pair0];
+		if (!(pr.max_score <= min_filter_score && B.ori[2 * p].chr_id != -1 && B.ori[2 * p + 1].chr_id != -1)) return;
+		OriRecord orr[2];
+		std::string cm[2];
+		for (int k = 0; k < 2; ++k) { const char *t; int n; B.comment(2 * p + k, t, n); cm[k].assign(t, (size_t)n); }
+		if (!parse_ori_record(cm[0], &orr[0]) || !parse_ori_record(cm[1], &orr[1])) return;
+		bool proper = pr.proper != 0;
+		for (int k = 0; proper && k < 2; ++k) {
+			const int mx = k == 0 ? pr.max1 : pr.max2;
+			if (mx == -1) { proper = false; break; }
+			if (mx == -2) { if (ori_has_clip(orr[k].cigar, 25)) proper = false; }
+			else {                                               // bam_has_clip_or_unmapped_new (rr.cpp:735-743): sums the 'I' ops
+				const psvr_cand_t &cd = V.cands[V.hdr[2 * (p - V.pair0) + k].cand_off + mx];
+				int tot = 0;
+				for (uint32_t j = 0; j < cd.n_cigar; ++j) { const uint32_t wv = V.cig[cd.cigar_off + j]; if ((wv & 0xf) == 1) tot += (int)(int16_t)(wv >> 4); }
+				if (cd.n_cigar == 0 || tot >= 25) proper = false;
+			}
+		}
+		if (proper) return;
+		std::string name, seq, qual, tags;
+		for (int k = 0; k < 2; ++k) {
+			const long long r = 2 * p + k;
+			const psvr_ori_t &ori = B.ori[r];
+			const char *t; int n;
+			B.seq(r, t, n), seq.assign(t, (size_t)n);
+			B.qual(r, t, n), qual.assign(t, (size_t)n);
+			B.name(r, t, n), name.assign(t, (size_t)n);
+			if (orr[k].flag & 0x10) sam_rev_seq(seq), sam_rev_qual(qual);
+			tags.clear();
+			if (!orr[k].tags.empty()) tags += "\t" + orr[k].tags;
+			char b[64];
+			snprintf(b, sizeof b, "\tMS:i:%d", pr.max_score);
+			tags += b;
+			const uint32_t ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg;
+			emit(dst, name, orr[k].flag, ori.chr_id, ref_bg + 1, orr[k].mapq, orr[k].cigar, true, orr[k].mate_chr, (uint32_t)orr[k].mate_pos, orr[k].isize, seq, qual, tags,
+			     "@ori_bam_sam_parse1 ERROR");
+		}
+	}
+};
+
+} // namespace psvr

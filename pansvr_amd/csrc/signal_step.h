@@ -50,6 +50,7 @@ struct BamStat {                                            // BAM_STAT, getSign
 	{
 		read_len = -1;
 		double tot_len = 0;
+		if (total == 0) { normal_percent = 0, ave_len = 0, read_len = 0, min_l2 = max_l2 = 0; return; }   // an empty BAM: the reference divides by zero here
 		for (int i = 0; i < kMaxLen; ++i) {
 			tot_len += (double)i * (double)len_n[i];
 			if ((double)len_n[i] > 0.6 * (double)total) { read_len = i, normal_percent = (double)len_n[i] / (double)total; break; }

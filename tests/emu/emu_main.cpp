@@ -6,7 +6,10 @@
 // and the speculative rand()-offset loop can be checked against the golden records in `-m "not gpu"`
 // tests.  It is never linked into libpsvr_engine.so.
 //
-// Usage: emu_aln <fixture_index_dir> <reads.fq> <header.sam> [--trace] [--batch N]
+// With --sam / --ori-sam it also runs the PRODUCT's host-side formatter (pansvr_amd/csrc/sam_emit.h, fastq_batch.h) over these
+// results, so the SAM text can be compared with the reference's own files without a GPU.
+//
+// Usage: emu_aln <fixture_index_dir> <reads.fq> <header.sam> [--trace] [--batch N] [--sam FILE --ori-sam FILE] [--threads N]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +17,8 @@
 #include <vector>
 #include "../../pansvr_amd/csrc/engine_core.h"
 #include "../../pansvr_amd/csrc/host_io.h"
+#include "../../pansvr_amd/csrc/fastq_batch.h"
+#include "../../pansvr_amd/csrc/sam_emit.h"
 #include "../../oracle/ksw_oracle.h"
 
 using namespace psvr;
@@ -110,15 +115,27 @@ struct CpuBE {
 	}
 };
 
+struct HostSvNames : SvNames {
+	const HostIndex *h;
+	const char *print_string(int sv) const override { return sv >= 0 && sv < (int)h->svh.size() ? h->svh[(size_t)sv].vcf_print_string.c_str() : nullptr; }
+	const char *vcf_id(int sv) const override { return sv >= 0 && sv < (int)h->svh.size() ? h->svh[(size_t)sv].vcf_id.c_str() : nullptr; }
+};
+
 int main(int argc, char **argv)
 {
-	if (argc < 4) { fprintf(stderr, "usage: emu_aln <index_dir> <reads.fq> <header.sam> [--trace] [--batch N]\n"); return 1; }
-	bool trace = false;
+	if (argc < 4) { fprintf(stderr, "usage: emu_aln <index_dir> <reads.fq> <header.sam> [--trace] [--batch N] [--sam FILE --ori-sam FILE]\n"); return 1; }
+	bool trace = false, quiet = false;
 	long long batch = 1 << 20;
+	int threads = 1;
+	const char *sam_fn = nullptr, *ori_fn = nullptr;
 	long long pos[3] = {-1, -1, -1}, from[3] = {-1, -1, -1};
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
+		else if (!strcmp(argv[i], "--no-records")) quiet = true;
 		else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoll(argv[++i]);
+		else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--sam") && i + 1 < argc) sam_fn = argv[++i];
+		else if (!strcmp(argv[i], "--ori-sam") && i + 1 < argc) ori_fn = argv[++i];
 		else if (!strcmp(argv[i], "--stream-pos") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &pos[0], &pos[1], &pos[2]);       // start of this shard in the three draw streams
 		else if (!strcmp(argv[i], "--rebase-from") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &from[0], &from[1], &from[2]);  // run there first, then rebase to --stream-pos
 	}
@@ -131,26 +148,49 @@ int main(int argc, char **argv)
 	aln_params_default(&par);
 	CpuBE be;
 	EngineCore<CpuBE> core(be);
+	FastqReader rd;
 	FastqBatch fb;
-	FILE *fq = fopen(argv[2], "r");
-	if (!fq) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+	if (!rd.open(argv[2])) { fprintf(stderr, "%s\n", rd.error().c_str()); return 2; }
+	HeaderInfo H;
+	HostSvNames svn;
+	svn.h = &hi;
+	SamEmitter em;
+	FILE *fsam = nullptr, *fori = nullptr;
+	if (sam_fn && ori_fn) {
+		if (!H.load(argv[3])) { fprintf(stderr, "cannot read %s\n", argv[3]); return 2; }
+		fsam = fopen(sam_fn, "w"), fori = fopen(ori_fn, "w");
+		if (!fsam || !fori) { fprintf(stderr, "cannot open the SAM outputs\n"); return 2; }
+		fputs(H.text.c_str(), fsam), fputs(H.text.c_str(), fori);
+		em.H = &H, em.sv = &svn;
+	}
 	bool first = true;
 	long long pair_base = 0;
-	while (fb.read(fq, batch)) {
+	while (rd.read(fb, batch, 100000000, threads)) {
 		if (first) {
-			fb.stat_params(&par);
+			rd.stat_params(&par);
 			core.init(ix, par);
 			first = false;
+			em.min_filter_score = par.min_filter_score;
 			const long long *st = from[0] >= 0 ? from : pos;
 			if (st[0] >= 0) core.grand_pos = st[0], core.hrand_pos[0] = st[1], core.hrand_pos[1] = st[2];
 		}
-		int rc = core.upload(fb.n_pairs(), fb.bases.data(), (const int64_t *)fb.base_off.data(), fb.ori.data());
+		int rc = core.upload(fb.n_pairs(), fb.bases, fb.base_off, fb.ori);
 		if (!rc) rc = core.run(trace, true);
 		if (!rc && from[0] >= 0 && pos[0] >= 0) { rc = core.rebase(pos[0], pos[1], pos[2], trace, true); from[0] = -1; }
 		if (rc) { fprintf(stderr, "emu error %d: %s\n", rc, core.err.c_str()); return 3; }
-		for (long long p = 0; p < fb.n_pairs(); ++p) {
-			int lens[2] = {(int)fb.recs[2 * p].seq.size(), (int)fb.recs[2 * p + 1].seq.size()};
-			puts(record_json(pair_base + p, core.c.res + 2 * p, core.c.pres[p], &fb.ori[2 * p], lens, core.c.cig.base, trace).c_str());
+		for (long long p = 0; p < fb.n_pairs() && !quiet; ++p) {
+			const char *t; int lens[2];
+			fb.seq(2 * p, t, lens[0]), fb.seq(2 * p + 1, t, lens[1]);
+			psvr_read_result_t rr[2];
+			materialize_read(core.c, 2 * p, &rr[0]), materialize_read(core.c, 2 * p + 1, &rr[1]);
+			puts(record_json(pair_base + p, rr, core.c.pres[p], &fb.ori[2 * p], lens, core.c.cig.base, trace).c_str());
+		}
+		if (fsam) {       // the engine's arrays ARE the compact form (headers + candidate list + CIGAR arena)
+			ResultView V;
+			V.hdr = core.c.rh, V.pairs = core.c.pres, V.cands = core.c.cand, V.cig = core.c.cig.base;
+			std::vector<uint8_t> a, b;
+			for (long long p = 0; p < fb.n_pairs(); ++p) em.main_pair(fb, V, p, a), em.ori_pair(fb, V, p, b);
+			fwrite(a.data(), 1, a.size(), fsam), fwrite(b.data(), 1, b.size(), fori);
 		}
 		core.commit();
 		fprintf(stderr, "[emu] stream_end %lld %lld %lld\n", core.grand_pos, core.hrand_pos[0], core.hrand_pos[1]);
@@ -158,5 +198,6 @@ int main(int argc, char **argv)
 		fprintf(stderr, "[emu] batch of %lld pairs: %lld rounds, %lld pair-runs (+%lld pairing-only, +%lld shadow, %lld sensitive, %lld window misses), %lld DP problems, %lld candidates\n", fb.n_pairs(), core.stats.rounds,
 		        core.stats.pairs_run, core.stats.pair_only, core.stats.shadow_runs, core.stats.sensitive, core.stats.window_miss, core.stats.dp_problems, core.stats.cands);
 	}
+	if (fsam) fclose(fsam), fclose(fori);
 	return 0;
 }

@@ -7,6 +7,8 @@ For every data set in DATASETS: synthesize anchors/reads (tests/synth.py, seeded
 with the reference deBGA (-k 22), run ref_aln --trace, and commit
     tests/golden/<name>/idx/          compact index (tests/index_fixture.py)
     tests/golden/<name>/<reads>.jsonl.gz   one record per read pair, as printed by the reference objects
+    tests/golden/<name>/<reads>.sam.gz, <reads>.ori.sam.gz   the two output files of `fc_aln -t 1 -S` (the reference's own
+                                           output_BAM / output_ori_bam -> sam_parse1 -> sam_format1 text)
 """
 import gzip
 import os
@@ -22,6 +24,12 @@ import index_fixture  # noqa: E402
 import datasets  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
+# non-default scoring options (-M -m -O -E -P -F -z) run through the reference objects as well: (data set, reads, options)
+SCORE_SETS = [("fx2", "reads150", s) for s in ((3, 9, 12, 2, 24, 1, 200), (1, 4, 6, 1, 20, 0, 50), (2, 30, 40, 3, 60, 2, 400))]
+
+
+def score_tag(s):
+    return "score_" + "_".join(str(x) for x in s)
 
 
 def main(names):
@@ -39,12 +47,30 @@ def main(names):
         os.makedirs(out, exist_ok=True)
         index_fixture.compact(idx, os.path.join(out, "idx"))
         for rname in ds["reads"]:
-            res = subprocess.run([os.path.join(REF, "ref_aln"), idx, os.path.join(work, rname + ".fq"), os.path.join(work, "header.sam"), "--trace"],
-                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
-            lines = [l for l in res.stdout.decode().split("\n") if l.startswith("{") or l.startswith(" {")]
-            with open(os.path.join(out, rname + ".jsonl.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:   # mtime=0: reproducible bytes
+            sam, ori, rec = (os.path.join(work, rname + e) for e in (".ref.sam", ".ref.ori.sam", ".ref.jsonl"))
+            subprocess.run([os.path.join(REF, "ref_aln"), "-t", "1", "-S", "-o", sam, "-p", ori, idx, os.path.join(work, rname + ".fq"), os.path.join(work, "header.sam"),
+                            "--trace", "--records", rec], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            lines = [l for l in open(rec).read().split("\n") if l.startswith("{") or l.startswith(" {")]
+
+            def put(path, data):
+                with open(path, "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:   # mtime=0: reproducible bytes
+                    f.write(data)
+            put(os.path.join(out, rname + ".jsonl.gz"), ("\n".join(l.strip() for l in lines) + "\n").encode())
+            put(os.path.join(out, rname + ".sam.gz"), open(sam, "rb").read())
+            put(os.path.join(out, rname + ".ori.sam.gz"), open(ori, "rb").read())
+            print(name, rname, len(lines), "pairs", os.path.getsize(sam), "B sam", os.path.getsize(ori), "B ori sam")
+        for sname, rname, sc in SCORE_SETS:
+            if sname != name:
+                continue
+            rec = os.path.join(work, rname + "." + score_tag(sc) + ".jsonl")
+            M, m, O, E, P, F, z = sc
+            subprocess.run([os.path.join(REF, "ref_aln"), "-t", "1", "-M", str(M), "-m", str(m), "-O", str(O), "-E", str(E), "-P", str(P), "-F", str(F), "-z", str(z),
+                            idx, os.path.join(work, rname + ".fq"), os.path.join(work, "header.sam"), "--trace", "--records", rec],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            lines = [l for l in open(rec).read().split("\n") if l.startswith("{")]
+            with open(os.path.join(out, rname + "." + score_tag(sc) + ".jsonl.gz"), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
                 f.write(("\n".join(l.strip() for l in lines) + "\n").encode())
-            print(name, rname, len(lines), "pairs")
+            print(name, rname, score_tag(sc), len(lines), "pairs")
 
 
 if __name__ == "__main__":

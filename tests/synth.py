@@ -48,7 +48,10 @@ def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, du
 
 
 def header_text():
-    return "@HD\tVN:1.6\tSO:unsorted\n@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n"
+    """The ORIGINAL genome's header: 32 contigs, so that every tid the read generator emits (0, 1 and the decoy-like 30 of the
+    `tid > 24 => unmapped` case) names a contig -- the reference indexes target_name[] with it unchecked."""
+    names = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY", "chrM"] + ["decoy%d" % i for i in range(1, 8)]
+    return "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:250000000\n" % n for n in names)
 
 
 def _mutate(rng, s, kind, maxindel=8):

@@ -1,0 +1,127 @@
+"""-m gpu: entry points of include/psvr_engine.h called directly through ctypes (no CLI in between):
+psvr_engine_align_batch (the call INTEGRATION.md tells a maintainer to make) against upload / run / download,
+psvr_engine_download_compact against the fixed-size records, psvr_index_clone against the index it was copied from."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import aln_common as ac
+import index_fixture
+import synth
+from test_emu_aln import normalise
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(name="fx2", rname="reads150", limit=600):
+    """bases / base_off / ori of the first `limit` pairs of a golden read set, parsed as the CLI's reader parses them."""
+    w = ac.workdir(name)
+    lines = open(os.path.join(w, rname + ".fq")).read().split("\n")
+    from pansvr_amd import aln
+    seqs, oris = [], []
+    for k in range(0, 8 * limit, 4):
+        cm = lines[k].split(" ", 1)[1]
+        tok = [t for t in cm.split("_") if t][:10]
+        seqs.append(lines[k + 1])
+        oris.append((int(tok[0]), int(tok[1]) & 0xffffffff, int(tok[2]), int(tok[3]), int(tok[4]) & 0xff, 1 if tok[9][0] == "F" else 0, 1 if tok[9][1] == "Y" else 0, 0))
+    bases = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    base_off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+    ori = np.array(oris, dtype=aln.ORI_DTYPE)
+    stat = (150, 200, 400, 600)
+    return bases, base_off, ori, stat
+
+
+def _index(name="fx2", device=0):
+    from pansvr_amd import aln
+    names = [l.split("SN:")[1].split("\t")[0] for l in synth.header_text().split("\n") if l.startswith("@SQ")]
+    return aln.Index(index_fixture.load_arrays(os.path.join(ac.golden_dir(name), "idx")), names, device=device)
+
+
+def test_align_batch_equals_upload_run_download_and_the_reference():
+    from pansvr_amd import aln
+    from pansvr_amd._lib import check, lib
+    bases, base_off, ori, stat = _inputs()
+    P = (len(base_off) - 1) // 2
+    index = _index()
+    # (1) upload / run / download
+    e1 = aln.Engine(index, aln.default_params(stat))
+    e1.upload(bases, base_off, ori)
+    e1.run()
+    r1, p1, c1 = e1.download()
+    # (2) the one-call form, into caller buffers
+    e2 = aln.Engine(index, aln.default_params(stat))
+    r2, p2 = np.zeros(2 * P, dtype=aln.READ_DTYPE), np.zeros(P, dtype=aln.PAIR_DTYPE)
+    c2 = np.zeros(len(c1) + 16, dtype=np.uint32)
+    check(lib().psvr_engine_align_batch(e2.h, C.c_int64(P), bases.ctypes.data_as(C.c_char_p), base_off.ctypes.data_as(C.c_void_p), ori.ctypes.data_as(C.c_void_p),
+                                        r2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p), C.c_int64(len(c2)), 0))
+    assert r1.tobytes() == r2.tobytes() and p1.tobytes() == p2.tobytes() and c1[:len(c1) - 1].tobytes() == c2[:len(c1) - 1].tobytes()
+    # a too small CIGAR arena is an error, not a silent truncation
+    rc = lib().psvr_engine_align_batch(e2.h, C.c_int64(P), bases.ctypes.data_as(C.c_char_p), base_off.ctypes.data_as(C.c_void_p), ori.ctypes.data_as(C.c_void_p),
+                                       r2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p), C.c_int64(8), 0)
+    assert rc == 6
+    # (3) and they are the reference's records
+    lens = np.diff(base_off)
+    got = ac.engine_records(r1, p1, c1, ori, lens, 0, P)
+    want = [ac.strip_trace(l) for l in ac.golden_lines("fx2", "reads150")[:P]]
+    assert got == want
+    e1.close(), e2.close(), index.close()
+
+
+def test_compact_download_holds_the_same_results_in_a_sixth_of_the_bytes():
+    from pansvr_amd import aln
+    bases, base_off, ori, stat = _inputs(limit=1500)
+    P = (len(base_off) - 1) // 2
+    index = _index()
+    eng = aln.Engine(index, aln.default_params(stat))
+    eng.upload(bases, base_off, ori)
+    eng.run()
+    reads, pairs, cig = eng.download()
+    hdr, pairs2, cands, cig2 = eng.download_compact()
+    assert pairs.tobytes() == pairs2.tobytes()
+    assert int(hdr["n_result"].sum()) == len(cands) == int(reads["n_result"].sum())
+    for f in ("n_result", "unmapped", "early_out", "is_str", "primary", "secondary", "has_mate", "mate_chr_id", "mate_ref_bg", "prim_sv_id", "mate_sv_id"):
+        assert (hdr[f] == reads[f]).all(), f
+    assert (hdr["cand_off"][hdr["n_result"] > 0] == (np.cumsum(hdr["n_result"]) - hdr["n_result"])[hdr["n_result"] > 0]).all()      # dense, in read order
+    k = 0
+    for r in range(2 * P):
+        for i in range(int(hdr["n_result"][r])):
+            a, b = reads["cand"][r][i], cands[k]
+            for f in ("align_score", "chain_score", "ref_bg", "read_bg", "chr_id", "sv_id", "max_index", "n_cigar", "direction", "mapq"):
+                assert a[f] == b[f], (r, i, f)
+            n = int(a["n_cigar"])
+            assert (cig[int(a["cigar_off"]):int(a["cigar_off"]) + n] == cig2[int(b["cigar_off"]):int(b["cigar_off"]) + n]).all()
+            k += 1
+    assert int(cands["n_cigar"].sum()) == len(cig2)                               # only the CIGAR words that exist
+    full_bytes = reads.nbytes + pairs.nbytes + cig.nbytes
+    compact_bytes = hdr.nbytes + pairs2.nbytes + cands.nbytes + cig2.nbytes
+    assert compact_bytes * 4 < full_bytes, (compact_bytes, full_bytes)
+    # page-locked buffers, second call on the same run (cached on the device)
+    hb = aln.HostBuffers()
+    h2, p2, c2, g2 = eng.download_compact(hb)
+    assert h2.tobytes() == hdr.tobytes() and c2.tobytes() == cands.tobytes() and g2.tobytes() == cig2.tobytes()
+    hb.close()
+    eng.close(), index.close()
+
+
+def test_index_clone_is_an_index():
+    from pansvr_amd import aln
+    from pansvr_amd._lib import check, lib
+    bases, base_off, ori, stat = _inputs(limit=400)
+    index = _index()
+    h = C.c_void_p()
+    check(lib().psvr_index_clone(index.h, 0, C.byref(h)))
+    lib().psvr_index_device_bytes.restype = C.c_int64
+    assert lib().psvr_index_device_bytes(h) == index.device_bytes
+    clone = aln.Index.__new__(aln.Index)
+    clone.h, clone.device_bytes = h, index.device_bytes
+    outs = []
+    for ix in (index, clone):
+        eng = aln.Engine(ix, aln.default_params(stat))
+        eng.upload(bases, base_off, ori)
+        eng.run()
+        outs.append(eng.download())
+        eng.close()
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(*outs))
+    clone.close(), index.close()

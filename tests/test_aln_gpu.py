@@ -30,31 +30,18 @@ def test_gpu_engine_matches_reference_records(name, rname):
     assert len(got) == len(want)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if normalise(a) != normalise(b)]
     assert not bad, "%d/%d pairs differ; first %d:\nref: %s\ngpu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
-    # SAM text (A15, restated from output_BAM + sam_parse1/sam_format1; not reference-pinned): every record must be the
-    # primary the decision record names, field for field
-    sam = [l.rstrip("\n").split("\t") for l in open(os.path.join(tmp, "out.sam")) if not l.startswith("@")]
-    by_key = {(f[0], int(f[1]) & 0x40): f for f in sam}
-    assert len(by_key) == len(sam)
-    n_expected = 0
-    for line in want:
-        d = normalise(line)
-        if not d["pe"][3]:
-            continue
-        for k, r in enumerate(d["reads"]):
-            prim = r.get("prim", -1)
-            if prim == -1:
-                continue
-            rec = r["ori"] if prim == -2 else r["res"][prim]
-            if rec[2] < 0 or rec[2] > 1 or rec[3] < 1:
-                continue                                   # out-of-header chromosome / POS 0: the reference's record is dropped
-            n_expected += 1
-            f = by_key[("r%07d" % d["i"], 0x40 if k == 0 else 0)]
-            assert int(f[3]) == rec[3] and f[5] == rec[7] and int(f[4]) == rec[6]
-            assert ("AS:i:%d" % rec[0]) in f and (int(f[1]) & 0x10 != 0) == (rec[5] == 0)
-            assert any(t.startswith("RC:Z:") for t in f) and any(t.startswith("OA:Z:") for t in f)
-    assert n_expected == len(sam) and n_expected > 0
-    ori = [l for l in open(os.path.join(tmp, "ori.sam")) if not l.startswith("@")]
-    assert all("MS:i:" in l for l in ori)
+    # A15: both files byte for byte the reference's own `fc_aln -t 1 -S` output (tests/golden/*/<reads>.sam.gz, .ori.sam.gz:
+    # output_BAM / output_ori_bam -> sam_parse1 -> sam_format1 of the reference objects)
+    import gzip
+    for got_fn, ext in (("out.sam", ".sam.gz"), ("ori.sam", ".ori.sam.gz")):
+        got = open(os.path.join(tmp, got_fn), "rb").read()
+        with gzip.open(os.path.join(ac.golden_dir(name), rname + ext), "rb") as f:
+            want = f.read()
+        if got != want:
+            gl, wl = got.split(b"\n"), want.split(b"\n")
+            first = next((i for i, (a, b) in enumerate(zip(wl, gl)) if a != b), min(len(gl), len(wl)))
+            raise AssertionError("%s: line %d differs (%d vs %d lines)\nref: %r\ngpu: %r" % (got_fn, first, len(wl), len(gl), wl[first][:500] if first < len(wl) else None,
+                                                                                             gl[first][:500] if first < len(gl) else None))
 
 
 def test_gpu_cli_bam_output_equals_sam_text():
@@ -84,10 +71,10 @@ def test_gpu_cli_bam_output_equals_sam_text():
 
 
 @pytest.mark.parametrize("score", [(3, 9, 12, 2, 24, 1, 200), (1, 4, 6, 1, 20, 0, 50), (2, 30, 40, 3, 60, 2, 400)])
-def test_gpu_cli_scoring_options_match_oracle(score):
-    """-M -m -O -E -P -F -z: the engine against the CPU restatement run with the same options (the reference objects behind the
-    golden records only ran the defaults).  The third set leaves the int8-safe regime, so its DP goes through the wavefront
-    kernels instead of the team kernel."""
+def test_gpu_cli_scoring_options_match_reference(score):
+    """-M -m -O -E -P -F -z: the engine against what the REFERENCE's objects decided with the same options
+    (tests/golden/fx2/reads150.score_*.jsonl.gz, through the reference's own option parser).  The third set leaves the int8-safe
+    regime, so its DP goes through the wavefront kernels instead of the team kernel."""
     name, rname = "fx2", "reads150"
     w = ac.workdir(name)
     tmp = tempfile.mkdtemp(prefix="psvr_score_")
@@ -98,11 +85,53 @@ def test_gpu_cli_scoring_options_match_oracle(score):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [normalise(l) for l in open(rec).read().split("\n") if l.strip()]
-    want = [normalise(l) for l in ac.run_oracle(name, rname, trace=True, score=score)]
+    want = [normalise(l) for l in ac.golden_lines(name, rname + ".score_" + "_".join(str(x) for x in score))]
     assert len(got) == len(want)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if a != b]
-    assert not bad, "%d/%d pairs differ; first %d:\norc: %s\ngpu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
+    assert not bad, "%d/%d pairs differ; first %d:\nref: %s\ngpu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
     assert got != [normalise(l) for l in ac.golden_lines(name, rname)]        # the options really changed the results
+
+
+def _run_cli(tmp, tag, name, rname, extra):
+    w = ac.workdir(name)
+    o = os.path.join(tmp, tag)
+    r = subprocess.run([CLI, "aln", "-S", "-t", "4", "-o", o + ".sam", "-p", o + ".ori.sam", "--records", o + ".jsonl"] + extra +
+                       [os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return o, r.stderr.decode()
+
+
+@pytest.mark.parametrize("name,rname", [("fx2", "reads150"), ("fx3", "ragged")])
+def test_gpu_cli_batch_boundaries_carry_the_draw_streams(name, rname):
+    """A16: the three-stage pipeline over many batches (97 pairs each: raw text, rand() and random_r positions carried across every
+    boundary) writes byte for byte the files of a single batch -- and those are the reference's (previous test)."""
+    tmp = tempfile.mkdtemp(prefix="psvr_pipe_")
+    one, _ = _run_cli(tmp, "one", name, rname, [])
+    many, err = _run_cli(tmp, "many", name, rname, ["--batch", "97"])
+    assert err.count("Processing ") >= 10
+    for ext in (".sam", ".ori.sam", ".jsonl"):
+        assert open(one + ext, "rb").read() == open(many + ext, "rb").read(), ext
+    # the reference's own batching rule (a batch ends at 100 MB of bases, read_realignment.cpp:109,126), scaled down
+    few, err = _run_cli(tmp, "few", name, rname, ["--batch-bases", "60000"])
+    assert err.count("Processing ") >= 5
+    assert open(one + ".sam", "rb").read() == open(few + ".sam", "rb").read()
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_gpu_cli_devices_split_every_batch_in_input_order(devices):
+    """(e) in the product: `--devices` cuts every batch into contiguous blocks, one engine per entry (here all mapped to the box's one
+    GPU), moves block d to where block d-1 stopped in the draw streams and gathers in order: the files must be those of one
+    device -- for one big batch and for many small ones."""
+    import json
+    tmp = tempfile.mkdtemp(prefix="psvr_dev_")
+    name, rname = "fx2", "reads150"
+    one, _ = _run_cli(tmp, "one", name, rname, [])
+    for tag, extra in (("split", []), ("split_batches", ["--batch", "211"])):
+        got, err = _run_cli(tmp, tag, name, rname, ["--devices", devices] + extra)
+        for ext in (".sam", ".ori.sam", ".jsonl"):
+            assert open(one + ext, "rb").read() == open(got + ext, "rb").read(), (tag, ext)
+        e2e = json.loads([l for l in err.split("\n") if "e2e_json" in l][-1].split("e2e_json ", 1)[1])
+        assert e2e["devices"] == len(devices.split(",")) and e2e["rebase_iterations"] >= 1
 
 
 def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
@@ -131,7 +160,8 @@ def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
             seq, qual = "".join(comp[c] for c in reversed(seq)), qual[::-1]
         recs.append(ts.record(name, flag, int(tok[0]), int(tok[1]), mapq, cigar, int(m.group(4)), int(m.group(5)), int(m.group(6)), seq, qual, tags))
     bam = os.path.join(tmp, "x.bam")
-    ts.write_bam(bam, recs, [("chr1", 250000000), ("chr2", 250000000)])
+    import synth
+    ts.write_bam(bam, recs, [(l.split("SN:")[1].split("\t")[0], 250000000) for l in synth.header_text().split("\n") if l.startswith("@SQ")])
     # route 1: two commands
     fq = os.path.join(tmp, "x.fq")
     r = subprocess.run([CLI, "signal", "-N", "-D", "-H", os.path.join(tmp, "h1.sam"), "-S", os.path.join(tmp, "s1.txt"), bam], stdout=open(fq, "wb"), stderr=subprocess.PIPE)

@@ -45,11 +45,12 @@ def test_emulated_engine_matches_reference_records(emu, name, rname):
     assert not bad, "%d/%d pairs differ; first %d:\nref: %s\nemu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
 
 
-@pytest.mark.parametrize("variant", ["crlf", "no_final_newline", "tiny_batches", "truncated_pair"])
+@pytest.mark.parametrize("variant", ["crlf", "no_final_newline", "tiny_batches", "truncated_pair", "gz", "pipe", "pipe_tiny_batches", "threads"])
 def test_fastq_reader_edge_cases(emu, variant):
-    """host_io.h's batch reader (memchr line scan + records built on threads) on awkward inputs: CR LF line ends, a last line without
-    a newline, batches of 7 pairs (raw text carried across batches), and a trailing incomplete pair (ignored, like the
-    reference's read loop).  The records must be those of the plain file."""
+    """fastq_batch.h's batch reader (memory-mapped or streamed text, line index built on threads, nothing copied but the bases) on
+    awkward inputs: CR LF line ends, a last line without a newline, batches of 7 pairs, a trailing incomplete pair (ignored, like
+    the reference's read loop), a gzip file, a pipe (stream mode: text carried across batches), several index threads.  The
+    records must be those of the plain file."""
     w = ac.workdir("fx1")
     text = open(os.path.join(w, "reads150.fq")).read()
     n_keep = 300
@@ -62,12 +63,28 @@ def test_fastq_reader_edge_cases(emu, variant):
     elif variant == "tiny_batches":
         data = "\n".join(lines) + "\n"
         extra = ["--batch", "7"]
-    else:
+    elif variant == "truncated_pair":
         data = "\n".join(lines + lines[:4]) + "\n"          # one more read without its mate
+    else:
+        data = "\n".join(lines) + "\n"
+        if variant == "pipe_tiny_batches":
+            extra = ["--batch", "11"]
+        if variant == "threads":
+            extra = ["--threads", "5", "--batch", "64"]
     path = os.path.join(w, "edge_%s.fq" % variant)
-    open(path, "w", newline="").write(data)
+    stdin = None
+    if variant == "gz":
+        import gzip
+        path += ".gz"
+        with gzip.open(path, "wb") as f:
+            f.write(data.encode())
+    else:
+        open(path, "w", newline="").write(data)
+    if variant.startswith("pipe"):
+        stdin, path = open(path, "rb"), "-"
+        stdin = subprocess.Popen(["cat"], stdin=stdin, stdout=subprocess.PIPE).stdout      # a real pipe, not a seekable file
     out = subprocess.run([emu, os.path.join(ac.golden_dir("fx1"), "idx"), path, os.path.join(w, "header.sam"), "--trace"] + extra,
-                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+                         stdin=stdin, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
     got = [normalise(l) for l in out.split("\n") if l.strip()]
     want = [normalise(l) for l in ac.golden_lines("fx1", "reads150")[:n_keep]]
     assert got == want

@@ -23,6 +23,22 @@ def test_oracle_matches_reference_records(name, rname):
     assert not bad, "%d/%d pairs differ; first %d:\nref: %s\norc: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
 
 
+SCORE_SETS = [(3, 9, 12, 2, 24, 1, 200), (1, 4, 6, 1, 20, 0, 50), (2, 30, 40, 3, 60, 2, 400)]
+
+
+def score_tag(score):
+    return "score_" + "_".join(str(x) for x in score)
+
+
+@pytest.mark.parametrize("score", SCORE_SETS)
+def test_oracle_matches_reference_records_with_scoring_options(score):
+    """-M -m -O -E -P -F -z through the reference's own option parser and aligner objects (tests/golden/fx2/reads150.score_*.jsonl.gz)."""
+    want = ac.golden_lines("fx2", "reads150." + score_tag(score))
+    got = ac.run_oracle("fx2", "reads150", trace=True, score=score)
+    assert len(got) == len(want) and got == want
+    assert want != ac.golden_lines("fx2", "reads150")          # the options really changed the results
+
+
 def test_private_rand_matches_libc():
     """orc::Rand3 must reproduce glibc rand() (seed 1) -- only meaningful on a glibc host."""
     libc = ctypes.CDLL(None)
