@@ -4,16 +4,20 @@
 One "step" = one pass of the whole `aln` hot path (prep -> seeding -> chaining -> candidate
 selection -> extension DP -> assembly -> pairing, incl. the speculative rand()-offset rounds) over one
 batch of synthetic 150 bp read pairs that is already resident in HBM (configs[1]: 1 M pairs vs a
-10 k-anchor SV reference).  With --gpus N every rank owns one GPU and an independent shard of the
-same size (weak scaling, no data-path collective: read pairs are independent given the replicated
-index); the shards form ONE input stream: after its run every rank all-gathers three integers (draws its shard consumed
-from the reference's rand()/random_r sequences) and rebases to start where the previous rank ended
-(pansvr_amd/dist.py), so N GPUs produce exactly the records of one `-t 1` pass over the concatenated shards.  Time is
-max over ranks between barriers.
+10 k-anchor SV reference).  With --gpus N every rank owns one GPU and one contiguous block of ONE input
+(weak scaling: 1 M pairs per GPU; block r of the input is generated from seed 13 + r, the input is their
+concatenation); read pairs are independent given the replicated index, so there is no data-path collective -- except
+that the reference draws from one rand()/random_r sequence in input order: after its run every rank all-gathers three
+integers (draws its block consumed) over RCCL and rebases to start where the previous rank ended (pansvr_amd/dist.py), so N
+GPUs produce exactly the records of one `-t 1` pass over the whole input.  Time is max over ranks between barriers.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel, timed live with HIP events on its launch stream
-  "cpu_baseline": the oracle restatement (kind "port") timed on this box's host cores on a bounded sample.
+  "cpu_baseline": the reference's own objects (oracle/_ref/ref_aln, kind "reference") or the oracle restatement
+                  (kind "port") timed on this box's host cores on a bounded sample: -t 1 and -t <all cores>
+  "parity_check": every rank's block (first pairs of it) against the reference objects started at that block's position
+  "e2e":          wall of the drop-in command `panSVR aln` on the same workload (FASTQ in -> SAM / BAM out), phase split
+  "pcie_inclusive": upload + run + compact download of one batch through the C ABI
 """
 import argparse
 import json
@@ -28,6 +32,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+HEADER = "@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n"
+
+
+def align_seconds(err, key="ALIGN_SECONDS"):
+    return max(float([l for l in err.split("\n") if l.startswith(key)][-1].split()[1]), 1e-9)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -36,9 +46,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU (configs[1]: 1 M)")
     ap.add_argument("--anchors", type=int, default=10000)
-    ap.add_argument("--cpu-pairs", type=int, default=60000, help="pairs of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--check-pairs", type=int, default=50000, help="pairs of the sample whose engine records are compared with the CPU run")
+    ap.add_argument("--cpu-pairs", type=int, default=300000, help="pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--check-pairs", type=int, default=50000, help="pairs per rank whose engine records are compared with the reference objects")
     ap.add_argument("--no-ref-cpu", action="store_true", help="time only the oracle port even if oracle/_ref/ref_aln is present")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `panSVR aln` leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU-baseline leg (0 = all cores, capped at the reference's 48)")
     args = ap.parse_args()
 
     import numpy as np
@@ -48,16 +60,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rehearse = os.environ.get("PSVR_BENCH_REHEARSE") == "1"      # all ranks share GPU 0 and exchange over gloo (single-GPU rehearsal of the N > 1 path)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # PSVR_BENCH_REHEARSE=1: all ranks share GPU 0 and exchange over gloo (single-GPU rehearsal of the N>1 code path)
-        rehearse = os.environ.get("PSVR_BENCH_REHEARSE") == "1"
         dist.init_process_group("gloo" if rehearse or not torch.cuda.is_available() else "nccl")
         if rehearse:
             local_rank = 0
-    if not torch.cuda.is_available():
+    if torch.cuda.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
     # the engine library, the CLI (its `index` sub-command builds the bench index) and the checkers: built here if the tree is a
     # fresh checkout (no-ops otherwise); one rank builds, the others wait
     if rank == 0:
@@ -65,20 +75,59 @@ def main():
         _build.build(force=False, verbose=False)
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     if world > 1:
+        torch.cuda.set_device(local_rank)
         dist.barrier()
-    xdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else None
 
     import bench_data
     from pansvr_amd import aln
 
+    # ---- workload (host side, before this process touches the GPU: the FASTQ writer forks)
     t_setup = time.time()
+    shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (8 << 30)
+    tmp = tempfile.mkdtemp(prefix="psvr_bench_r%d_" % rank, dir="/dev/shm" if shm_ok else None)
     anc = bench_data.make_anchors(args.anchors, seed=11)
     ix_arrays = bench_data.build_index_cli(anc, dense=True)      # `panSVR index`: byte-identical to the reference builder's files
+    bases, base_off, ori, isize = bench_data.make_reads(anc, args.pairs, seed=13 + rank)     # block `rank` of the input
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_aln")    # the reference's own aligner objects (oracle/Makefile)
+    have_ref = os.path.exists(ref_exe) and not args.no_ref_cpu and shm_ok     # its loader reads the dense 2 GiB table: RAM-backed tmp only
+    n_cpu = min(args.cpu_pairs, args.pairs) if rank == 0 else 0
+    n_chk = min(args.check_pairs, args.pairs)
+    n_e2e = args.pairs if (rank == 0 and world == 1 and not args.no_e2e) else 0
+    n_fq = max(n_cpu, n_chk, n_e2e)
+    fq = os.path.join(tmp, "block.fq")
+    ncore = os.cpu_count() or 1
+    if n_fq:
+        # (forked formatting workers only in the single-process case, where nothing has touched the GPU yet)
+        bench_data.write_fastq(fq, bases, base_off, ori, isize, n_pairs=n_fq, procs=min(16, ncore) if world == 1 else 1)
+    with open(os.path.join(tmp, "header.sam"), "w") as f:
+        f.write(HEADER)
+    ix_small = {k: v for k, v in ix_arrays.items() if k != "hash"}
+    # one index directory per node in RAM-backed storage: the sparse form for `panSVR aln` / aln_oracle, the dense table for ref_aln
+    idx_dir = os.path.join("/dev/shm" if shm_ok else tempfile.gettempdir(), "psvr_bench_idx_%d" % os.getppid()) if world > 1 else os.path.join(tmp, "idx")
+    if local_rank == 0 or world == 1:
+        bench_data.write_index_dir(ix_small, idx_dir, dense_hash=ix_arrays["hash"] if have_ref else None)
+    t_host = time.time() - t_setup
+
+    torch.cuda.set_device(local_rank)
+    xdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else None
+    t_up = time.time()
     index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
-    ix_sparse, ix_small = ix_arrays["hash_sparse"], {k: v for k, v in ix_arrays.items() if k != "hash"}
-    ix_hash = ix_arrays["hash"] if rank == 0 and args.cpu_pairs > 0 else None
+    t_index_upload = time.time() - t_up
+    index_bytes = int(sum(v.nbytes for k, v in ix_arrays.items() if hasattr(v, "nbytes") and k != "hash_sparse"))
     del ix_arrays
-    bases, base_off, ori, isize = bench_data.make_reads(anc, args.pairs, seed=13 + rank)
+    index_bcast = None
+    if world > 1 and xdev:
+        # SURVEY 8(e) asks for both: every rank uploads its own copy over PCIe (above) vs one RCCL broadcast of the same bytes over xGMI
+        try:
+            buf = torch.empty(index_bytes, dtype=torch.uint8, device="cuda")
+            dist.barrier(); torch.cuda.synchronize()
+            tb = time.time()
+            dist.broadcast(buf, src=0)
+            torch.cuda.synchronize()
+            index_bcast = round((time.time() - tb) * 1e3, 2)
+            del buf
+        except Exception as ex:      # the measurement is optional
+            index_bcast = "failed: %r" % (ex,)
     eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
     eng.upload(bases, base_off, ori)
     t_setup = time.time() - t_setup
@@ -91,8 +140,10 @@ def main():
     from pansvr_amd import dist as pdist
 
     exchange_iters = []
+    my_start = [2, 0, 0]
 
     def step():
+        nonlocal my_start
         if world == 1:
             eng.run()
             return
@@ -106,7 +157,7 @@ def main():
             eng.rebase(pos)
             return eng.stream_end()
 
-        _, _, it = pdist.resolve_stream_order([2, 0, 0], run_at, rebase_to, device=xdev)
+        my_start, _, it = pdist.resolve_stream_order([2, 0, 0], run_at, rebase_to, device=xdev)
         exchange_iters.append(it)
 
     for _ in range(args.warmup):
@@ -124,6 +175,38 @@ def main():
     reads_per_step = 2 * args.pairs * world
     value = reads_per_step * args.steps / dt
 
+    # ---- every rank's block against the reference objects, started where the block starts in the draw streams (checker only)
+    parity_local = None
+    if n_chk > 0 and (have_ref or os.path.exists(os.path.join(ROOT, "oracle", "aln_oracle"))):
+        import aln_common as ac
+        reads_o, pairs_o, cig_o = eng.download()
+        lens = np.diff(base_off)
+        got = ac.engine_records(reads_o, pairs_o, cig_o, ori, lens, 0, n_chk)
+        del reads_o, pairs_o, cig_o
+        base = [idx_dir, fq, os.path.join(tmp, "header.sam")]
+        if have_ref:
+            cmd = [ref_exe, "-t", "1", "-R", str(n_chk)] + base + ["--quiet", "--stream-pos", ",".join(str(x) for x in my_start)]
+            against = "oracle/_ref/ref_aln (reference objects)"
+        else:
+            cmd = [os.path.join(ROOT, "oracle", "aln_oracle")] + base + ["--limit", str(n_chk)]
+            against = "oracle/aln_oracle"
+            if world > 1 and rank > 0:
+                cmd = None           # the port has no --stream-pos: only rank 0's block can be replayed
+        if cmd:
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+            want = [json.loads(l) for l in out.split("\n") if l.lstrip().startswith("{")][:n_chk]
+            for i, w in enumerate(want):
+                w["i"] = i
+            parity_local = [n_chk, sum(1 for i in range(n_chk) if got[i] != want[i]), against]
+    parity = None
+    if world > 1:
+        cnt = pdist.all_gather_i64([parity_local[0] if parity_local else 0, parity_local[1] if parity_local else 0], xdev)
+        if rank == 0:
+            parity = {"pairs_checked": sum(c[0] for c in cnt), "pairs_differing": sum(c[1] for c in cnt), "ranks_checked": sum(1 for c in cnt if c[0]),
+                      "against": parity_local[2] if parity_local else None, "per_rank": cnt}
+    elif parity_local:
+        parity = {"pairs_checked": parity_local[0], "pairs_differing": parity_local[1], "ranks_checked": 1, "against": parity_local[2]}
+
     # two extra passes (not timed above): per-kernel HIP-event durations on the launch stream, then the work
     # counters (their atomics would distort the timings)
     eng.run(timing=True)
@@ -132,79 +215,63 @@ def main():
     st = eng.stats()
     dom = max(kern, key=lambda k: kern[k]["ms"])
     # the boundary hands over host buffers: one extra, separately reported pass incl. H2D of the batch and D2H of the results
+    # (compact form: headers + the candidates / CIGAR words that exist), first from pageable memory ...
     torch.cuda.synchronize()
     tp = time.time()
     eng.upload(bases, base_off, ori)
     eng.set_stream_pos([2, 0, 0])      # a new upload continues the reference's rand() streams; this is the same first batch again
     eng.run()
-    out_host = eng.download()
+    out_host = eng.download_compact()
     tp = time.time() - tp
     pcie = {"reads_per_s": round(2 * args.pairs / tp, 1), "ms": round(tp * 1e3, 2),
             "h2d_bytes": int(bases.nbytes + base_off.nbytes + ori.nbytes), "d2h_bytes": int(sum(a.nbytes for a in out_host)),
-            "note": "upload (pageable host memory) + run + download of one batch through psvr_engine_upload/run/download; not `value`"}
+            "note": "upload + run + compact download (psvr_engine_download_compact) of one batch through the C ABI from pageable host memory; not `value`"}
     del out_host
-    # the same with result buffers a pipeline slot keeps page-locked across batches (psvr_host_alloc; allocated before the clock starts)
+    # ... then with buffers a pipeline slot keeps page-locked across batches (psvr_host_alloc; allocated before the clock starts), inputs included
     hb = aln.HostBuffers()
-    eng.download_into(hb)
+    eng.download_compact(hb)
+    pin_in = aln.HostBuffers()
+    pb, po, pr = pin_in.input_views(bases, base_off, ori)
     torch.cuda.synchronize()
     tp = time.time()
-    eng.upload(bases, base_off, ori)
+    eng.upload(pb, po, pr)
     eng.set_stream_pos([2, 0, 0])
     eng.run()
-    eng.download_into(hb)
+    eng.download_compact(hb)
     tp = time.time() - tp
-    pcie["page_locked_results"] = {"reads_per_s": round(2 * args.pairs / tp, 1), "ms": round(tp * 1e3, 2)}
-    hb.close()
-    roofline, cpu, parity = None, None, None
+    pcie["page_locked"] = {"reads_per_s": round(2 * args.pairs / tp, 1), "ms": round(tp * 1e3, 2)}
+    hb.close(), pin_in.close()
+
+    roofline, cpu, e2e = None, None, None
     if rank == 0:
-        # algorithmic bytes per read, counted by the oracle on the CPU sample below
-        shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (6 << 30)
-        tmp = tempfile.mkdtemp(prefix="psvr_bench_", dir="/dev/shm" if shm_ok else None)
-        n_cpu = min(args.cpu_pairs, args.pairs)
         bytes_per_read, seed_bytes_per_read = None, None
+        base = [idx_dir, fq, os.path.join(tmp, "header.sam")]
         if n_cpu > 0:
-            ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_aln")      # the reference's own aligner objects (oracle/Makefile)
-            have_ref = os.path.exists(ref_exe) and not args.no_ref_cpu and shm_ok     # its loader reads the dense 2 GiB table: RAM-backed tmp only
-            ix_small["hash_sparse"] = ix_sparse
-            bench_data.write_index_dir(ix_small, os.path.join(tmp, "idx"), dense_hash=ix_hash if have_ref else None)
-            bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, n_pairs=n_cpu)
-            with open(os.path.join(tmp, "header.sam"), "w") as f:
-                f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")
-            base = [os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam")]
-
-            def timed(cmd, out_path):
-                # the executables report the wall of their per-pair loop on stderr (index load excluded)
-                with open(out_path, "w") as fo:
-                    err = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, check=True).stderr.decode()
-                return max(float([l for l in err.split("\n") if l.startswith("ALIGN_SECONDS")][-1].split()[1]), 1e-9)
-
+            # algorithmic bytes per read, counted by the oracle on a part of the CPU sample; the executables report the
+            # wall of their per-pair loop on stderr (index load excluded)
+            n_port = min(n_cpu, 60000)
             exe = os.path.join(ROOT, "oracle", "aln_oracle")
-            tc = timed([exe] + base + ["--stats", "--print"], os.path.join(tmp, "port.jsonl"))
-            port_lines = open(os.path.join(tmp, "port.jsonl")).read().strip().split("\n")
-            cs = json.loads(port_lines[-1])
-            bytes_per_read = cs["bytes"]["total"] / (2.0 * n_cpu)
-            seed_bytes_per_read = (cs["bytes"]["probe"] + cs["bytes"]["hit"] + cs["bytes"]["read"]) / (2.0 * n_cpu)
-            port_rate = round(2 * n_cpu / tc, 1)
+            r = subprocess.run([exe] + base + ["--stats", "--limit", str(n_port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+            cs = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
+            bytes_per_read = cs["bytes"]["total"] / (2.0 * n_port)
+            seed_bytes_per_read = (cs["bytes"]["probe"] + cs["bytes"]["hit"] + cs["bytes"]["read"]) / (2.0 * n_port)
+            port_rate = round(2 * n_port / align_seconds(r.stderr.decode()), 1)
             cpu = {"value": port_rate, "unit": "reads/s", "cores": 1, "kind": "port",
-                   "sample": "first %d pairs of the same workload, oracle/aln_oracle (scalar C++ restatement, -t 1 equivalent), index load excluded" % n_cpu}
-            want = [json.loads(l) for l in port_lines[:-1] if l.startswith("{")][:n_cpu]
-            against = "oracle/aln_oracle"
+                   "sample": "first %d pairs of the same workload, oracle/aln_oracle (scalar C++ restatement, -t 1 equivalent), index load excluded" % n_port}
             if have_ref:
-                tr = timed([ref_exe] + base, os.path.join(tmp, "ref.jsonl"))
-                cpu = {"value": round(2 * n_cpu / tr, 1), "unit": "reads/s", "cores": 1, "kind": "reference", "port_value": port_rate,
-                       "sample": "first %d pairs of the same workload through the reference's own aligner objects (oracle/_ref/ref_aln: read_realignment/deBGA_index/"
-                                 "graph/ksw2_extd2_sse compiled from the reference tree, -t 1 code path, no BAM encode), index load excluded; port_value = oracle/aln_oracle on the same sample" % n_cpu}
-                want = [json.loads(l) for l in open(os.path.join(tmp, "ref.jsonl")) if l.lstrip().startswith("{")][:n_cpu]
-                against = "oracle/_ref/ref_aln (reference objects)"
-            # the batch just timed, checked against the CPU run on that sample (checker only; nothing here is timed)
-            import aln_common as ac
-            n_chk = min(n_cpu, args.check_pairs)
-            reads_o, pairs_o, cig_o = eng.download()
-            lens = np.diff(base_off)
-            got = ac.engine_records(reads_o, pairs_o, cig_o, ori, lens, 0, n_chk)
-            differ = sum(1 for i in range(n_chk) if got[i] != want[i])
-            parity = {"pairs_checked": n_chk, "pairs_differing": differ, "against": against}
-            shutil.rmtree(tmp, ignore_errors=True)
+                nt = args.cpu_threads or min(48, ncore)
+                r1 = subprocess.run([ref_exe, "-t", "1", "-S", "-o", os.path.join(tmp, "r1.sam"), "-p", os.path.join(tmp, "r1o.sam"), "-R", str(n_cpu)] + base + ["--quiet"],
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.decode()
+                rn = subprocess.run([ref_exe, "-t", str(nt), "-S", "-o", os.path.join(tmp, "rn.sam"), "-p", os.path.join(tmp, "rno.sam"), "-R", str(n_cpu)] + base + ["--quiet"],
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True).stderr.decode()
+                cpu = {"value": round(2 * n_cpu / align_seconds(rn), 1), "unit": "reads/s", "cores": nt, "kind": "reference",
+                       "value_1_thread": round(2 * n_cpu / align_seconds(r1), 1),
+                       "whole_command": {"reads_per_s_%d_threads" % nt: round(2 * n_cpu / align_seconds(rn, "TOTAL_SECONDS"), 1), "reads_per_s_1_thread": round(2 * n_cpu / align_seconds(r1, "TOTAL_SECONDS"), 1),
+                                         "note": "load_reads (kseq) + kt_for + sam_format1 text of both files, index load excluded"},
+                       "port_value": port_rate, "host_cores": ncore,
+                       "sample": "first %d pairs of the same workload through the reference's own fc_aln objects (oracle/_ref/ref_aln: read_realignment / deBGA_index / graph / "
+                                 "ksw2_extd2_sse / htslib sam_parse1, compiled from the reference tree): `value` = the reference's kt_for over align_read_pair (incl. output_BAM) at -t %d, "
+                                 "value_1_thread the same at -t 1; port_value = oracle/aln_oracle on %d pairs" % (n_cpu, nt, n_port)}
         launches = max(1, kern[dom]["launches"])
         avg_ms = kern[dom]["ms"] / launches
         share = {"k_seed": seed_bytes_per_read}.get(dom, bytes_per_read)
@@ -213,8 +280,8 @@ def main():
         traffic = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            want = dom.replace(",hbm>", ", true>").replace(",lds>", ", false>")
-            kd = pj["kernels"].get(want) or next((v for k, v in pj["kernels"].items() if k.split("<")[0] == want), None)
+            want_k = dom.replace(",hbm>", ", true>").replace(",lds>", ", false>")
+            kd = pj["kernels"].get(want_k) or next((v for k, v in pj["kernels"].items() if k.split("<")[0] == want_k), None)
             if kd and pj.get("pairs_per_gpu") == args.pairs:
                 traffic = int((kd["fetch_KiB_per_step"] + kd["write_KiB_per_step"]) * 1024)
         except Exception:
@@ -223,25 +290,48 @@ def main():
             # first launch of the dominant kernel covers all 2P reads of the batch; later (speculative) launches cover few
             alg_bytes = share * 2 * args.pairs
             achieved = alg_bytes / (kern[dom]["ms"] * 1e-3) / 1e9
+            step_ms = dt / args.steps * 1e3
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
-                        "traffic": traffic, "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (KiB*1024) per step from profiles/pmc_latest.json; gfx950 FETCH_SIZE under-reports coalesced reads by up to 2x", "alg_bytes_per_read": round(share, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
-                        "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4)}
+                        "traffic": traffic, "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (KiB*1024) per step from profiles/pmc_latest.json (rocprofv3 --pmc passes of this command, committed); gfx950 FETCH_SIZE under-reports coalesced reads by up to 2x", "alg_bytes_per_read": round(share, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
+                        "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
+                        "whole_step": {"achieved": round(bytes_per_read * 2 * args.pairs / (step_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                       "note": "the whole path's algorithmic bytes over the whole step (per GPU), for scale: the step is latency / issue bound"}}
+        # ---- the drop-in command end to end: FASTQ file in, both record files out (index load reported separately)
+        if n_e2e:
+            cli = os.path.join(ROOT, "pansvr_amd", "bin", "panSVR")
+            nt = min(16, ncore)
+            e2e = {"pairs": n_e2e, "threads": nt, "input": "FASTQ of the bench batch in RAM-backed storage (%.2f GB)" % (os.path.getsize(fq) / 1e9)}
+            for mode, ext in ((["-S"], "sam"), ([], "bam")):
+                r = subprocess.run([cli, "aln", "-t", str(nt)] + mode + ["-o", os.path.join(tmp, "o." + ext), "-p", os.path.join(tmp, "p." + ext)] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                if r.returncode != 0:
+                    e2e[ext] = {"error": r.stderr.decode()[-300:]}
+                    continue
+                j = json.loads([l for l in r.stderr.decode().split("\n") if "e2e_json" in l][-1].split("e2e_json ", 1)[1])
+                e2e[ext] = {"reads_per_s": round(2 * n_e2e / j["wall_s"], 1), "wall_s": j["wall_s"], "index_load_s": j["index_s"], "read_parse_s": j["read_parse_s"], "engine_s": j["engine_s"],
+                            "format_s": j["format_s"], "write_s": j["write_s"], "batches": j["batches"], "d2h_bytes": j["d2h_bytes"], "out_bytes": os.path.getsize(os.path.join(tmp, "o." + ext))}
+            e2e["note"] = "wall_s = first FASTQ byte to both files closed (three overlapped stages); index_load_s (files -> HBM) is outside it"
     if rank == 0:
         line = {"metric": "signal reads realigned/sec (150 bp PE); bit-exact CIGAR vs CPU ref", "value": round(value, 1), "unit": "reads/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (2-bit k-mers, 8-bit DP deltas, 32-bit scores)",
                 "data": "synthetic", "config": {"workload": "configs[1]: %d synthetic 150 bp PE signal read pairs per GPU vs %d-anchor SV reference (%.1f Mbp), `panSVR aln` hot path"
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
-                                                 "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step, "parallelism": "shard%d (index replicated, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank, %d iteration(s)/step" % (max(exchange_iters) if exchange_iters else 0)),
-                                                 "index_hbm_bytes": index.device_bytes, "setup_s": round(t_setup, 1)},
-                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "pcie_inclusive": pcie,
-                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells")},
+                                                 "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step,
+                                                 "parallelism": "shard%d (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank over %s, %d iteration(s)/step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
+                                                 "index_hbm_bytes": index.device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
+                                                 "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie,
+                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)
     eng.close()
     index.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    shutil.rmtree(tmp, ignore_errors=True)
+    if world > 1 and local_rank == 0:
+        shutil.rmtree(idx_dir, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -16,6 +16,9 @@
 // htslib functions nothing here reaches.  No stand-in header or library is involved.
 //
 // Usage: ref_aln [fc_aln options] <IndexDir> <reads.fq> <header.sam> [--records FILE|-] [--trace] [--limit N] [--batch N] [--quiet]
+//                [--stream-pos G,H0,H1]
+//   --stream-pos       : (-t 1) the input is the continuation of a longer run: before the first pair, rand() is called until G draws
+//                        have been made in total and handler k's random_r until Hk -- where a shard of a sharded run stands
 //   -S -o FILE -p FILE : SAM text of the two output files (without -S nothing is formatted; BAM needs htslib's bgzf/hfile layer)
 //   --records          : one JSON line per pair with what align_read_pair decided (default: stdout when no -S is given)
 //   -t N               : the reference's own kt_for over N threads (timing only: output is non-deterministic for N > 1)
@@ -115,6 +118,7 @@ int main(int argc, char **argv)
 	const char *records = NULL;
 	bool trace = false, quiet = false;
 	long limit = -1, batch = 200000;
+	long long spos[3] = {-1, -1, -1};
 	av.push_back(argv[0]);
 	av.push_back((char *)"fc_aln");                        // get_option is entered with argv pointing behind the sub-command (main.cpp:18-25)
 	for (int a = 1; a < argc; ++a) {
@@ -123,6 +127,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[a], "--limit") && a + 1 < argc) limit = atol(argv[++a]);
 		else if (!strcmp(argv[a], "--batch") && a + 1 < argc) batch = atol(argv[++a]);
 		else if (!strcmp(argv[a], "--records") && a + 1 < argc) records = argv[++a];
+		else if (!strcmp(argv[a], "--stream-pos") && a + 1 < argc) sscanf(argv[++a], "%lld,%lld,%lld", &spos[0], &spos[1], &spos[2]);
 		else av.push_back(argv[a]);
 	}
 	av.push_back(NULL);
@@ -153,6 +158,11 @@ int main(int argc, char **argv)
 		buff[i].ps.init(o->ISIZE_MAX, o->ISIZE_MIN, o->normal_read_length, 0);
 		buff[i].SE_h[0].init(o, idx);
 		buff[i].SE_h[1].init(o, idx);
+	}
+	if (spos[0] >= 0 && nt == 1) {                           // the two init() calls above made draws #0 and #1 of rand()
+		for (long long k = 2; k < spos[0]; ++k) (void)rand();
+		int32_t tmp;
+		for (int h = 0; h < 2; ++h) for (long long k = 0; k < spos[1 + h]; ++k) random_r(&buff[0].SE_h[h].rand_buff, &tmp);
 	}
 	Batch B;
 	B.seqs1 = (kseq_t *)xcalloc(batch, sizeof(kseq_t)), B.seqs2 = (kseq_t *)xcalloc(batch, sizeof(kseq_t));

@@ -158,8 +158,8 @@ class HostBuffers:
     """Page-locked result buffers from psvr_host_alloc, kept across batches (what a pipeline slot of the reference would own)."""
 
     def __init__(self):
-        self._p = [None, None, None, None]
-        self._cap = [0, 0, 0, 0]
+        self._p = [None] * 7
+        self._cap = [0] * 7
 
     def _get(self, i, nbytes):
         if nbytes > self._cap[i]:
@@ -189,8 +189,16 @@ class HostBuffers:
         cig = np.frombuffer(self._get(2, n_cig * 4), dtype=np.uint32)
         return hdr, pairs, cands, cig
 
+    def input_views(self, bases, base_off, ori):
+        """Page-locked copies of a batch's input arrays (what a pipeline slot would parse its reads into)."""
+        b = np.frombuffer(self._get(4, max(1, bases.nbytes)), dtype=np.uint8)[:len(bases)]
+        o = np.frombuffer(self._get(5, base_off.nbytes), dtype=np.int64)
+        r = np.frombuffer(self._get(6, max(1, ori.nbytes)), dtype=ORI_DTYPE)[:len(ori)]
+        b[:], o[:], r[:] = bases, base_off, ori
+        return b, o, r
+
     def close(self):
-        for i in range(4):
+        for i in range(7):
             if self._p[i]:
                 lib().psvr_host_free.argtypes = [C.c_void_p]
                 lib().psvr_host_free(self._p[i])

@@ -173,20 +173,44 @@ def make_reads(anc, n_pairs, seed=13, L=150, frag=(300, 500), maxindel=8, miss_f
     return asc.reshape(-1), base_off, ori, flen
 
 
-def write_fastq(path, bases, base_off, ori, isize, stat=(150, 200, 400, 600), n_pairs=None):
-    """FASTQ with the fc_signal comment (tests/synth.py format) for the first n_pairs pairs."""
-    P = (len(base_off) - 1) // 2 if n_pairs is None else n_pairs
+def _fastq_chunk(args):
+    path, bases, base_off, ori, isize, stat, p0, p1, name_base = args
+    out = []
+    for p in range(p0, p1):
+        for k in range(2):
+            r = 2 * p + k
+            o = ori[r]
+            fw = bool(o["direction"])
+            mate = ori[2 * p + 1 - k]
+            flag = (0x40 if k == 0 else 0x80) | 0x1 | (0 if fw else 0x10) | (0x20 if fw else 0)
+            c = "%d_%d_%d_%d_20_20_0_0_%d_%sNNY_%sNNY_" % (o["chr_id"], o["ref_bg"], o["read_bg"], o["align_score"], isize[p], "F" if fw else "R", "R" if fw else "F")
+            if p == 0 and k == 0 and stat is not None:
+                c += "STAT_%d_%d_%d_%d_" % stat
+            c += "FLAG_%d_20_CIGAR_40S110M_MATE_0_%d_%d_TAG_NM:i:3_" % (flag, mate["ref_bg"], isize[p] if fw else -isize[p])
+            s = bases[base_off[r]:base_off[r + 1]].tobytes().decode()
+            out.append("@r%07d %s\n%s\n+\n%s\n" % (name_base + p, c, s, "I" * len(s)))
     with open(path, "w") as f:
-        for p in range(P):
-            for k in range(2):
-                r = 2 * p + k
-                o = ori[r]
-                fw = bool(o["direction"])
-                mate = ori[2 * p + 1 - k]
-                flag = (0x40 if k == 0 else 0x80) | 0x1 | (0 if fw else 0x10) | (0x20 if fw else 0)
-                c = "%d_%d_%d_%d_20_20_0_0_%d_%sNNY_%sNNY_" % (o["chr_id"], o["ref_bg"], o["read_bg"], o["align_score"], isize[p], "F" if fw else "R", "R" if fw else "F")
-                if p == 0 and k == 0 and stat is not None:
-                    c += "STAT_%d_%d_%d_%d_" % stat
-                c += "FLAG_%d_20_CIGAR_40S110M_MATE_0_%d_%d_TAG_NM:i:3_" % (flag, mate["ref_bg"], isize[p] if fw else -isize[p])
-                s = bases[base_off[r]:base_off[r + 1]].tobytes().decode()
-                f.write("@r%07d %s\n%s\n+\n%s\n" % (p, c, s, "I" * len(s)))
+        f.write("".join(out))
+    return path
+
+
+def write_fastq(path, bases, base_off, ori, isize, stat=(150, 200, 400, 600), n_pairs=None, procs=1, name_base=0, append=False):
+    """FASTQ with the fc_signal comment (tests/synth.py format) for the first n_pairs pairs.  procs > 1: chunks are formatted by forked
+    worker processes (call this BEFORE the process touches the GPU); append: add to an existing file (a multi-part input)."""
+    import os
+    import shutil
+    P = (len(base_off) - 1) // 2 if n_pairs is None else n_pairs
+    nchunk = max(1, min(procs, P // 20000 + 1))
+    bounds = [P * i // nchunk for i in range(nchunk + 1)]
+    jobs = [(path + ".part%d" % i, bases, base_off, ori, isize, stat, bounds[i], bounds[i + 1], name_base) for i in range(nchunk)]
+    if nchunk > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nchunk) as pool:
+            parts = pool.map(_fastq_chunk, jobs)
+    else:
+        parts = [_fastq_chunk(jobs[0])]
+    with open(path, "ab" if append else "wb") as f:
+        for q in parts:
+            with open(q, "rb") as g:
+                shutil.copyfileobj(g, f, 1 << 24)
+            os.remove(q)
