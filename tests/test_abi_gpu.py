@@ -124,5 +124,8 @@ def test_index_clone_is_an_index():
         eng.run()
         outs.append(eng.download())
         eng.close()
-    assert all(a.tobytes() == b.tobytes() for a, b in zip(*outs))
+    lens = np.diff(base_off)
+    P = (len(base_off) - 1) // 2
+    a, b = (ac.engine_records(r, p, c, ori, lens, 0, P) for r, p, c in outs)      # (arena positions differ from run to run: compare what they point at)
+    assert a == b and outs[0][1].tobytes() == outs[1][1].tobytes()
     clone.close(), index.close()
