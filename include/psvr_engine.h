@@ -156,6 +156,26 @@ const char *psvr_index_sv_print_string(const psvr_index_t *idx, int32_t sv_id);
 const char *psvr_index_sv_vcf_id(const psvr_index_t *idx, int32_t sv_id);
 
 /* ------------------------------------------------------------------------------------------
+ * Seam B3: the two index look-ups of the seed loop, batched (src/PanSVgenerateVCF/deBGA_index.hpp:198-201; north-star copy
+ * src/deBGA_index.hpp:205-208).  The engine runs the same device functions inside its seeding kernel; these entry points
+ * expose them on their own (host buffers in, host buffers out) so the seeding stage can be bound or tested separately.
+ * ------------------------------------------------------------------------------------------ */
+/* bool deBGA_INDEX::search_kmer(20, kmer, range, 2) for n 20-mers (40 significant bits each): found[i], and when found the
+ * inclusive index range range[2i] .. range[2i+1] of the 22-mers of unipath_g.kmer / unipath_g.offset that start with it */
+int psvr_seed_search_kmer_batch(const psvr_index_t *idx, int64_t n, const uint64_t *kmers, int64_t *range, uint8_t *found);
+typedef struct psvr_vertex_mem {            /* vertex_MEM, deBGA_index.hpp:24-58 (+ the right_i the reference returns through max_right_i) */
+	uint64_t uid;
+	uint32_t seed_id;                       /* position in the caller's vector in the reference: always 0 here */
+	uint32_t read_pos, uni_pos_off, length, pos_n;
+	uint32_t right_i;
+} psvr_vertex_mem_t;
+/* int deBGA_INDEX::UNITIG_MEM_search(kmer_index, ..., read_bit, read_off, read_length, 20, max_right_i) for n items: item i extends
+ * index entry kmer_index[i] inside its unipath against the 2-bit packed read (32 bases per word, MSB first) that starts at
+ * read_bits[word_off[i]]; every read needs ceil(len / 32) + 1 words (the reference's read_bit arrays are padded the same way) */
+int psvr_seed_mem_batch(const psvr_index_t *idx, int64_t n, const uint64_t *kmer_index, const uint64_t *read_bits, int64_t n_words,
+                        const int64_t *word_off, const uint32_t *read_off, const uint32_t *read_len, psvr_vertex_mem_t *out);
+
+/* ------------------------------------------------------------------------------------------
  * Seam B1: one batch of read pairs through seeding -> chaining -> extension DP -> pairing.
  * Replaces kt_for(worker_for -> align_read_pair) minus the SAM text formatting
  * (src/PanSVgenerateVCF/read_realignment.cpp:114,154-161,745-775; legacy src/jlra_aln.cpp:115,140-147).

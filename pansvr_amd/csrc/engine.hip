@@ -1135,6 +1135,71 @@ extern "C" const char *psvr_index_sv_vcf_id(const psvr_index_t *ix, int32_t sv)
 }
 
 // ------------------------------------------------------------------------------------------------
+// seam B3: the seed loop's two look-ups on their own (the device functions are the ones k_seed runs)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_b3_search_kmer(DevIndex ix, long long n, const uint64_t *kmers, long long *range, uint8_t *found)
+{
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t kmer = kmers[i] & 0xffffffffffull;
+	uint64_t first = 0;
+	const uint32_t nh = bucket_occupied(ix, kmer >> 12) ? probe_kmer(ix, kmer, first) : 0;
+	found[i] = nh != 0;
+	range[2 * i] = nh ? (long long)first : 0, range[2 * i + 1] = nh ? (long long)(first + nh - 1) : -1;
+}
+__global__ __launch_bounds__(kBlock) void k_b3_mem(DevIndex ix, long long n, const uint64_t *kmer_index, const uint64_t *read_bits, const long long *word_off, const uint32_t *read_off,
+                                                   const uint32_t *read_len, psvr_vertex_mem_t *out)
+{
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	VMem m;
+	const uint32_t ri = mem_for_hit(ix, kmer_index[i], read_bits + word_off[i], read_off[i], (int)read_len[i], m);
+	psvr_vertex_mem_t &o = out[i];
+	o.uid = m.uid, o.seed_id = 0, o.read_pos = m.read_pos, o.uni_pos_off = m.uni_pos_off, o.length = m.length, o.pos_n = m.pos_n, o.right_i = ri;
+}
+
+extern "C" int psvr_seed_search_kmer_batch(const psvr_index_t *ix, int64_t n, const uint64_t *kmers, int64_t *range, uint8_t *found)
+{
+	if (!ix || n < 0 || (n && (!kmers || !range || !found))) return set_error(PSVR_ERR_ARG, "psvr_seed_search_kmer_batch: bad argument");
+	if (n == 0) return PSVR_OK;
+	PSVR_HIP(hipSetDevice(ix->device));
+	DevBuf dk, dr, df;
+	PSVR_HIP(dk.alloc((size_t)n * 8)); PSVR_HIP(dr.alloc((size_t)n * 16)); PSVR_HIP(df.alloc((size_t)n));
+	PSVR_HIP(hipMemcpy(dk.p, kmers, (size_t)n * 8, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_b3_search_kmer, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, ix->dev, (long long)n, dk.as<uint64_t>(), dr.as<long long>(), df.as<uint8_t>());
+	PSVR_HIP(hipGetLastError());
+	PSVR_HIP(hipMemcpy(range, dr.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+	PSVR_HIP(hipMemcpy(found, df.p, (size_t)n, hipMemcpyDeviceToHost));
+	return PSVR_OK;
+}
+
+extern "C" int psvr_seed_mem_batch(const psvr_index_t *ix, int64_t n, const uint64_t *kmer_index, const uint64_t *read_bits, int64_t n_words, const int64_t *word_off,
+                                   const uint32_t *read_off, const uint32_t *read_len, psvr_vertex_mem_t *out)
+{
+	if (!ix || n < 0 || n_words < 0 || (n && (!kmer_index || !read_bits || !word_off || !read_off || !read_len || !out))) return set_error(PSVR_ERR_ARG, "psvr_seed_mem_batch: bad argument");
+	if (n == 0) return PSVR_OK;
+	const uint64_t n_index = ix->off.bytes / 8;
+	for (int64_t i = 0; i < n; ++i) {                      // the kernel indexes with these: check them here, on the host
+		const int64_t words = ((int64_t)read_len[i] + 31) / 32 + 1;
+		if (kmer_index[i] >= n_index || word_off[i] < 0 || word_off[i] + words > n_words || read_len[i] < (uint32_t)kLenKmer || read_off[i] + (uint32_t)kLenKmer > read_len[i])
+			return set_error(PSVR_ERR_ARG, "psvr_seed_mem_batch: item %lld is out of range (index entry, word window or read offset)", (long long)i);
+	}
+	PSVR_HIP(hipSetDevice(ix->device));
+	DevBuf dk, db, dw, dro, drl, dout;
+	PSVR_HIP(dk.alloc((size_t)n * 8)); PSVR_HIP(db.alloc((size_t)(n_words + 2) * 8)); PSVR_HIP(dw.alloc((size_t)n * 8)); PSVR_HIP(dro.alloc((size_t)n * 4)); PSVR_HIP(drl.alloc((size_t)n * 4));
+	PSVR_HIP(dout.alloc((size_t)n * sizeof(psvr_vertex_mem_t)));
+	PSVR_HIP(hipMemset((char *)db.p + (size_t)n_words * 8, 0, 16));
+	PSVR_HIP(hipMemcpy(dk.p, kmer_index, (size_t)n * 8, hipMemcpyHostToDevice)); PSVR_HIP(hipMemcpy(db.p, read_bits, (size_t)n_words * 8, hipMemcpyHostToDevice));
+	PSVR_HIP(hipMemcpy(dw.p, word_off, (size_t)n * 8, hipMemcpyHostToDevice)); PSVR_HIP(hipMemcpy(dro.p, read_off, (size_t)n * 4, hipMemcpyHostToDevice));
+	PSVR_HIP(hipMemcpy(drl.p, read_len, (size_t)n * 4, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_b3_mem, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, ix->dev, (long long)n, dk.as<uint64_t>(), db.as<uint64_t>(), dw.as<long long>(), dro.as<uint32_t>(), drl.as<uint32_t>(),
+	                   dout.as<psvr_vertex_mem_t>());
+	PSVR_HIP(hipGetLastError());
+	PSVR_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(psvr_vertex_mem_t), hipMemcpyDeviceToHost));
+	return PSVR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------------
 struct psvr_engine {
