@@ -19,6 +19,10 @@ DATASETS = {
                                       heavy_n_frac=0.03, stat=(150, 300, 500, 800)),
                        "repeat": dict(n_pairs=300, seed=41, L=150, frag=(300, 420), center_frac=0.9, miss_frac=0.05),
                        "lower": dict(n_pairs=300, seed=43, L=150, frag=(520, 560), lower_frac=0.5, stat=(150, 300, 500, 800))}),
+    # configs[4] shape: edge-2000 anchors with alleles up to 2 kbp, 250 bp reads, indels up to 40 -- the wide DP problems
+    # (extensions of q <= 250 against t = q + 30, 529 anti-diagonals) pinned against the reference objects
+    "fx4": dict(anchors=dict(n_anchors=60, seed=51, edge=2000, allele=(60, 2000)),
+                reads={"reads250": dict(n_pairs=2000, seed=53, L=250, frag=(400, 700), maxindel=40, n_frac=0.01, stat=(250, 300, 550, 800))}),
 }
 
 

@@ -138,6 +138,19 @@ def fixed_cases(seed=20241008):
             q = rand_seq(rng, ql)
             t = (mutate(rng, q, 0.05, 0.03, 0.03, 20) + rand_seq(rng, 40))[: max(1, ql + rng.randint(-8, 40))]
             cs.append(case(q, t, **pr))
+    # 10. the second user of ksw_extd2_sse, fc_sv's contig re-alignment (SignalAssembly.hpp:418-420,463): match 2 / mismatch 10,
+    #     gaps 24+2k | 32+1k, bandwidth = zdrop = gap_open2 + 100 = 132, contig-length queries against an anchor region
+    sv = dict(match=2, mismatch=10, q=24, e=2, q2=32, e2=1, w=132, zdrop=132)
+    for ql, tl in [(300, 350), (600, 640), (1000, 1100), (1500, 1500), (2000, 2100), (3000, 3100), (1000, 1300), (2500, 2400)]:
+        t = rand_seq(rng, tl)
+        base = t[: min(ql, tl)]
+        q = mutate(rng, base, 0.01, 0.003, 0.003, 12)
+        cs.append(case((q + rand_seq(rng, ql))[:ql], t, **sv))
+        k = len(base) // 2                                               # an SV-sized event in the middle of the contig
+        g = 40 + rng.randint(80)
+        cs.append(case((base[:k] + rand_seq(rng, g) + base[k:])[:ql], t, **sv))      # insertion allele
+        cs.append(case((base[:k] + base[k + g:] + rand_seq(rng, ql))[:ql], t, **sv))  # deletion allele
+    cs.append(case(rand_seq(rng, 800), rand_seq(rng, 900), **sv))            # unrelated: z-drop at 132
     return cs
 
 
