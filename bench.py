@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--check-pairs", type=int, default=50000, help="pairs per rank whose engine records are compared with the reference objects")
     ap.add_argument("--no-ref-cpu", action="store_true", help="time only the oracle port even if oracle/_ref/ref_aln is present")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `panSVR aln` leg")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the configs[4] (250 bp / edge-2000) leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU-baseline leg (0 = all cores, capped at the reference's 48)")
     args = ap.parse_args()
 
@@ -130,6 +131,7 @@ def main():
             index_bcast = "failed: %r" % (ex,)
     eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
     eng.upload(bases, base_off, ori)
+    index_device_bytes = index.device_bytes
     t_setup = time.time() - t_setup
 
     def barrier():
@@ -310,6 +312,49 @@ def main():
                 e2e[ext] = {"reads_per_s": round(2 * n_e2e / j["wall_s"], 1), "wall_s": j["wall_s"], "index_load_s": j["index_s"], "read_parse_s": j["read_parse_s"], "engine_s": j["engine_s"],
                             "format_s": j["format_s"], "write_s": j["write_s"], "batches": j["batches"], "d2h_bytes": j["d2h_bytes"], "out_bytes": os.path.getsize(os.path.join(tmp, "o." + ext))}
             e2e["note"] = "wall_s = first FASTQ byte to both files closed (three overlapped stages); index_load_s (files -> HBM) is outside it"
+    # ---- configs[4] beside it (not `value`): 250 bp reads against edge-2000 anchors, the shape whose DP problems are several hundred
+    # anti-diagonals wide, so the wavefront-per-alignment kernels get a timing and a roofline of their own
+    cfg5 = None
+    if rank == 0 and world == 1 and not args.no_cfg5:
+        eng.close(), index.close()
+        eng = index = None
+        try:
+            anc5 = bench_data.make_anchors(2000, seed=17, edge=2000, allele=(60, 2000))
+            ix5 = bench_data.build_index_cli(anc5, dense=True)
+            b5, o5, r5, _ = bench_data.make_reads(anc5, args.pairs, seed=19, L=250, frag=(400, 700), maxindel=40)
+            index5 = aln.Index(ix5, ["chr1", "chr2"], device=local_rank)
+            del ix5
+            eng5 = aln.Engine(index5, aln.default_params((250, 400, 550, 700)))
+            eng5.upload(b5, o5, r5)
+            eng5.run()
+            torch.cuda.synchronize()
+            t5 = time.time()
+            for _ in range(3):
+                eng5.run()
+            torch.cuda.synchronize()
+            t5 = (time.time() - t5) / 3
+            eng5.run(timing=True)
+            k5 = eng5.stats()["kernels"]
+            eng5.run(stats=True)
+            s5 = eng5.stats()
+            dom5 = max(k5, key=lambda k: k5[k]["ms"])
+            wide = {k: round(v["ms"], 4) for k, v in k5.items() if k.startswith("extd2_")}
+            # algorithmic bytes of a DP kernel: query + target bytes in, ksw_extz_t + CIGAR words out; per problem ~ qlen + tlen + 40 + 4 * n_cigar.
+            # Counted from the run: dp_cells / dp_problems gives the mean shape; direction bytes are scratch and not counted.
+            cfg5 = {"workload": "configs[4]: %d synthetic 250 bp PE pairs vs 2000 anchors with 2 kbp edges (%.1f Mbp), indels up to 40" % (args.pairs, len(anc5["codes"]) / 1e6),
+                    "reads_per_s": round(2 * args.pairs / t5, 1), "ms_per_step": round(t5 * 1e3, 3), "dominant_kernel": dom5,
+                    "dp_problems": s5["dp_problems"], "dp_cells": s5["dp_cells"], "dp_kernels_ms": wide,
+                    "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(k5.items(), key=lambda kv: -kv[1]["ms"])}}
+            dp_ms = sum(wide.values())
+            if dp_ms > 0 and s5["dp_problems"]:
+                mean_cells = s5["dp_cells"] / s5["dp_problems"]
+                dp_bytes = s5["dp_problems"] * (2 * mean_cells ** 0.5 + 30 + 56 + 4 * 6)      # q + t (~ 2 sqrt(cells) + 30), ez (56 B), ~6 CIGAR words
+                cfg5["dp_roofline"] = {"bound": "hbm", "kernels": "all extd2_* launches of a step", "achieved": round(dp_bytes / (dp_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(dp_bytes / (dp_ms * 1e-3) / 1e9 / 8000.0, 6), "cells_per_s": round(s5["dp_cells"] / (dp_ms * 1e-3), 1),
+                                       "note": "integer DP: issue-bound, the byte roofline is far away; cells/s is the figure to watch"}
+            eng5.close(), index5.close()
+        except Exception as ex:
+            cfg5 = {"error": repr(ex)}
     if rank == 0:
         line = {"metric": "signal reads realigned/sec (150 bp PE); bit-exact CIGAR vs CPU ref", "value": round(value, 1), "unit": "reads/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -318,14 +363,14 @@ def main():
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step,
                                                  "parallelism": "shard%d (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank over %s, %d iteration(s)/step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
-                                                 "index_hbm_bytes": index.device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
+                                                 "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
-                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie,
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,
                 "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)
-    eng.close()
-    index.close()
+    if eng is not None:
+        eng.close(), index.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,6 +148,9 @@ int psvr_index_load(const char *index_dir, const char *header_sam, int device, p
 /* Multi-GPU: a second copy of an index that is already resident on another device, moved device to device (xGMI peer
  * copies instead of N host uploads; SURVEY 8(e) "broadcast index").  `src` stays valid. */
 int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_t **out);
+/* The index straight from the anchor FASTA (what `deBGA index -k 22` + load_index_file do through nine files: the builder of
+ * `panSVR index` runs on the host, the 2 GiB first-level table is expanded in HBM and never exists on the host or on disk) */
+int psvr_index_build(const char *anchors_fa, const char *header_sam, int device, psvr_index_t **out);
 void psvr_index_destroy(psvr_index_t *idx);
 int64_t psvr_index_device_bytes(const psvr_index_t *idx);
 int32_t psvr_index_n_anchor(const psvr_index_t *idx);

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <time.h>
 #include <unistd.h>
@@ -54,7 +55,7 @@ static int usage()
 	fprintf(stderr,
 	        "\n  Usage:     panSVR  aln|fc_aln  [Options] <IndexDir> [ReadFiles.fa][ori_header_fn.sam]>\n"
 	        "  Basic:   \n"
-	        "    <IndexDir>      FOLDER   the directory contains index\n"
+	        "    <IndexDir>      FOLDER   the directory contains index (or the anchor FASTA: the index is then built in GPU memory)\n"
 	        "    [ReadFiles.fa]  FILES    reads files, FASTQ(A) format (or fq.gz), read 1 and 2 of a pair stored together ('-' = stdin),\n"
 	        "                             or a *.bam: the signal step then runs in-process ([ori_header.sam] is written;\n"
 	        "                             -N / -D / -U as in fc_signal: name-sorted input / all pairs are signals / drop fully matching pairs)\n"
@@ -235,7 +236,13 @@ int main(int argc, char **argv)
 		for (int q = 0; q < d; ++q) if (o.devices[(size_t)q] == o.devices[(size_t)d]) { same = q; break; }
 		if (same >= 0) { idx[(size_t)d] = idx[(size_t)same]; continue; }
 		const double t0 = walltime();
-		if (d == 0) { if (psvr_index_load(o.index_dir.c_str(), o.header.c_str(), o.devices[0], &idx[0])) die("index"); t_idx_first = walltime() - t0; }
+		if (d == 0) {
+			// <IndexDir> may also be the anchor FASTA itself: the index is then built straight into HBM (no `index` step, no files)
+			struct stat st;
+			const bool is_fasta = stat(o.index_dir.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+			if (is_fasta ? psvr_index_build(o.index_dir.c_str(), o.header.c_str(), o.devices[0], &idx[0]) : psvr_index_load(o.index_dir.c_str(), o.header.c_str(), o.devices[0], &idx[0])) die("index");
+			t_idx_first = walltime() - t0;
+		}
 		else { if (psvr_index_clone(idx[0], o.devices[(size_t)d], &idx[(size_t)d])) die("index clone"); t_idx_clone += walltime() - t0; }
 	}
 	const double t_index = walltime() - t_idx0;

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "engine_core.h"
 #include "host_io.h"
+#include "index_build.h"
 #include "ksw_device.h"
 #include "ksw_launch.h"
 
@@ -1002,7 +1003,15 @@ struct psvr_index {
 	int64_t bytes = 0;
 };
 
-static int index_upload(psvr_index *ix, const psvr_index_view_t *v)
+__global__ void k_scatter_counts(const uint32_t *ids, const uint32_t *cnts, long long n, int32_t *dense)
+{
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) dense[ids[i]] = (int32_t)cnts[i];
+}
+
+// `sparse` (optional, when v->hash is null): the non-empty first-level buckets as (id, count) -- the dense prefix-sum table is
+// then built in HBM (scatter + device scan) instead of being uploaded: 2 GiB that never exist on the host
+static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32_t *sparse_id = nullptr, const uint32_t *sparse_cnt = nullptr, long long n_sparse = 0)
 {
 	PSVR_HIP(hipSetDevice(ix->device));
 	auto up = [&](DevBuf &b, const void *src, size_t n, size_t pad) -> hipError_t {
@@ -1017,7 +1026,22 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v)
 	PSVR_HIP(up(ix->seqf, v->seqf, v->n_seqf * 8, 0));
 	PSVR_HIP(up(ix->pos, v->pos, v->n_pos * 8, 0));
 	PSVR_HIP(up(ix->posp, v->posp, v->n_posp * 8, 0));
-	PSVR_HIP(up(ix->hash, v->hash, v->n_hash * 8, 0));
+	if (v->hash) PSVR_HIP(up(ix->hash, v->hash, v->n_hash * 8, 0));
+	else {
+		const long long NB = (long long)1 << 28;
+		PSVR_HIP(ix->hash.alloc((size_t)(NB + 1) * 8));
+		ix->bytes += (NB + 1) * 8;
+		DevBuf cnt, ids, cn;
+		PSVR_HIP(cnt.alloc((size_t)(NB + 1) * 4)); PSVR_HIP(ids.alloc((size_t)n_sparse * 4 + 4)); PSVR_HIP(cn.alloc((size_t)n_sparse * 4 + 4));
+		PSVR_HIP(hipMemset(cnt.p, 0, (size_t)(NB + 1) * 4));
+		PSVR_HIP(hipMemcpy(ids.p, sparse_id, (size_t)n_sparse * 4, hipMemcpyHostToDevice)); PSVR_HIP(hipMemcpy(cn.p, sparse_cnt, (size_t)n_sparse * 4, hipMemcpyHostToDevice));
+		if (n_sparse) hipLaunchKernelGGL(k_scatter_counts, dim3(grid_for(n_sparse)), dim3(kBlock), 0, nullptr, ids.as<uint32_t>(), cn.as<uint32_t>(), n_sparse, cnt.as<int32_t>());
+		GpuBE be;                                            // its three-kernel scan: hash[i] = number of 22-mers in buckets < i
+		be.st_scan(cnt.as<int32_t>(), NB + 1, 1, 0, 0ll, ix->hash.as<long long>());
+		PSVR_HIP(hipGetLastError());
+		PSVR_HIP(hipDeviceSynchronize());
+		if (be.last != hipSuccess) return set_error(PSVR_ERR_DEVICE, "index build: %s", hipGetErrorString(be.last));
+	}
 	PSVR_HIP(up(ix->off, v->off, v->n_off * 8, 0));
 	PSVR_HIP(up(ix->kmer, v->kmer, v->n_kmer * 4, 16));
 	const HostIndex &h = ix->host;
@@ -1073,6 +1097,35 @@ extern "C" int psvr_index_create(const psvr_index_view_t *v, int device, psvr_in
 	return PSVR_OK;
 }
 
+// f1, "direct-to-HBM build": anchor FASTA -> the index, resident in HBM, without the nine files in between (the host builder of
+// `panSVR index` produces the small arrays; the dense first-level table is expanded on the device)
+extern "C" int psvr_index_build(const char *anchors_fa, const char *header_sam, int device, psvr_index_t **out)
+{
+	if (!anchors_fa || !header_sam || !out) return set_error(PSVR_ERR_ARG, "psvr_index_build: null argument");
+	if (psvr_device_count() <= 0) return set_error(PSVR_ERR_DEVICE, "no HIP device visible: the engine has no CPU path");
+	IndexBuilder b;
+	BuiltIndex bi;
+	if (!b.build(anchors_fa, &bi)) return set_error(PSVR_ERR_IO, "index build: %s", b.error().c_str());
+	std::vector<std::string> names;
+	if (!HostIndex::header_names_of(header_sam, &names)) return set_error(PSVR_ERR_IO, "cannot read header %s", header_sam);
+	psvr_index *ix = new psvr_index;
+	ix->device = device;
+	std::string err;
+	if (!ix->host.parse_chr(bi.chr_text, names, &err)) { delete ix; return set_error(PSVR_ERR_IO, "%s", err.c_str()); }
+	bi.ref_seq.resize(bi.ref_seq.size());
+	psvr_index_view_t v;
+	memset(&v, 0, sizeof v);
+	v.ref_seq = bi.ref_seq.data(), v.n_ref_seq = bi.ref_seq.size(), v.seq = bi.seqb.data(), v.n_seq = bi.seqb.size();
+	v.seqf = bi.seqf.data(), v.n_seqf = bi.seqf.size(), v.pos = bi.pos.data(), v.n_pos = bi.pos.size(), v.posp = bi.posp.data(), v.n_posp = bi.posp.size();
+	v.hash = nullptr, v.n_hash = ((uint64_t)1 << 28) + 1, v.kmer = bi.kmer.data(), v.n_kmer = bi.kmer.size(), v.off = bi.off.data(), v.n_off = bi.off.size();
+	std::vector<uint32_t> sid(bi.hash_sparse_id.size()), scn(bi.hash_sparse_cnt.size());
+	for (size_t i = 0; i < sid.size(); ++i) sid[i] = (uint32_t)bi.hash_sparse_id[i], scn[i] = (uint32_t)bi.hash_sparse_cnt[i];
+	int rc = index_upload(ix, &v, sid.data(), scn.data(), (long long)sid.size());
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return PSVR_OK;
+}
+
 extern "C" int psvr_index_load(const char *dir, const char *header_sam, int device, psvr_index_t **out)
 {
 	if (!dir || !header_sam || !out) return set_error(PSVR_ERR_ARG, "psvr_index_load: null argument");
@@ -1080,6 +1133,7 @@ extern "C" int psvr_index_load(const char *dir, const char *header_sam, int devi
 	psvr_index *ix = new psvr_index;
 	ix->device = device;
 	std::string err;
+	ix->host.defer_dense = true;
 	if (!ix->host.load_dir(dir, header_sam, &err)) { delete ix; return set_error(PSVR_ERR_IO, "%s", err.c_str()); }
 	HostIndex &h = ix->host;
 	psvr_index_view_t v;
@@ -1087,7 +1141,15 @@ extern "C" int psvr_index_load(const char *dir, const char *header_sam, int devi
 	v.ref_seq = h.ref_seq.data(), v.n_ref_seq = h.ref_seq.size(), v.seq = h.seq.data(), v.n_seq = h.seq.size();
 	v.seqf = h.seqf.data(), v.n_seqf = h.seqf.size(), v.pos = h.pos.data(), v.n_pos = h.pos.size(), v.posp = h.posp.data(), v.n_posp = h.posp.size();
 	v.hash = h.hash.data(), v.n_hash = h.hash.size(), v.kmer = h.kmer.data(), v.n_kmer = h.kmer.size(), v.off = h.off.data(), v.n_off = h.off.size();
-	int rc = index_upload(ix, &v);
+	int rc;
+	if (!h.sparse_pairs.empty()) {                 // fixture / `panSVR index --sparse-hash` form: expand on the device
+		const size_t ns = h.sparse_pairs.size() / 2;
+		std::vector<uint32_t> sid(ns), scn(ns);
+		for (size_t i = 0; i < ns; ++i) sid[i] = h.sparse_pairs[2 * i], scn[i] = h.sparse_pairs[2 * i + 1];
+		v.hash = nullptr, v.n_hash = ((uint64_t)1 << 28) + 1;
+		rc = index_upload(ix, &v, sid.data(), scn.data(), (long long)ns);
+		std::vector<uint32_t>().swap(h.sparse_pairs);
+	} else rc = index_upload(ix, &v);
 	std::vector<uint64_t>().swap(h.hash);          // the 2 GiB table now lives in HBM only
 	if (rc) { delete ix; return rc; }
 	*out = ix;

@@ -42,6 +42,8 @@ struct HostIndex {
 	std::vector<uint32_t> kmer;
 	std::vector<uint32_t> sp_id; std::vector<uint64_t> sp_start;   // sparse first level (tests/emu only)
 	bool keep_sparse = false;
+	bool defer_dense = false;                 // GPU engine: leave a sparse first level as (bucket, count) pairs; the dense table is built in HBM
+	std::vector<uint32_t> sparse_pairs;
 	std::vector<uint32_t> chr_end_n, chr_search_index;
 	std::vector<std::string> chr_names;
 	std::vector<SvDev> sv;
@@ -147,12 +149,14 @@ struct HostIndex {
 			uint64_t acc = 0;
 			for (size_t i = 0; i + 1 < sparse.size(); i += 2) { sp_id.push_back(sparse[i]); sp_start.push_back(acc); acc += sparse[i + 1]; }
 			hash.assign(((size_t)1 << 28) + 1 > 0 ? 0 : 0, 0);
+		} else if (defer_dense && slurp_file(dir + "unipath_g.hash.sparse", &sparse)) {
+			sparse_pairs.swap(sparse);
 		} else if (slurp_file(dir + "unipath_g.hash.sparse", &sparse)) {
 			hash.assign(((size_t)1 << 28) + 1, 0);
 			for (size_t i = 0; i + 1 < sparse.size(); i += 2) hash[(size_t)sparse[i] + 1] = sparse[i + 1];
 			for (size_t i = 1; i < hash.size(); ++i) hash[i] += hash[i - 1];
 		} else if (!slurp_file(dir + "unipath_g.hash", &hash)) { *err = "missing unipath_g.hash in " + dir; return false; }
-		if (!(keep_sparse && !sp_id.empty()) && hash.size() != ((size_t)1 << 28) + 1) { *err = "unipath_g.hash has the wrong size"; return false; }
+		if (!(keep_sparse && !sp_id.empty()) && sparse_pairs.empty() && hash.size() != ((size_t)1 << 28) + 1) { *err = "unipath_g.hash has the wrong size"; return false; }
 		std::vector<char> txt;
 		if (!slurp_file(dir + "unipath.chr", &txt)) { *err = "missing unipath.chr"; return false; }
 		return parse_chr(std::string(txt.begin(), txt.end()), names, err);

@@ -129,3 +129,42 @@ def test_index_clone_is_an_index():
     a, b = (ac.engine_records(r, p, c, ori, lens, 0, P) for r, p, c in outs)      # (arena positions differ from run to run: compare what they point at)
     assert a == b and outs[0][1].tobytes() == outs[1][1].tobytes()
     clone.close(), index.close()
+
+
+def test_index_built_in_hbm_from_the_anchor_fasta_aligns_like_the_reference_built_one():
+    """f1: psvr_index_build (host builder + first-level table expanded on the device, nothing written to disk) against the index
+    the reference's deBGA built for the same anchors (tests/golden/fx2/idx): same HBM footprint, same records; and the CLI given
+    the FASTA in place of <IndexDir> writes the reference's SAM files."""
+    import gzip
+    import subprocess
+    import tempfile
+    from pansvr_amd import aln
+    from pansvr_amd._lib import check, lib
+    w = ac.workdir("fx2")
+    bases, base_off, ori, stat = _inputs(limit=800)
+    index = _index()
+    h = C.c_void_p()
+    check(lib().psvr_index_build(os.path.join(w, "anchors.fa").encode(), os.path.join(w, "header.sam").encode(), 0, C.byref(h)))
+    lib().psvr_index_device_bytes.restype = C.c_int64
+    assert lib().psvr_index_device_bytes(h) == index.device_bytes
+    built = aln.Index.__new__(aln.Index)
+    built.h, built.device_bytes = h, index.device_bytes
+    outs = []
+    for ix in (index, built):
+        eng = aln.Engine(ix, aln.default_params(stat))
+        eng.upload(bases, base_off, ori)
+        eng.run()
+        outs.append(eng.download())
+        eng.close()
+    lens = np.diff(base_off)
+    P = (len(base_off) - 1) // 2
+    a, b = (ac.engine_records(r, p, c, ori, lens, 0, P) for r, p, c in outs)
+    assert a == b
+    built.close(), index.close()
+    tmp = tempfile.mkdtemp(prefix="psvr_fa_")
+    cli = os.path.join(ac.ROOT, "pansvr_amd", "bin", "panSVR")
+    r = subprocess.run([cli, "aln", "-S", "-o", os.path.join(tmp, "o.sam"), "-p", os.path.join(tmp, "p.sam"), os.path.join(w, "anchors.fa"), os.path.join(w, "reads150.fq"),
+                        os.path.join(w, "header.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    with gzip.open(os.path.join(ac.golden_dir("fx2"), "reads150.sam.gz"), "rb") as f:
+        assert open(os.path.join(tmp, "o.sam"), "rb").read() == f.read()

@@ -51,9 +51,10 @@ def test_fullsize_properties_and_prefix_parity():
 
 def test_cfg5_long_reads_properties_and_prefix_parity():
     """BASELINE configs[4] shape (250 bp reads, 2 000 anchors with 2 kbp edges, indels up to 40: DP problems of several hundred
-    anti-diagonals, direction bytes in the HBM slab, K = 3..5 kernels) at 100 k pairs, oracle parity on the first 5 k."""
+    anti-diagonals, direction bytes in the HBM slab, K = 3..5 kernels) at the configuration's full 1 M pairs, oracle parity on the
+    first 5 k (the oracle's behaviour on this shape is pinned against the reference objects by tests/golden/fx4)."""
     run_config(dict(n_anchors=2000, seed=17, edge=2000, allele=(60, 2000)), dict(seed=19, L=250, frag=(400, 700), maxindel=40), (250, 400, 550, 700),
-               int(os.environ.get("PSVR_CFG5_PAIRS", "100000")), 5000, False)
+               int(os.environ.get("PSVR_CFG5_PAIRS", "1000000")), 5000, False)
 
 
 def run_config(anc_kw, reads_kw, stat, N_PAIRS, N_ORACLE, split):
