@@ -259,7 +259,7 @@ int main(int argc, char **argv)
 		signal(SIGPIPE, SIG_IGN);            // if the reader stops early (-R), the signal step's writes fail quietly and it runs to its end
 		int fds[2];
 		if (pipe(fds)) { fprintf(stderr, "[panSVR-amd] pipe() failed\n"); abort(); }
-		sig.o.sort_by_name = true, sig.o.input = o.reads, sig.o.header_fn = o.header, sig.o.status_fn = o.header + ".status";
+		sig.o.sort_by_name = sig_by_name, sig.o.input = o.reads, sig.o.header_fn = o.header, sig.o.status_fn = o.header + ".status";
 		sig.o.not_use_filter = o.sig_all, sig.o.discard_full_match = o.sig_discard;
 		sig.o.match = o.match, sig.o.mismatch = o.mismatch, sig.o.gap_open = o.gap_open, sig.o.gap_ex = o.gap_ex, sig.o.gap_open2 = o.gap_open2, sig.o.gap_ex2 = o.gap_ex2;
 		FILE *w = fdopen(fds[1], "w");

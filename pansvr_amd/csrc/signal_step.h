@@ -4,9 +4,14 @@
 // the reference's build of this step needs htslib, which cannot be built in this image, so the only checker is the independent
 // restatement in oracle/signal_oracle.py (tests/test_signal.py).
 //
-// Implemented: the name-sorted input mode (`-N`, SURVIVOR_SV_region_get_all_signal_records_SORT_BY_NAME, getSignalRead.cpp:491-519).
-// Not implemented: the position-sorted default (mate search in 60 Mbp windows + temporary BAM of unpaired records + the
-// Manta-derived insert-size sampler of cpp_lib/statistics): the command asks for `samtools sort -n` input instead.
+// Both input orders are implemented: name-sorted (`-N`, SURVIVOR_SV_region_get_all_signal_records_SORT_BY_NAME, getSignalRead.cpp:491-519)
+// and the default, position-sorted one (..._SORT_BY_pos, :285-489: blocks of up to 1 M primary records / one chromosome / 60 Mbp, mates
+// found through a 64 bp position index, the records left over -- mate on another chromosome or in another block, and always the last
+// record of a block -- paired by name afterwards).  Two deliberate differences in that mode: the left-over records are kept in memory
+// instead of going through the temporary BAM (the reference reads that file back into memory in one piece anyway; `-t` is accepted and
+// unused), and the insert-size quantiles of the STAT_ field come from the first 100 000 primary records like in the name-sorted mode,
+// not from the Manta-derived genome-wide sampler of cpp_lib/statistics (`--isize MIN,MID,MAX` overrides them, e.g. with the
+// reference's numbers).  A mate the index search cannot find is left to the by-name pass; the reference aborts there.
 // Where the reference reads uninitialised memory this code uses 0 (soft-clip lengths of a record without CIGAR,
 // getSignalRead.cpp:129 with clib/bam_file.c:1033-1034; the sampled depth in the status file, getSignalRead.hpp:170).
 #pragma once
@@ -28,6 +33,7 @@ struct SignalOpt {
 	bool sort_by_name = false, not_use_filter = false, discard_full_match = false;
 	double sample_rate = 1;
 	std::string header_fn = "./header.sam", status_fn = "./status.sam", input;
+	int isize_override[3] = {-1, -1, -1};                                                   // --isize MIN,MID,MAX
 };
 
 struct BamStat {                                            // BAM_STAT, getSignalRead.hpp:33-190
@@ -260,6 +266,7 @@ struct SignalStep {
 		if (!rd.error().empty()) { fprintf(stderr, "[panSVR-amd] signal: %s\n", rd.error().c_str()); return false; }
 		bs.global();
 		bs.min_i = bs.min_l2, bs.mid_i = (bs.min_l2 + bs.max_l2) / 2, bs.max_i = bs.max_l2;
+		if (o.isize_override[0] >= 0) bs.min_i = (uint32_t)o.isize_override[0], bs.mid_i = (uint32_t)o.isize_override[1], bs.max_i = (uint32_t)o.isize_override[2];
 		bs.dist.clear();
 		for (uint32_t i = bs.min_i; i < bs.max_i; ++i) bs.dist.push_back((float)bs.isize_n[i] / (float)(bs.total + 1));
 		bs.depth = 0;
@@ -268,12 +275,113 @@ struct SignalStep {
 		return true;
 	}
 
+	// SURVIVOR_SV_region_get_all_signal_records_SORT_BY_pos, getSignalRead.cpp:285-489
+	bool run_pos_sorted(BamReader &rd)
+	{
+		static const int kBuf = 1000000, kStep = 64, kIndex = 1000000, kRegion = 60000000;   // SAM_LOAD_BUFF_SIZE, SEARCH_STEP, SEARCH_POS_INDEX_SIZE, SEARCH_REGION_MAX
+		std::vector<BamRecord> buf, left;                        // the block; the records no mate was found for
+		std::vector<uint32_t> mate, index((size_t)kIndex);
+		const uint32_t none = 0xffffffffu;
+		long long unmated_warned = 0;
+		bool eof = false;
+		for (;;) {
+			// part 1: a block of primary records -- until the chromosome changes, 60 Mbp are spanned or the buffer is full
+			buf.clear();
+			while ((int)buf.size() < kBuf && !eof) {
+				BamRecord r;
+				if (!rd.next(r)) { eof = true; break; }
+				if (!primary(r)) continue;
+				buf.push_back(std::move(r));
+				if (buf.back().tid != buf[0].tid) break;
+				if (buf.back().pos - buf[0].pos > kRegion) break;
+			}
+			const int n = (int)buf.size();
+			if (n < 2) break;                                     // (a single left-over record is dropped, like in the reference)
+			// part 2: position index in steps of 64 bp, then the mate of every record but the last
+			mate.assign((size_t)n, none);
+			int index_n = 0;
+			const int32_t start_pos = buf[0].pos, final_pos = buf[(size_t)n - 2].pos;
+			for (int i = 0; i < n; ++i) {
+				const int pi = (buf[(size_t)i].pos - start_pos) / kStep;
+				while (pi >= index_n) {
+					if (!(index_n < kIndex - 2)) { fprintf(stderr, "[panSVR-amd] signal: position index overflow (is the input sorted by position?)\n"); abort(); }   // xassert, :327
+					index[(size_t)index_n++] = (uint32_t)i;
+				}
+			}
+			index[(size_t)index_n] = (uint32_t)n;
+			for (int i = 0; i < n - 1; ++i) {
+				if (mate[(size_t)i] != none) continue;
+				const BamRecord &c = buf[(size_t)i];
+				if (c.tid != c.mtid) continue;
+				int m = -1;
+				if (c.tid == -1) {                                 // both unmapped: the mate is a neighbour
+					if (i == 0 || i > n - 2) continue;
+					if (!strcmp(buf[(size_t)i + 1].qname(), c.qname())) m = i + 1;
+					else if (!strcmp(buf[(size_t)i - 1].qname(), c.qname())) m = i - 1;
+				} else {
+					const int mpos = c.mpos;
+					if (mpos <= start_pos || mpos >= final_pos) continue;
+					const int pi = (mpos - start_pos) / kStep;
+					for (uint32_t k = index[(size_t)pi]; k < index[(size_t)pi + 1]; ++k) {
+						const BamRecord &t = buf[k];
+						if (t.pos < mpos) continue;
+						if (t.pos > mpos) break;
+						if (t.mpos != c.pos) continue;
+						if ((int)k != i && !strcmp(t.qname(), c.qname())) { m = (int)k; break; }
+					}
+				}
+				if (m < 0 || mate[(size_t)m] != none) { if (++unmated_warned % 1000 == 0) fprintf(stderr, "NUM: [%lld]: Mate failed, index:[%d] in [%d] size block, tid: [ %d ], pos [%d] name [%s]\n", unmated_warned, i, n, c.tid, c.pos, c.qname()); continue; }
+				mate[(size_t)i] = (uint32_t)m, mate[(size_t)m] = (uint32_t)i;
+			}
+			// part 3: what found no mate waits for the by-name pass
+			int unmated = 0;
+			for (int i = 0; i < n; ++i) if (mate[(size_t)i] == none) ++unmated;
+			if ((long long)unmated * 20 > n) fprintf(stderr, "WARNING, too many total_unmated_read![ %d %d %f]\n", unmated, n, (float)unmated / (float)n);
+			// part 4: the pairs, in the order of their first reads
+			for (int i = 0; i < n - 1; ++i) {
+				if (mate[(size_t)i] == none) continue;
+				const BamRecord &b1 = buf[(size_t)i];
+				if (b1.flag & 0x80) continue;
+				const BamRecord &b2 = buf[mate[(size_t)i]];
+				bs.total += 2;
+				if (bs.total % 100000 == 0) fprintf(stderr, "%ld\n", (long)bs.total);
+				if (!(b1.flag & 0x40) || !(b2.flag & 0x80)) { fprintf(stderr, "[panSVR-amd] signal: records of [%s] are not first/second in template\n", b1.qname()); abort(); }
+				bool used = true;
+				if (o.sample_rate < 0.9999 && rand() > sample_max) used = false;
+				pair(b1, b2, used);
+			}
+			for (int i = 0; i < n; ++i) if (mate[(size_t)i] == none) left.push_back(std::move(buf[(size_t)i]));
+		}
+		if (!rd.error().empty()) return false;
+		// phase 2: the left-over records by name, first before second (sam_cmp_by_name, :3-12; glibc's qsort is a stable merge sort)
+		fprintf(stderr, "phase 2:\nSort all unpaired records: [%zu] in total\n", left.size());
+		if (left.size() % 2) { fprintf(stderr, "[panSVR-amd] signal: an odd number of records found no mate: the BAM is incomplete\n"); abort(); }   // xassert, :437
+		std::vector<uint32_t> ord(left.size());
+		for (size_t i = 0; i < ord.size(); ++i) ord[i] = (uint32_t)i;
+		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+			const int c = strcmp(left[a].qname(), left[b].qname());
+			if (c) return c < 0;
+			return (left[a].flag & 0x40) != 0 && !(left[b].flag & 0x40);
+		});
+		for (size_t i = 0; i + 1 < ord.size(); i += 2) {
+			bs.total += 2;
+			if (bs.total % 100000 == 0) fprintf(stderr, "%ld\n", (long)bs.total);
+			const BamRecord &b1 = left[ord[i]], &b2 = left[ord[i + 1]];
+			if (strcmp(b1.qname(), b2.qname())) {
+				fprintf(stderr, "Read Pairing error!, reads names are not same, please confirm the completeness of BAM/CRAM file.\n");
+				--i;                                               // (the reference steps on by one record)
+				continue;
+			}
+			if (!(b1.flag & 0x40) || !(b2.flag & 0x80)) { fprintf(stderr, "[panSVR-amd] signal: records of [%s] are not first/second in template\n", b1.qname()); abort(); }
+			bool used = true;
+			if (o.sample_rate < 0.9999 && rand() > sample_max) used = false;
+			pair(b1, b2, used);
+		}
+		return true;
+	}
+
 	int run()                                               // init_run, getSignalRead.hpp:228-330
 	{
-		if (!o.sort_by_name) {
-			fprintf(stderr, "[panSVR-amd] signal: only name-sorted input is supported (give -N; `samtools sort -n` the file first)\n");
-			return 1;
-		}
 		if (!sample_stats()) return 1;
 		bs.final_stat(stderr);
 		FILE *st = fopen(o.status_fn.c_str(), "w");
@@ -296,6 +404,14 @@ struct SignalStep {
 			if (!h) { fprintf(stderr, "fail to open file '%s'\n", o.header_fn.c_str()); return 1; }
 			fwrite(rd.header_text.data(), 1, rd.header_text.size(), h);
 			fclose(h);
+		}
+		if (!o.sort_by_name) {
+			if (!run_pos_sorted(rd)) { fprintf(stderr, "[panSVR-amd] signal: %s\n", rd.error().c_str()); return 1; }
+			fflush(out);
+			bs.global();
+			fprintf(stderr, "BAM/CRAM status: ave_read_depth: [%f] read length: [Normal: %d @ %f%%, AVE: %f] ISIZE: [MIN: %d MAX: %d]\n", bs.depth, bs.read_len, bs.normal_percent * 100, bs.ave_len,
+			        bs.min_l2, bs.max_l2);
+			return 0;
 		}
 		BamRecord b1, b2;
 		for (;;) {                                          // SURVIVOR_SV_region_get_all_signal_records_SORT_BY_NAME
@@ -326,7 +442,7 @@ inline int signal_main(int argc, char **argv)
 	static struct option lo[] = {{"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'}, {"match-score", 1, 0, 'M'},
 	                             {"mis-score", 1, 0, 'm'}, {"max-tid-filter", 1, 0, 'I'}, {"sort-by-name", 0, 0, 'N'}, {"not-ignore-low-q", 0, 0, 'L'}, {"reference", 1, 0, 'r'},
 	                             {"header-file", 1, 0, 'H'}, {"status-file", 1, 0, 'S'}, {"tmp_file_pairing", 1, 0, 't'}, {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'},
-	                             {"sample-rate", 1, 0, 'R'}, {0, 0, 0, 0}};
+	                             {"sample-rate", 1, 0, 'R'}, {"isize", 1, 0, 1000}, {0, 0, 0, 0}};
 	int c;
 	optind = 2;
 	while ((c = getopt_long(argc, argv, "O:P:E:F:M:m:I:NLr:H:S:t:DUR:", lo, NULL)) >= 0) {
@@ -339,16 +455,17 @@ inline int signal_main(int argc, char **argv)
 		case 'm': S.o.mismatch = atoi(optarg); break;
 		case 'I': S.o.max_tid = atoi(optarg); break;
 		case 'N': S.o.sort_by_name = true; break;
-		case 'L': case 'r': case 't': break;                // accepted: unused by the name-sorted mode
+		case 'L': case 'r': case 't': break;                // accepted and unused (-t: the left-over records stay in memory)
 		case 'H': S.o.header_fn = optarg; break;
 		case 'S': S.o.status_fn = optarg; break;
 		case 'D': S.o.not_use_filter = true; break;
 		case 'U': S.o.discard_full_match = true; break;
 		case 'R': S.o.sample_rate = atof(optarg); break;
-		default: fprintf(stderr, "usage: panSVR signal|fc_signal -N [options] <name-sorted.bam>  > reads.fq\n"); return 1;
+		case 1000: if (sscanf(optarg, "%d,%d,%d", &S.o.isize_override[0], &S.o.isize_override[1], &S.o.isize_override[2]) != 3) { fprintf(stderr, "--isize wants MIN,MID,MAX\n"); return 1; } break;
+		default: fprintf(stderr, "usage: panSVR signal|fc_signal [-N] [options] <in.bam>  > reads.fq\n"); return 1;
 		}
 	}
-	if (argc - optind < 1) { fprintf(stderr, "usage: panSVR signal|fc_signal -N [options] <name-sorted.bam>  > reads.fq\n"); return 1; }
+	if (argc - optind < 1) { fprintf(stderr, "usage: panSVR signal|fc_signal [-N] [options] <in.bam>  > reads.fq\n"); return 1; }
 	S.o.input = argv[optind];
 	return S.run();
 }

@@ -171,7 +171,7 @@ def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
     outs = []
     for tag, reads, hdr in (("a", fq, os.path.join(tmp, "h1.sam")), ("b", bam, os.path.join(tmp, "h2.sam"))):
         o = os.path.join(tmp, tag)
-        r = subprocess.run([CLI, "aln", "-S", "-D", "-o", o + ".sam", "-p", o + ".ori.sam", "--records", o + ".jsonl", idx, reads, hdr], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r = subprocess.run([CLI, "aln", "-S", "-D", "-N", "-o", o + ".sam", "-p", o + ".ori.sam", "--records", o + ".jsonl", idx, reads, hdr], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(o)
     for ext in (".sam", ".ori.sam", ".jsonl"):

@@ -155,3 +155,40 @@ def test_signal_step_matches_the_restatement(tmp_path, flags):
     for l in names[:50]:
         tok = l.split(b" ", 1)[1].split(b"_")
         assert all(t.lstrip(b"-").isdigit() for t in tok[:9]) and len(tok[9]) == 4 and len(tok[10]) == 4
+
+
+def _pair_records(fastq_bytes):
+    """FASTQ text -> sorted list of 8-line pair records with the STAT_ token (carried by whichever pair is written first) removed."""
+    import re
+    lines = fastq_bytes.split(b"\n")
+    assert lines[-1] == b"" and (len(lines) - 1) % 8 == 0
+    out = []
+    for k in range(0, len(lines) - 1, 8):
+        out.append(re.sub(rb"STAT_-?\d+_-?\d+_-?\d+_-?\d+_", b"", b"\n".join(lines[k:k + 8])))
+    return sorted(out)
+
+
+@pytest.mark.parametrize("flags", [["-D"], [], ["-U"]])
+def test_position_sorted_mode_finds_the_pairs_of_the_name_sorted_mode(tmp_path, flags):
+    """The default input order of fc_signal (getSignalRead.cpp:285-489): the same records sorted by (chromosome, position) -- mates
+    adjacent, far apart, on other chromosomes, unmapped (placed at the mate or at the end of the file), with secondary / supplementary
+    records in between -- must yield exactly the pairs the name-sorted mode writes for them (any order)."""
+    recs, refs = make_pairs(777 + len(flags), 1500)
+    by_name = str(tmp_path / "name.bam")
+    write_bam(by_name, recs, refs)
+
+    def key(i):
+        tid, pos = struct.unpack_from("<ii", recs[i], 4)
+        return (tid if tid >= 0 else 1 << 31, pos, i)
+    order = sorted(range(len(recs)), key=key)
+    by_pos = str(tmp_path / "pos.bam")
+    write_bam(by_pos, [recs[i] for i in order], refs)
+    a = subprocess.run([CLI, "signal", "-N"] + flags + ["-H", str(tmp_path / "h1.sam"), "-S", str(tmp_path / "s1.txt"), by_name], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([CLI, "signal"] + flags + ["-H", str(tmp_path / "h2.sam"), "-S", str(tmp_path / "s2.txt"), by_pos], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr.decode()[-800:], b.stderr.decode()[-800:])
+    pa, pb = _pair_records(a.stdout), _pair_records(b.stdout)
+    assert len(pa) == len(pb) and len(pa) > (1000 if flags == ["-D"] else 100)
+    assert pa == pb
+    assert b"phase 2:" in b.stderr and b.stdout.count(b"STAT_") == 1
+    # both orders see the same first 100 000 primary records only when the file is short: the status line's read length agrees
+    assert open(tmp_path / "s1.txt").read().split("_")[1] == open(tmp_path / "s2.txt").read().split("_")[1]
