@@ -49,6 +49,9 @@ class BgzfWriter {
 		for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
 		return clen + 26;
 	}
+public:
+	static size_t compress_block_public(const uint8_t *p, size_t n, uint8_t *out) { return compress_block(p, n, out); }   // out: 0x10000 + 64 bytes
+private:
 	// blocks are independent: compress them on `threads_` threads, write in order
 	void flush_blocks(const uint8_t *p, size_t n)
 	{

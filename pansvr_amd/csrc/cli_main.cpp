@@ -32,6 +32,7 @@
 #include "bam_writer.h"
 #include "index_build.h"
 #include "signal_step.h"
+#include "bam_sort.h"
 
 using namespace psvr;
 
@@ -165,8 +166,9 @@ int main(int argc, char **argv)
 {
 	if (argc >= 2 && !strcmp(argv[1], "index")) return index_main(argc, argv);
 	if (argc >= 2 && (!strcmp(argv[1], "signal") || !strcmp(argv[1], "fc_signal"))) return psvr::signal_main(argc, argv);
+	if (argc >= 2 && !strcmp(argv[1], "sort")) return psvr::bam_sort_main(argc, argv);
 	if (argc < 2 || (strcmp(argv[1], "aln") && strcmp(argv[1], "fc_aln"))) {
-		fprintf(stderr, "panSVR (MI355X engine): the read re-alignment step and its two neighbours.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n         panSVR index [-k 22] <anchors.fa> <IndexDir>\n         panSVR signal [-N] [options] <in.bam> > reads.fq\n");
+		fprintf(stderr, "panSVR (MI355X engine): the read re-alignment step and its two neighbours.\n  usage: panSVR aln|fc_aln [options] <IndexDir> <reads.fq|-> <header.sam>\n         panSVR index [-k 22] <anchors.fa> <IndexDir>\n         panSVR signal [-N] [options] <in.bam> > reads.fq\n         panSVR sort [-n] [-t threads] [-o out.bam] in.bam      (coordinate order + .bai, or -n name order)\n");
 		return 1;
 	}
 	Opt o;

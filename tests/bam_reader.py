@@ -25,8 +25,8 @@ def check_bgzf(path):
     return n
 
 
-def read_bam(path):
-    """Returns (header_text, [(name, length)], [sam_line_fields])."""
+def read_bam(path, check_bin=True):
+    """Returns (header_text, [(name, length)], [sam_line_fields]).  check_bin: the stored bin must be reg2bin of the record's interval."""
     raw = gzip.open(path, "rb").read()
     assert raw[:4] == b"BAM\x01"
     l_text = struct.unpack_from("<i", raw, 4)[0]
@@ -83,7 +83,7 @@ def read_bam(path):
         cigar = "".join("%d%s" % (c >> 4, CIGAR_OPS[c & 15]) for c in cig) or "*"
         # reg2bin of the record's own interval (section 5.3)
         rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8)) or 1
-        assert bin_ == reg2bin(pos, pos + rlen), (bin_, pos, rlen)
+        assert not check_bin or bin_ == reg2bin(max(pos, 0), max(pos, 0) + rlen), (bin_, pos, rlen)
         recs.append([qname, str(flag), rname, str(pos + 1), str(mapq), cigar, rnext, str(mpos + 1), str(tlen), seq or "*", qual] + tags)
     return text, refs, recs
 
