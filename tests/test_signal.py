@@ -1,7 +1,11 @@
-"""`panSVR signal -N` (pansvr_amd/csrc/signal_step.h) against the independent restatement
-oracle/signal_oracle.py on BAM files written here record by record.  PARITY UNPINNED: the reference's own build of this
-step needs htslib, which this image cannot build, and the reference has no fixture for it; both sides restate
-getSignalRead.cpp.  The FASTQ comments are also fed through the `aln` step's own parser (the wire-format contract)."""
+"""`panSVR signal` (pansvr_amd/csrc/signal_step.h) on BAM files written here record by record, against
+  * the REFERENCE's own per-pair function READ_SIGNAL_HANDLER::all_signal_records_read_pair (getSignalRead.cpp:100-256: the filter,
+    the scores, the FASTQ comment wire format, strand handling), run on the same records through oracle/_ref/ref_signal --
+    tests/golden/signal/*.fq.gz, made by tests/golden/gen_signal_golden.py;
+  * the independent restatement oracle/signal_oracle.py (which also covers the header / status files and the statistics the
+    reference takes from the BAM through htslib's file layer -- that layer cannot be built in this image, so the sampling of the
+    first 100 000 records stays pinned by restatement only).
+The FASTQ comments are also fed through the `aln` step's own parser (the wire-format contract)."""
 import os
 import struct
 import subprocess
@@ -192,3 +196,37 @@ def test_position_sorted_mode_finds_the_pairs_of_the_name_sorted_mode(tmp_path, 
     assert b"phase 2:" in b.stderr and b.stdout.count(b"STAT_") == 1
     # both orders see the same first 100 000 primary records only when the file is short: the status line's read length agrees
     assert open(tmp_path / "s1.txt").read().split("_")[1] == open(tmp_path / "s2.txt").read().split("_")[1]
+
+
+REF_CASES = [([], 20240), (["-D"], 20241), (["-U"], 20241), (["-D", "-U", "-I", "22"], 20244)]
+
+
+@pytest.mark.parametrize("flags,seed", REF_CASES)
+def test_signal_step_writes_what_the_reference_function_writes(tmp_path, flags, seed):
+    """Byte for byte, except where the reference's output depends on uninitialised memory: the soft-clip lengths of a record
+    without CIGAR (getSignalRead.cpp:129 with clib/bam_file.c:1033-1034 leaves soft_left / soft_right unset: third token and the
+    clip flag of the comment) and the character get_bam_seq leaves unwritten for a '=' base.  Pairs touched by either are
+    compared by name and length only."""
+    import gzip
+    recs, refs = make_pairs(seed, 600)
+    bam = str(tmp_path / "in.bam")
+    write_bam(bam, recs, refs)
+    got = subprocess.run([CLI, "signal", "-N"] + flags + ["-H", str(tmp_path / "h.sam"), "-S", str(tmp_path / "s.txt"), bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()[-2000:]
+    name = "pairs%d%s" % (seed, "".join(f.replace("-", "_") for f in flags))
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "signal", name + ".fq.gz"), "rb") as f:
+        want = f.read()
+    a, b = got.stdout.split(b"\n"), want.split(b"\n")
+    assert len(a) == len(b) and len(a) > 3000
+    exact = undefined = 0
+    for k in range(0, len(a) - 1, 8):
+        pa, pb = a[k:k + 8], b[k:k + 8]
+        ub = any(b"CIGAR__" in l for l in (pb[0], pb[4])) or len(pa[1]) != len(pb[1]) or len(pa[5]) != len(pb[5]) or got.stderr.count(b"Wrong base!") and (pa[1] != pb[1] or pa[5] != pb[5])
+        if ub:
+            undefined += 1
+            assert pa[0].split(b" ")[0] == pb[0].split(b" ")[0] and pa[4].split(b" ")[0] == pb[4].split(b" ")[0]
+            assert pa[3] == pb[3] or len(pa[3]) + 1 == len(pb[3])          # qualities are defined either way
+            continue
+        assert pa == pb, "pair at line %d differs:\n%r\n%r" % (k, pa, pb)
+        exact += 1
+    assert exact > 4 * undefined and exact > 350
