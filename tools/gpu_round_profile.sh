@@ -1,11 +1,19 @@
 set -e
+# Evidence of one round: kernel-trace stats + per-kernel PMC counters of the bench command (separate --pmc passes, no trace domains
+# besides --kernel-trace).  usage (on the GPU box): bash tools/gpu_round_profile.sh <tag>   ->  gpurun_out/<tag>/
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01n
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $R/gpurun_out/r01n/tests.log 2>&1
-tail -3 $R/gpurun_out/r01n/tests.log
-timeout -k 10 400 python bench.py > $R/gpurun_out/r01n/bench.json 2> $R/gpurun_out/r01n/bench.err
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+B="--cpu-pairs 0 --check-pairs 0 --no-e2e --no-cfg5"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01n/ks -o ks -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-pairs 0 > $R/gpurun_out/r01n/ks.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r01n/pf -o pf -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-pairs 0 > $R/gpurun_out/r01n/pf.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r01n/pw -o pw -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-pairs 0 > $R/gpurun_out/r01n/pw.log 2>&1
-ls -R $R/gpurun_out/r01n | head -40
+rocprofv3 -L > $O/counters_available.txt 2>&1 || true
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --steps 2 --warmup 1 $B > $O/ks.log 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" \
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p$i -- python3 $R/bench.py --steps 1 --warmup 0 $B > $O/p$i.log 2>&1 || { echo "pmc set $i failed"; tail -n 5 $O/p$i.log; }
+done
+find $O -name "*.csv" | head -20
