@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-ref-cpu", action="store_true", help="time only the oracle port even if oracle/_ref/ref_aln is present")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `panSVR aln` leg")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the configs[4] (250 bp / edge-2000) leg")
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("PSVR_BENCH_ENGINES", "2")),
+                    help="engines per GPU: the rank's block is cut into that many contiguous sub-blocks, each run by its own engine on its own HIP queue (1 = one engine)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU-baseline leg (0 = all cores, capped at the reference's 48)")
     args = ap.parse_args()
 
@@ -129,8 +131,16 @@ def main():
             del buf
         except Exception as ex:      # the measurement is optional
             index_bcast = "failed: %r" % (ex,)
-    eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
-    eng.upload(bases, base_off, ori)
+    from pansvr_amd import dist as pdist
+    K = max(1, args.engines)
+    cuts = [args.pairs * j // K for j in range(K + 1)]
+    engs = []
+    for j in range(K):
+        e = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
+        lo, hi = cuts[j], cuts[j + 1]
+        e.upload(bases[base_off[2 * lo]:base_off[2 * hi]], base_off[2 * lo:2 * hi + 1] - base_off[2 * lo], ori[2 * lo:2 * hi])
+        engs.append(e)
+    group = pdist.EngineGroup(engs)
     index_device_bytes = index.device_bytes
     t_setup = time.time() - t_setup
 
@@ -139,27 +149,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from pansvr_amd import dist as pdist
-
     exchange_iters = []
     my_start = [2, 0, 0]
 
     def step():
         nonlocal my_start
         if world == 1:
-            eng.run()
+            group.run_at([2, 0, 0])
             return
-
-        def run_at(pos):
-            eng.set_stream_pos(pos)
-            eng.run()
-            return eng.stream_end()
-
-        def rebase_to(pos):
-            eng.rebase(pos)
-            return eng.stream_end()
-
-        my_start, _, it = pdist.resolve_stream_order([2, 0, 0], run_at, rebase_to, device=xdev)
+        my_start, _, it = pdist.resolve_stream_order([2, 0, 0], group.run_at, group.rebase_to, device=xdev)
         exchange_iters.append(it)
 
     for _ in range(args.warmup):
@@ -181,10 +179,18 @@ def main():
     parity_local = None
     if n_chk > 0 and (have_ref or os.path.exists(os.path.join(ROOT, "oracle", "aln_oracle"))):
         import aln_common as ac
-        reads_o, pairs_o, cig_o = eng.download()
         lens = np.diff(base_off)
-        got = ac.engine_records(reads_o, pairs_o, cig_o, ori, lens, 0, n_chk)
-        del reads_o, pairs_o, cig_o
+        got = []
+        for j, e in enumerate(engs):                      # the sub-blocks in order = the block
+            lo, hi = cuts[j], cuts[j + 1]
+            if lo >= n_chk:
+                break
+            reads_o, pairs_o, cig_o = e.download()
+            part = ac.engine_records(reads_o, pairs_o, cig_o, ori[2 * lo:2 * hi], lens[2 * lo:2 * hi], 0, min(hi, n_chk) - lo)
+            for q, rec in enumerate(part):
+                rec["i"] = lo + q
+            got += part
+            del reads_o, pairs_o, cig_o
         base = [idx_dir, fq, os.path.join(tmp, "header.sam")]
         if have_ref:
             cmd = [ref_exe, "-t", "1", "-R", str(n_chk)] + base + ["--quiet", "--stream-pos", ",".join(str(x) for x in my_start)]
@@ -209,8 +215,17 @@ def main():
     elif parity_local:
         parity = {"pairs_checked": parity_local[0], "pairs_differing": parity_local[1], "ranks_checked": 1, "against": parity_local[2]}
 
-    # two extra passes (not timed above): per-kernel HIP-event durations on the launch stream, then the work
-    # counters (their atomics would distort the timings)
+    # two extra passes (not timed above) on ONE engine over the whole block: per-kernel HIP-event durations on the launch stream, then
+    # the work counters (their atomics would distort the timings)
+    group_rebases = group.rebases
+    if K > 1:
+        for e in engs:
+            e.close()
+        eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
+        eng.upload(bases, base_off, ori)
+        eng.run()
+    else:
+        eng = engs[0]
     eng.run(timing=True)
     kern = eng.stats()["kernels"]
     eng.run(stats=True)
@@ -362,7 +377,8 @@ def main():
                 "data": "synthetic", "config": {"workload": "configs[1]: %d synthetic 150 bp PE signal read pairs per GPU vs %d-anchor SV reference (%.1f Mbp), `panSVR aln` hot path"
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step,
-                                                 "parallelism": "shard%d (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, "none" if world == 1 else "all-gather of 3 int64 per rank over %s, %d iteration(s)/step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
+                                                 "parallelism": "shard%d x %d engine(s) per GPU (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, K, "none" if world == 1 else "all-gather of 3 int64 per rank over %s, %d iteration(s)/step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
+                                                 "engines_per_gpu": K, "in_process_rebases": group_rebases,
                                                  "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,

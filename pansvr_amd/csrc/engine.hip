@@ -1273,6 +1273,9 @@ struct psvr_engine {
 	DevBuf full_out, cmp_cnt_c, cmp_cnt_w, cmp_off_c, cmp_off_w, cmp_hdr, cmp_cand, cmp_cig;
 	bool compact_valid = false;
 	long long compact_nc = 0, compact_nw = 0;
+	// the engine's own queue (non-blocking: engines of one process, on one device or several, run beside each other); a caller's
+	// stream, when psvr_engine_run / _rebase is given one, takes its place for that call
+	hipStream_t own = nullptr;
 	explicit psvr_engine(const psvr_index *i) : ix(i), core(be) {}
 };
 
@@ -1283,6 +1286,8 @@ extern "C" int psvr_engine_create(const psvr_index_t *ix, const psvr_aln_params_
 	if (!ix || !par || !out) return set_error(PSVR_ERR_ARG, "psvr_engine_create: null argument");
 	PSVR_HIP(hipSetDevice(ix->device));
 	psvr_engine *e = new psvr_engine(ix);
+	if (hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking) != hipSuccess) e->own = nullptr;     // (the default queue then)
+	e->be.stream = e->own;
 	e->core.init(ix->dev, *par);
 	*out = e;
 	return PSVR_OK;
@@ -1293,6 +1298,7 @@ extern "C" void psvr_engine_destroy(psvr_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->ix->device);
 	e->core.free_all();
+	if (e->own) (void)hipStreamSynchronize(e->own), (void)hipStreamDestroy(e->own);
 	delete e;
 }
 
@@ -1307,6 +1313,7 @@ extern "C" int psvr_engine_upload(psvr_engine_t *e, int64_t n_pairs, const char 
 {
 	if (!e || n_pairs < 0 || (n_pairs && (!bases || !base_off || !ori))) return set_error(PSVR_ERR_ARG, "psvr_engine_upload: bad argument");
 	PSVR_HIP(hipSetDevice(e->ix->device));
+	e->be.stream = e->own;
 	if (!e->committed) { e->core.commit(); e->committed = true; }
 	e->compact_valid = false;
 	int rc = e->core.upload(n_pairs, bases, base_off, ori);
@@ -1317,7 +1324,7 @@ extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
 {
 	if (!e) return set_error(PSVR_ERR_ARG, "psvr_engine_run: null engine");
 	PSVR_HIP(hipSetDevice(e->ix->device));
-	e->be.stream = (hipStream_t)stream;
+	e->be.stream = stream ? (hipStream_t)stream : e->own;
 	e->be.timing = (trace & 4) != 0;
 	e->be.timed.clear();
 	e->compact_valid = false;
@@ -1353,7 +1360,7 @@ extern "C" int psvr_engine_rebase(psvr_engine_t *e, const int64_t pos[3], void *
 {
 	if (!e || !pos) return set_error(PSVR_ERR_ARG, "psvr_engine_rebase: null argument");
 	PSVR_HIP(hipSetDevice(e->ix->device));
-	e->be.stream = (hipStream_t)stream;
+	e->be.stream = stream ? (hipStream_t)stream : e->own;
 	e->compact_valid = false;
 	int rc = e->core.rebase(pos[0], pos[1], pos[2], e->core.c.trace, false);
 	hipError_t s = hipStreamSynchronize(e->be.stream);
@@ -1374,9 +1381,10 @@ extern "C" int psvr_engine_download(psvr_engine_t *e, psvr_read_result_t *reads,
 	if (reads) {
 		// the engine keeps compact headers + a candidate list; the fixed 12-slot records are built here, on request
 		PSVR_HIP(e->full_out.ensure((size_t)c.R * sizeof(psvr_read_result_t)));
-		hipLaunchKernelGGL(k_materialize, dim3(grid_for(c.R)), dim3(kBlock), 0, nullptr, c.c, c.R, e->full_out.as<psvr_read_result_t>());
+		hipLaunchKernelGGL(k_materialize, dim3(grid_for(c.R)), dim3(kBlock), 0, e->own, c.c, c.R, e->full_out.as<psvr_read_result_t>());
 		PSVR_HIP(hipGetLastError());
-		PSVR_HIP(hipMemcpy(reads, e->full_out.p, c.R * sizeof(psvr_read_result_t), hipMemcpyDeviceToHost));
+		PSVR_HIP(hipMemcpyAsync(reads, e->full_out.p, c.R * sizeof(psvr_read_result_t), hipMemcpyDeviceToHost, e->own));
+		PSVR_HIP(hipStreamSynchronize(e->own));
 	}
 	if (pairs) PSVR_HIP(hipMemcpy(pairs, c.c.pres, c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost));
 	if (cigar && top) PSVR_HIP(hipMemcpy(cigar, c.c.cig.base, top * 4, hipMemcpyDeviceToHost));
@@ -1392,20 +1400,21 @@ extern "C" int psvr_engine_download_compact(psvr_engine_t *e, psvr_read_hdr_t *h
 	if (c.P == 0) { if (cand_used) *cand_used = 0; if (cigar_used) *cigar_used = 0; return PSVR_OK; }
 	const long long R = c.R;
 	if (!e->compact_valid) {
-		e->be.stream = nullptr;
+		e->be.stream = e->own;
 		PSVR_HIP(e->cmp_cnt_c.ensure((size_t)(R + 1) * 4)); PSVR_HIP(e->cmp_cnt_w.ensure((size_t)(R + 1) * 4));
 		PSVR_HIP(e->cmp_off_c.ensure((size_t)(R + 2) * 8)); PSVR_HIP(e->cmp_off_w.ensure((size_t)(R + 2) * 8));
-		hipLaunchKernelGGL(k_compact_count, dim3(grid_for(R + 1)), dim3(kBlock), 0, nullptr, c.c, R, e->cmp_cnt_c.as<int32_t>(), e->cmp_cnt_w.as<int32_t>());
+		hipLaunchKernelGGL(k_compact_count, dim3(grid_for(R + 1)), dim3(kBlock), 0, e->own, c.c, R, e->cmp_cnt_c.as<int32_t>(), e->cmp_cnt_w.as<int32_t>());
 		e->be.st_scan(e->cmp_cnt_c.as<int32_t>(), R + 1, 1, 0, 0ll, e->cmp_off_c.as<long long>());
 		e->be.st_scan(e->cmp_cnt_w.as<int32_t>(), R + 1, 1, 0, 0ll, e->cmp_off_w.as<long long>());
 		PSVR_HIP(hipGetLastError());
 		long long tot[2] = {0, 0};
-		PSVR_HIP(hipMemcpy(&tot[0], e->cmp_off_c.as<long long>() + R, 8, hipMemcpyDeviceToHost));
-		PSVR_HIP(hipMemcpy(&tot[1], e->cmp_off_w.as<long long>() + R, 8, hipMemcpyDeviceToHost));
+		PSVR_HIP(hipMemcpyAsync(&tot[0], e->cmp_off_c.as<long long>() + R, 8, hipMemcpyDeviceToHost, e->own));
+		PSVR_HIP(hipMemcpyAsync(&tot[1], e->cmp_off_w.as<long long>() + R, 8, hipMemcpyDeviceToHost, e->own));
+		PSVR_HIP(hipStreamSynchronize(e->own));
 		PSVR_HIP(e->cmp_hdr.ensure((size_t)R * sizeof(psvr_read_hdr_t)));
 		PSVR_HIP(e->cmp_cand.ensure((size_t)(tot[0] + 1) * sizeof(psvr_cand_t)));
 		PSVR_HIP(e->cmp_cig.ensure((size_t)(tot[1] + 1) * 4));
-		hipLaunchKernelGGL(k_compact_copy, dim3(grid_for(R, kBlock / 16)), dim3(kBlock), 0, nullptr, c.c, R, (const long long *)e->cmp_off_c.p, (const long long *)e->cmp_off_w.p,
+		hipLaunchKernelGGL(k_compact_copy, dim3(grid_for(R, kBlock / 16)), dim3(kBlock), 0, e->own, c.c, R, (const long long *)e->cmp_off_c.p, (const long long *)e->cmp_off_w.p,
 		                   e->cmp_hdr.as<psvr_read_hdr_t>(), e->cmp_cand.as<psvr_cand_t>(), e->cmp_cig.as<uint32_t>());
 		PSVR_HIP(hipGetLastError());
 		e->compact_nc = tot[0], e->compact_nw = tot[1], e->compact_valid = true;
@@ -1414,11 +1423,11 @@ extern "C" int psvr_engine_download_compact(psvr_engine_t *e, psvr_read_hdr_t *h
 	if (cigar_used) *cigar_used = e->compact_nw;
 	if ((cands && e->compact_nc > cand_cap) || (cigar && e->compact_nw > cigar_cap))
 		return set_error(PSVR_ERR_OVERFLOW, "compact download: need %lld candidates / %lld cigar words", e->compact_nc, e->compact_nw);
-	if (hdr) PSVR_HIP(hipMemcpyAsync(hdr, e->cmp_hdr.p, (size_t)R * sizeof(psvr_read_hdr_t), hipMemcpyDeviceToHost, nullptr));
-	if (pairs) PSVR_HIP(hipMemcpyAsync(pairs, c.c.pres, (size_t)c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost, nullptr));
-	if (cands && e->compact_nc) PSVR_HIP(hipMemcpyAsync(cands, e->cmp_cand.p, (size_t)e->compact_nc * sizeof(psvr_cand_t), hipMemcpyDeviceToHost, nullptr));
-	if (cigar && e->compact_nw) PSVR_HIP(hipMemcpyAsync(cigar, e->cmp_cig.p, (size_t)e->compact_nw * 4, hipMemcpyDeviceToHost, nullptr));
-	PSVR_HIP(hipStreamSynchronize(nullptr));
+	if (hdr) PSVR_HIP(hipMemcpyAsync(hdr, e->cmp_hdr.p, (size_t)R * sizeof(psvr_read_hdr_t), hipMemcpyDeviceToHost, e->own));
+	if (pairs) PSVR_HIP(hipMemcpyAsync(pairs, c.c.pres, (size_t)c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost, e->own));
+	if (cands && e->compact_nc) PSVR_HIP(hipMemcpyAsync(cands, e->cmp_cand.p, (size_t)e->compact_nc * sizeof(psvr_cand_t), hipMemcpyDeviceToHost, e->own));
+	if (cigar && e->compact_nw) PSVR_HIP(hipMemcpyAsync(cigar, e->cmp_cig.p, (size_t)e->compact_nw * 4, hipMemcpyDeviceToHost, e->own));
+	PSVR_HIP(hipStreamSynchronize(e->own));
 	return PSVR_OK;
 }
 

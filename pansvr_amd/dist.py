@@ -48,3 +48,66 @@ def resolve_stream_order(first_pos, run_at, rebase_to, device=None, max_iter=16)
             start = new_start
             end = rebase_to(start)
         it += 1
+
+
+class EngineGroup:
+    """Several engines of ONE process that share a block of pairs (on one device: the stages of the path are latency / issue bound, so
+    two or three engines running beside each other on their own HIP queues fill the chip better than one; or one per device).  Engine j
+    owns the j-th contiguous sub-block; run_at / rebase_to give the group the interface resolve_stream_order expects of one engine:
+    inside the group the same draw-order rule holds -- engine j starts where engine j-1 ended."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self.starts = [[2, 0, 0] for _ in self.engines]
+        self.rebases = 0
+
+    def _parallel(self, fns):
+        import threading
+        if len(fns) == 1:
+            fns[0]()
+            return
+        err = []
+
+        def wrap(f):
+            try:
+                f()
+            except Exception as ex:      # surfaced on the calling thread
+                err.append(ex)
+        th = [threading.Thread(target=wrap, args=(f,)) for f in fns[1:]]
+        for t in th:
+            t.start()
+        wrap(fns[0])
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+
+    def _resolve(self, pos):
+        pos = [int(x) for x in pos]
+        for it in range(64):
+            ends = [e.stream_end() for e in self.engines]
+            acc, moved = list(pos), []
+            for j, e in enumerate(self.engines):
+                used = [ends[j][k] - self.starts[j][k] for k in range(3)]
+                if self.starts[j] != acc:
+                    self.starts[j] = list(acc)
+                    moved.append(j)
+                acc = [acc[k] + used[k] for k in range(3)]
+            if not moved:
+                return ends[-1]
+            self.rebases += len(moved)
+            self._parallel([(lambda j=j: self.engines[j].rebase(self.starts[j])) for j in moved])
+        raise RuntimeError("draw-order resolution inside the engine group did not converge")
+
+    def run_at(self, pos):
+        pos = [int(x) for x in pos]
+
+        def one(e):
+            e.set_stream_pos(pos)
+            e.run()
+        self.starts = [list(pos) for _ in self.engines]
+        self._parallel([(lambda e=e: one(e)) for e in self.engines])
+        return self._resolve(pos)
+
+    def rebase_to(self, pos):
+        return self._resolve(pos)
