@@ -1322,8 +1322,12 @@ PSVR_HD void adopt_variant(const Ctx &c, long long pair, long long slot, const l
 // rr.cpp:920-928)
 PSVR_HD void dp_fetch_base(const Ctx &c, const DpDesc &d, int i, uint8_t *q, uint8_t *t)
 {
-	const uint8_t *src = c.bin + ((long long)d.read * 2 + d.strand) * c.lmax + d.q_st;
-	if (i < d.qlen) q[i] = d.type == 0 ? src[d.qlen - 1 - i] : src[i];
+	if (i < d.qlen) {
+		const int qi = d.q_st + (d.type == 0 ? d.qlen - 1 - i : i);
+		// the read's bases from its 2-bit words; the byte form exists only for reads with a lower-case 'n' (code 4 does not fit two bits)
+		if (c.has_n4[d.read]) q[i] = c.bin[((long long)d.read * 2 + d.strand) * c.lmax + qi];
+		else q[i] = (uint8_t)base_at(c.rb + ((long long)d.read * 2 + d.strand) * c.wmax, (uint64_t)qi);
+	}
 	if (i < d.tlen) t[i] = (uint8_t)base_at(c.idx.ref_seq, (uint64_t)d.ref_st + (d.type == 0 ? d.tlen - 1 - i : i));
 }
 PSVR_HD void dp_fetch_one(const Ctx &c, const DpDesc &d, uint8_t *q, uint8_t *t)

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 		}
 		draws += __popcll(m);
 		const uint8_t code = lut[ch & 0x7f];                                   // input is 7-bit ASCII
-		if (i < L) fw[i] = code, rv[L - 1 - i] = code ^ 3, b0[i] = code, b1[L - 1 - i] = code ^ 3;
+		if (i < L) fw[i] = code, rv[L - 1 - i] = code ^ 3;
 		else if (i < c.lmax) fw[i] = 0, rv[i] = 0;
 		any4 |= __ballot(i < L && code > 3) != 0;
 	};
@@ -94,6 +94,9 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	for (int i0 = 256; i0 < c.lmax; i0 += 64) round(i0, i0 + lane < L ? s[i0 + lane] : 'A');
 	if (lane == 0) c.has_n4[read] = any4;
 	__builtin_amdgcn_wave_barrier();
+	// the per-base byte form of both strands is only needed where the 2-bit words cannot hold the read: a lower-case 'n' (code 4).
+	// Every other consumer (mismatch counts, DP query bytes) reads the packed words, so 2 x lmax bytes per read stay unwritten.
+	if (any4) for (int i = lane; i < L; i += 64) b0[i] = fw[i], b1[i] = rv[i];
 	// packed words of both strands (binary_read_64_bit, rr.cpp:295-300): word = OR of code << 2*(31 - (i & 31)).  One lane per
 	// word: four codes (one per byte of a 32-bit LDS word) are gathered MSB-first into eight bits by one multiply.
 	for (int j = lane; j < 2 * c.wmax; j += 64) {
@@ -657,9 +660,23 @@ struct GpuBE {
 	void *pin = nullptr;
 	static constexpr size_t kPin = (size_t)4 << 20, kPinUse = kPin - 4096;   // the last 4 KB are st_dp's slot for an upload nobody waits for
 	void *pinned() { if (!pin && hipHostMalloc(&pin, kPin, hipHostMallocDefault) != hipSuccess) pin = nullptr; return pin; }
+	// Small uploads do not wait: they are staged in a ring of page-locked memory and ride the stream in order.  A slot is reused only
+	// after kUp bytes of later uploads, and every round of the engine synchronises the stream several times in between (its readbacks),
+	// so the copy out of a slot has long finished when the ring comes round; an upload that would not fit the ring's free span waits.
+	void *up_ring = nullptr;
+	static constexpr size_t kUp = (size_t)8 << 20;
+	size_t up_pos = 0, up_since_sync = 0;
 	void h2d(void *d, const void *h, size_t n)
 	{
-		if (n && n <= kPinUse && pinned()) { memcpy(pin, h, n); note(hipMemcpyAsync(d, pin, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); return; }
+		if (n && n <= kUp / 4 && (up_ring || hipHostMalloc(&up_ring, kUp, hipHostMallocDefault) == hipSuccess)) {
+			const size_t need = (n + 255) & ~(size_t)255;
+			if (up_since_sync + need > kUp / 2) { note(hipStreamSynchronize(stream)); up_since_sync = 0; }
+			if (up_pos + need > kUp) up_pos = 0;
+			memcpy((char *)up_ring + up_pos, h, n);
+			note(hipMemcpyAsync(d, (char *)up_ring + up_pos, n, hipMemcpyHostToDevice, stream));
+			up_pos += need, up_since_sync += need;
+			return;
+		}
 		note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream));
 	}
 	void d2h(void *h, const void *d, size_t n)
@@ -682,6 +699,7 @@ struct GpuBE {
 	~GpuBE()
 	{
 		if (pin) (void)hipHostFree(pin);
+		if (up_ring) (void)hipHostFree(up_ring);
 		for (int i = 0; i < kSide; ++i) {
 			if (side[i]) (void)hipStreamSynchronize(side[i]), (void)hipStreamDestroy(side[i]);
 			if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
