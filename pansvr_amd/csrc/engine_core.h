@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 #include "aln_device.h"
 
@@ -193,26 +194,39 @@ template <class BE> struct EngineCore {
 		c.n_pairs = P;
 		int lm = (lmax + 31) & ~31;
 		if (lm < 32) lm = 32;
-		// pairs whose reads will draw for 1..3 N bases (early-out reads draw nothing: rr.cpp:414 returns first)
+		// pairs whose reads will draw for 1..3 N bases (early-out reads draw nothing: rr.cpp:414 returns first).  The scan reads every base
+		// once: on a few host threads for a large batch (it was a third of an upload's wall on one).
 		special.clear();
 		V = 0;
-		for (long long p = 0; p < P; ++p) {
-			int nn[2];
-			for (int k = 0; k < 2; ++k) {
-				long long r = 2 * p + k;
-				const char *b = bases + base_off[r];
-				long long L = base_off[r + 1] - base_off[r];
-				int n = 0;
-				for (const char *q = (const char *)memchr(b, 'N', L); q; q = (const char *)memchr(q + 1, 'N', b + L - (q + 1))) ++n;
-				bool unm = ori[r].unmapped || (uint32_t)ori[r].chr_id > 24u;
-				if ((!unm && ori[r].align_score == (uint32_t)(L * c.par.match)) || L < kLenKmer) n = 0;
-				nn[k] = n;
-			}
-			if (nn[0] + nn[1] >= 1 && nn[0] + nn[1] <= 3) {
-				Special sp{(int32_t)p, (uint8_t)nn[0], (uint8_t)nn[1], (int32_t)(P + V), 1 << (2 * (nn[0] + nn[1]))};
-				special.push_back(sp);
-				V += sp.nvar;
-			}
+		{
+			auto n_of = [&](long long p, int *nn) {
+				for (int k = 0; k < 2; ++k) {
+					const long long r = 2 * p + k;
+					const char *b = bases + base_off[r];
+					const long long L = base_off[r + 1] - base_off[r];
+					int n = 0;
+					for (const char *q = (const char *)memchr(b, 'N', L); q; q = (const char *)memchr(q + 1, 'N', b + L - (q + 1))) ++n;
+					const bool unm = ori[r].unmapped || (uint32_t)ori[r].chr_id > 24u;
+					if ((!unm && ori[r].align_score == (uint32_t)(L * c.par.match)) || L < kLenKmer) n = 0;
+					nn[k] = n;
+				}
+			};
+			const int nt = P >= 200000 ? 8 : 1;
+			std::vector<std::vector<Special>> part((size_t)nt);
+			auto scan = [&](int t) {
+				const long long p0 = P * t / nt, p1 = P * (t + 1) / nt;
+				for (long long p = p0; p < p1; ++p) {
+					int nn[2];
+					n_of(p, nn);
+					if (nn[0] + nn[1] >= 1 && nn[0] + nn[1] <= 3) part[(size_t)t].push_back(Special{(int32_t)p, (uint8_t)nn[0], (uint8_t)nn[1], 0, 1 << (2 * (nn[0] + nn[1]))});
+				}
+			};
+			std::vector<std::thread> th;
+			for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
+			scan(0);
+			for (std::thread &t : th) t.join();
+			for (auto &v : part)
+				for (Special sp : v) { sp.vslot = (int32_t)(P + V); special.push_back(sp); V += sp.nvar; }
 		}
 		const long long shadow_cap = P / 16 + 8192;
 		S = P + V + shadow_cap;
