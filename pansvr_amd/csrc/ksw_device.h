@@ -78,7 +78,8 @@ __host__ __device__ inline int dp_team_lanes(int n_strips16) { return PSVR_DP_TE
 __host__ __device__ inline unsigned long long dp_team_ws_bytes(int qmax, int n_strips16, int lanes)
 {
 	const int sw = 4 * lanes, pb = 64 / lanes, n_strips = (n_strips16 * 16 + sw - 1) / sw;
-	return (unsigned long long)256 * n_strips * (qmax + sw - 1) + (unsigned long long)pb * 28 * (qmax + sw * n_strips + 1);
+	// direction dwords, then per diagonal and alignment: two boundary dwords (ping-pong) + D, D2, D3
+	return (unsigned long long)256 * n_strips * (qmax + sw - 1) + (unsigned long long)pb * 20 * (qmax + sw * n_strips + 1);
 }
 
 // true when the band [(r-w+1)>>1, (r+w)>>1] never clips the DP matrix: then st0/en0 follow the matrix edges only, every

@@ -535,11 +535,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	// Every scratch address is a wave-uniform base (scalar registers) plus a constant 32-bit lane offset, so a step spends no
 	// vector instruction on addresses: direction dwords of strip s, step k at [(s * R + k) * 64 + lane]; strip-boundary values
 	// (8 bytes) and the per-diagonal records D, D2, D3 (4 bytes) of diagonal r at [r * PB + team].
-	uint8_t *const uE0 = w0 + offE, *const uE1 = w0 + offE + (size_t)8 * PB * NR;
-	uint8_t *const uD = w0 + offE + (size_t)16 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
-	const unsigned l4 = 4u * (unsigned)lane, t4 = 4u * (unsigned)team, t8 = 8u * (unsigned)team;
+	// (a boundary record is one dword: v, x, x2 are multiples of 8 plus a constant tag and fit int8 once divided, see the step)
+	uint8_t *const uE0 = w0 + offE, *const uE1 = w0 + offE + (size_t)4 * PB * NR;
+	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
+	const unsigned l4 = 4u * (unsigned)lane, t4 = 4u * (unsigned)team;
 	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
-	auto at8 = [=](uint8_t *ub, int r) -> uint2 & { return *(uint2 *)(ub + (size_t)r * (8 * PB) + t8); };
 	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	const int n_rows = qlen + tlen - 1;
@@ -586,10 +586,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		uint8_t *const Ein = (s & 1) ? uE0 : uE1, *const Eout = (s & 1) ? uE1 : uE0;
 		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
 		// loaded one step ahead, so the loads have a whole step to arrive
-		uint2 e_prev = make_uint2(0, 0);
+		unsigned e_prev = 0;
 		int d_cur = kNone;
 		if (s > 0) {
-			e_prev = at8(Ein, c0 - 1);
+			e_prev = (unsigned)at4(Ein, c0 - 1);
 			if (0 <= qlen - 2) d_cur = at4(uD, c0);
 		}
 		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? query[0 - jb] : 0u;   // query[k - jb] for k = 0 (raw byte: masking it here would wait for the load)
