@@ -282,10 +282,11 @@ int main(int argc, char **argv)
 	psvr_aln_params_default(&par);
 	par.match = o.match, par.mismatch = o.mismatch, par.gap_open = o.gap_open, par.gap_ex = o.gap_ex, par.gap_open2 = o.gap_open2, par.gap_ex2 = o.gap_ex2, par.zdrop = o.zdrop;
 	std::vector<psvr_engine_t *> eng((size_t)D, nullptr);
-	// classify_pipeline's three overlapped steps (rr.cpp:100-131, kt_pipeline): load_reads | align | output_results.  Three job
+	// classify_pipeline's overlapped steps (rr.cpp:100-131, kt_pipeline): load_reads | align | output_results -- the last one as two
+	// stages here, format | write, because formatting (or BGZF deflate) and the file write each take about as long as the parse.  Job
 	// slots cycle through the stages in input order, so the output order is the input order.  A slot keeps its buffers (like the
-	// reference's Classify_buff_pool): the raw text + line index of its batch, the page-locked upload arrays, and per device the
-	// page-locked compact results.
+	// reference's Classify_buff_pool): the raw text + line index of its batch, the page-locked upload arrays, per device the
+	// page-locked compact results, and the formatted records.
 	struct Block {                       // the share of one device
 		long long lo = 0, hi = 0;
 		HostBuf hdr_buf, pair_buf, cand_buf, cig_buf;
@@ -296,10 +297,12 @@ int main(int argc, char **argv)
 		FastqBatch fb;
 		std::vector<Block> blk;
 		long long pair_base = 0;
-		int state = 0;              // 0 free, 1 loaded, 2 aligned
+		std::vector<std::vector<uint8_t>> mb, ob;   // formatted records of both files, per chunk of pairs
+		int state = 0;              // 0 free, 1 loaded, 2 aligned, 3 formatted
 		bool last = false;          // end-of-input marker travelling through the stages
 	};
-	Job jobs[3];
+	const int kSlots = 5;
+	Job jobs[kSlots];
 	for (Job &J : jobs) J.blk = std::vector<Block>((size_t)D);
 	std::mutex mu;
 	std::condition_variable cv;
@@ -312,7 +315,7 @@ int main(int argc, char **argv)
 	EmitStats emit_stats;
 	std::thread reader([&]() {
 		long long loaded = 0, pair_base = 0;
-		for (int slot = 0;; slot = (slot + 1) % 3) {
+		for (int slot = 0;; slot = (slot + 1) % kSlots) {
 			Job &J = jobs[slot];
 			wait_state(J, 0);
 			long long want = o.batch_pairs;
@@ -331,11 +334,11 @@ int main(int argc, char **argv)
 	svn.idx = idx[0];
 	SamEmitter em;
 	em.H = &H, em.sv = &svn, em.as_bam = !o.sam, em.not_ori = o.not_ori, em.stats = &emit_stats;
-	std::thread writer([&]() {
-		for (int slot = 0;; slot = (slot + 1) % 3) {
+	std::thread formatter([&]() {
+		for (int slot = 0;; slot = (slot + 1) % kSlots) {
 			Job &J = jobs[slot];
 			wait_state(J, 2);
-			if (J.last) return;
+			if (J.last) { set_state(J, 3); return; }
 			const long long P = J.fb.n_pairs();
 			double tw = walltime();
 			fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
@@ -350,7 +353,10 @@ int main(int argc, char **argv)
 			}
 			// ---- step 2: records of both files, formatted for runs of pairs on -t threads and written in input order
 			const long long chunk = 4096, nchunk = (P + chunk - 1) / chunk;
-			std::vector<std::vector<uint8_t>> mb((size_t)nchunk), ob((size_t)nchunk);
+			std::vector<std::vector<uint8_t>> &mb = J.mb, &ob = J.ob;
+			mb.resize((size_t)nchunk), ob.resize((size_t)nchunk);
+			for (auto &v : mb) v.clear();
+			for (auto &v : ob) v.clear();
 			std::atomic<long long> next(0);
 			auto work = [&]() {
 				for (long long ci = next++; ci < nchunk; ci = next++) {
@@ -366,15 +372,24 @@ int main(int argc, char **argv)
 			for (int t = 1; t < o.thread_n && t < nchunk; ++t) th.emplace_back(work);
 			work();
 			for (std::thread &t : th) t.join();
-			t_format += walltime() - tw, tw = walltime();
-			for (long long ci = 0; ci < nchunk; ++ci) fo.write_raw(mb[(size_t)ci]), fo_ori.write_raw(ob[(size_t)ci]);
+			t_format += walltime() - tw;
+			set_state(J, 3);
+		}
+	});
+	std::thread writer([&]() {
+		for (int slot = 0;; slot = (slot + 1) % kSlots) {
+			Job &J = jobs[slot];
+			wait_state(J, 3);
+			if (J.last) return;
+			const double tw = walltime();
+			for (size_t ci = 0; ci < J.mb.size(); ++ci) fo.write_raw(J.mb[ci]), fo_ori.write_raw(J.ob[ci]);
 			t_write += walltime() - tw;
 			set_state(J, 0);
 		}
 	});
 	// ---- step 1: the engine(s)
 	int64_t pos[3] = {0, 0, 0};                          // where the next batch starts in the three draw streams
-	for (int slot = 0;; slot = (slot + 1) % 3) {
+	for (int slot = 0;; slot = (slot + 1) % kSlots) {
 		Job &J = jobs[slot];
 		wait_state(J, 1);
 		if (J.last) { set_state(J, 2); break; }
@@ -465,7 +480,7 @@ int main(int argc, char **argv)
 		t_engine += walltime() - tw;
 		set_state(J, 2);
 	}
-	reader.join(), writer.join();
+	reader.join(), formatter.join(), writer.join();
 	if (sig_thread.joinable()) {
 		sig_thread.join();
 		if (sig_rc) { fprintf(stderr, "[panSVR-amd] the signal step failed\n"); abort(); }
