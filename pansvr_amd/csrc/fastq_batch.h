@@ -220,6 +220,7 @@ struct FastqBatch {
 class FastqReader {
 	TextSource src_;
 	size_t est_pair_bytes_ = 1024;                   // bytes of text per pair, refined from the previous batch
+	std::vector<int32_t> slen_;                      // scratch: sequence length per candidate read of the batch being cut
 	std::string first_comment_;
 	bool have_first_ = false;
 
@@ -283,17 +284,22 @@ public:
 		size_t nlines = B.ls.size() - 1;
 		if (nlines > want_lines) nlines = want_lines;
 		long long npairs = (long long)(nlines / 8);
+		// sequence length of every candidate read, on the threads (a line's end is a cache miss each: not a loop for one core)
+		std::vector<int32_t> &slen = slen_;
+		slen.resize((size_t)(2 * npairs));
+		parallel_ranges(2 * npairs, threads, [&](long long r0, long long r1) {
+			for (long long r = r0; r < r1; ++r) {
+				const size_t li = (size_t)(4 * r + 1);
+				size_t m = (size_t)(B.ls[li + 1] - B.ls[li]);
+				const char *b = B.text + B.ls[li];
+				while (m > 0 && (b[m - 1] == '\n' || b[m - 1] == '\r')) --m;
+				slen[(size_t)r] = (int32_t)m;
+			}
+		});
 		// the 100 MB limit: load_reads stops BEFORE a pair once the bases loaded so far reach it
 		{
 			long long total = 0, keep = 0;
-			for (long long p = 0; p < npairs && total < max_bases; ++p, ++keep)
-				for (int k = 0; k < 2; ++k) {
-					const size_t li = (size_t)(8 * p + 4 * k + 1);
-					size_t m = (size_t)(B.ls[li + 1] - B.ls[li]);
-					const char *b = B.text + B.ls[li];
-					while (m > 0 && (b[m - 1] == '\n' || b[m - 1] == '\r')) --m;
-					total += (long long)m;
-				}
+			for (long long p = 0; p < npairs && total < max_bases; ++p, ++keep) total += slen[(size_t)(2 * p)] + slen[(size_t)(2 * p + 1)];
 			npairs = keep;
 		}
 		const size_t used = (size_t)B.ls[(size_t)npairs * 8];
@@ -308,7 +314,7 @@ public:
 		B.base_off = (int64_t *)B.off_buf.reserve((size_t)(R + 1) * 8);
 		B.ori = (psvr_ori_t *)B.ori_buf.reserve((size_t)R * sizeof(psvr_ori_t));
 		B.base_off[0] = 0;
-		for (long long r = 0; r < R; ++r) { const char *b; int n; B.seq(r, b, n); B.base_off[r + 1] = B.base_off[r] + n; }
+		for (long long r = 0; r < R; ++r) B.base_off[r + 1] = B.base_off[r] + slen[(size_t)r];
 		B.bases = (char *)B.bases_buf.reserve((size_t)B.base_off[R] + 16);
 		parallel_ranges(R, threads, [&](long long r0, long long r1) {
 			for (long long r = r0; r < r1; ++r) {

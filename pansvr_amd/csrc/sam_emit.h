@@ -98,7 +98,16 @@ public:
 private:
 	static void put(std::vector<uint8_t> &d, const char *p, size_t n) { d.insert(d.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
 	static void put(std::vector<uint8_t> &d, const std::string &s) { put(d, s.data(), s.size()); }
-	static void put_int(std::vector<uint8_t> &d, long long v) { char b[24]; const int n = snprintf(b, sizeof b, "%lld", v); put(d, b, (size_t)n); }
+	static void put_int(std::vector<uint8_t> &d, long long v)          // %lld without the format machinery
+	{
+		char b[24];
+		int n = 24;
+		unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+		do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+		if (v < 0) b[--n] = '-';
+		put(d, b + n, (size_t)(24 - n));
+	}
+	static void put_tag_int(std::vector<uint8_t> &d, const char *tag5, long long v) { put(d, "\t", 1), put(d, tag5, 5), put_int(d, v); }
 	static void cigar_text(const psvr_cand_t &c, const uint32_t *cig, std::string &s)
 	{
 		char b[32];
@@ -243,6 +252,74 @@ public:
 			if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
 			const int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
 			const int isize = direction == 1 ? pr.cur_isize : -pr.cur_isize;
+			if (!as_bam) {
+				// SAM text straight into the output buffer (the string-building path below serves the BAM encoder): same fields, same rules
+				const char *qt, *nt, *ct; int qn, nn, cn;
+				B.qual(r, qt, qn), B.name(r, nt, nn), B.comment(r, ct, cn);
+				const int pos = (int)ref_bg;
+				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
+				if (nn <= 0 || nn > 254 || qn != read_l) { drop("@sam_parse1 ERROR"); continue; }
+				dst.reserve(dst.size() + (size_t)(2 * read_l + nn + cn + 256));
+				put(dst, nt, (size_t)nn), put(dst, "\t", 1), put_int(dst, flag), put(dst, "\t", 1);
+				const std::string &rn = H->names[(size_t)chr_id];
+				put(dst, rn), put(dst, "\t", 1), put_int(dst, pos), put(dst, "\t", 1), put_int(dst, mapq), put(dst, "\t", 1);
+				if (cg.empty()) put(dst, "*", 1); else put(dst, cg);
+				put(dst, "\t", 1);
+				if (rr.has_mate) {
+					const int mp = (int)rr.mate_ref_bg, mc = rr.mate_chr_id;
+					const bool mate_ok = mc >= 0 && mc < (int)H->names.size() && !(mp - 1 < 0);
+					if (!mate_ok) put(dst, "*", 1); else if (mc == chr_id) put(dst, "=", 1); else put(dst, H->names[(size_t)mc]);
+					put(dst, "\t", 1), put_int(dst, mp);
+				} else put(dst, "*\t0", 3);
+				put(dst, "\t", 1), put_int(dst, isize), put(dst, "\t", 1);
+				{   // SEQ through the reverse complement (getReverseStr_char) and htslib's 4-bit code; QUAL through getReverseStr_qual_char
+					const size_t at = dst.size();
+					dst.resize(at + (size_t)(2 * read_l + 1));
+					uint8_t *sq = &dst[at], *ql = sq + read_l + 1;
+					if (direction == 0) {
+						for (int i = 0; i < read_l; ++i) sq[i] = (uint8_t)sam_rc_char(t[read_l - 1 - i]);      // A C G T N only: already what the 4-bit code gives back
+						for (int i = 0; i < read_l; ++i) ql[i] = (uint8_t)qt[read_l - 1 - i];
+						if (!(read_l & 1) && read_l >= 2) ql[read_l / 2 - 1] = (uint8_t)qt[read_l / 2 - 1], ql[read_l / 2] = (uint8_t)qt[read_l / 2];   // loop bound len/2 + 1: the middle pair is swapped back
+					} else {
+						for (int i = 0; i < read_l; ++i) sq[i] = (uint8_t)nt16_char(t[i]);
+						memcpy(ql, qt, (size_t)read_l);
+					}
+					sq[read_l] = '\t';
+				}
+				put_tag_int(dst, "AS:i:", (int)align_score), put_tag_int(dst, "OS:i:", (int)ori.align_score);
+				put(dst, "\tOA:Z:", 6), put_int(dst, ori.chr_id), put(dst, ",", 1), put_int(dst, (int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg)), put(dst, ",", 1);
+				put_int(dst, (int)ori.read_bg), put(dst, ",", 1), put_int(dst, (int)ori.mapq), put(dst, rr.unmapped ? ",U;" : ",M;", 3);
+				if (!is_ori) put_tag_int(dst, "CS:i:", (int)chain_score);
+				const char *svs = sv->print_string(rr.prim_sv_id);
+				if (svs) put(dst, "\tSV:Z:", 6), put(dst, svs, strlen(svs));
+				const char *mvs = rr.has_mate ? sv->print_string(rr.mate_sv_id) : nullptr;
+				if (mvs) put(dst, "\tMV:Z:", 6), put(dst, mvs, strlen(mvs));
+				if (rr.secondary >= 0) {
+					const psvr_cand_t &sc = V.cands[rr.cand_off + rr.secondary];
+					const char *vid = sv->vcf_id(sc.sv_id);
+					put(dst, "\tXA:Z:", 6), put_int(dst, sc.chr_id), put(dst, ",", 1), put_int(dst, (int)sc.ref_bg), put(dst, ",", 1), put_int(dst, (int)sc.read_bg), put(dst, ",", 1);
+					put_int(dst, (int)sc.align_score), put(dst, sc.direction == 1 ? ",F," : ",R,", 3);
+					if (vid) put(dst, vid, strlen(vid)); else put(dst, "*", 1);
+					put(dst, ";", 1);
+				}
+				{   // RC:Z = the comment as parse_ori_mapping_rst leaves it (see rewrite_comment)
+					put(dst, "\tRC:Z:", 6);
+					const size_t at = dst.size();
+					put(dst, ct, (size_t)cn);
+					int32_t cut[10];
+					parse_ori_span(ct, cn, cut);
+					size_t len = (size_t)cn;
+					for (int q = 0; q < 10; ++q) {
+						if (cut[q] < 0) continue;
+						if (cut[q] < cn - 1) dst[at + (size_t)cut[q]] = ',';
+						else if ((size_t)cut[q] < len) len = (size_t)cut[q];
+					}
+					for (size_t i = 0; i < len; ++i) if (dst[at + i] == 0) { len = i; break; }       // (%s stops at a NUL)
+					dst.resize(at + len);
+				}
+				put(dst, "\n", 1);
+				continue;
+			}
 			seq.assign(t, (size_t)n);
 			B.qual(r, t, n), qual.assign(t, (size_t)n);
 			if (direction == 0) sam_rev_seq(seq), sam_rev_qual(qual);
@@ -297,6 +374,40 @@ public:
 			const long long r = 2 * p + k;
 			const psvr_ori_t &ori = B.ori[r];
 			const char *t; int n;
+			if (!as_bam) {
+				// SAM text straight into the output buffer (same fields and rules as the BAM path below)
+				const char *qt, *nt; int qn, nn;
+				B.seq(r, t, n), B.qual(r, qt, qn), B.name(r, nt, nn);
+				const uint32_t rb = (ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg) + 1;
+				const int pos = (int)rb, chr_id = ori.chr_id;
+				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
+				if (!acceptable(std::string(nt, (size_t)nn), orr[k].cigar, std::string("x"), std::string("x")) || qn != n) { drop("@ori_bam_sam_parse1 ERROR"); continue; }
+				dst.reserve(dst.size() + (size_t)(2 * n + nn + 256) + orr[k].tags.size());
+				put(dst, nt, (size_t)nn), put(dst, "\t", 1), put_int(dst, orr[k].flag), put(dst, "\t", 1), put(dst, H->names[(size_t)chr_id]), put(dst, "\t", 1);
+				put_int(dst, pos), put(dst, "\t", 1), put_int(dst, orr[k].mapq), put(dst, "\t", 1);
+				if (orr[k].cigar.empty()) put(dst, "*", 1); else put(dst, orr[k].cigar);
+				put(dst, "\t", 1);
+				const int mp = orr[k].mate_pos, mc = orr[k].mate_chr;
+				const bool mate_ok = mc >= 0 && mc < (int)H->names.size() && !(mp - 1 < 0);
+				if (!mate_ok) put(dst, "*", 1); else if (mc == chr_id) put(dst, "=", 1); else put(dst, H->names[(size_t)mc]);
+				put(dst, "\t", 1), put_int(dst, mp), put(dst, "\t", 1), put_int(dst, orr[k].isize), put(dst, "\t", 1);
+				const size_t at = dst.size();
+				dst.resize(at + (size_t)(2 * n + 1));
+				uint8_t *sq = &dst[at], *ql = sq + n + 1;
+				if (orr[k].flag & 0x10) {
+					for (int i = 0; i < n; ++i) sq[i] = (uint8_t)sam_rc_char(t[n - 1 - i]);
+					for (int i = 0; i < n; ++i) ql[i] = (uint8_t)qt[n - 1 - i];
+					if (!(n & 1) && n >= 2) ql[n / 2 - 1] = (uint8_t)qt[n / 2 - 1], ql[n / 2] = (uint8_t)qt[n / 2];
+				} else {
+					for (int i = 0; i < n; ++i) sq[i] = (uint8_t)nt16_char(t[i]);
+					memcpy(ql, qt, (size_t)n);
+				}
+				sq[n] = '\t';
+				if (!orr[k].tags.empty()) put(dst, "\t", 1), put(dst, orr[k].tags);
+				put_tag_int(dst, "MS:i:", pr.max_score);
+				put(dst, "\n", 1);
+				continue;
+			}
 			B.seq(r, t, n), seq.assign(t, (size_t)n);
 			B.qual(r, t, n), qual.assign(t, (size_t)n);
 			B.name(r, t, n), name.assign(t, (size_t)n);
