@@ -355,7 +355,7 @@ int main(int argc, char **argv)
 			const long long chunk = 4096, nchunk = (P + chunk - 1) / chunk;
 			std::vector<std::vector<uint8_t>> &mb = J.mb, &ob = J.ob;
 			mb.resize((size_t)nchunk), ob.resize((size_t)nchunk);
-			for (auto &v : mb) v.clear();
+			for (auto &v : mb) v.clear();        // (capacity is kept from the slot's previous batch: no growth copies in steady state)
 			for (auto &v : ob) v.clear();
 			std::atomic<long long> next(0);
 			auto work = [&]() {

@@ -259,7 +259,6 @@ public:
 				const int pos = (int)ref_bg;
 				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
 				if (nn <= 0 || nn > 254 || qn != read_l) { drop("@sam_parse1 ERROR"); continue; }
-				dst.reserve(dst.size() + (size_t)(2 * read_l + nn + cn + 256));
 				put(dst, nt, (size_t)nn), put(dst, "\t", 1), put_int(dst, flag), put(dst, "\t", 1);
 				const std::string &rn = H->names[(size_t)chr_id];
 				put(dst, rn), put(dst, "\t", 1), put_int(dst, pos), put(dst, "\t", 1), put_int(dst, mapq), put(dst, "\t", 1);
@@ -382,7 +381,6 @@ public:
 				const int pos = (int)rb, chr_id = ori.chr_id;
 				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
 				if (!acceptable(std::string(nt, (size_t)nn), orr[k].cigar, std::string("x"), std::string("x")) || qn != n) { drop("@ori_bam_sam_parse1 ERROR"); continue; }
-				dst.reserve(dst.size() + (size_t)(2 * n + nn + 256) + orr[k].tags.size());
 				put(dst, nt, (size_t)nn), put(dst, "\t", 1), put_int(dst, orr[k].flag), put(dst, "\t", 1), put(dst, H->names[(size_t)chr_id]), put(dst, "\t", 1);
 				put_int(dst, pos), put(dst, "\t", 1), put_int(dst, orr[k].mapq), put(dst, "\t", 1);
 				if (orr[k].cigar.empty()) put(dst, "*", 1); else put(dst, orr[k].cigar);
