@@ -330,7 +330,7 @@ def main():
                 j = json.loads([l for l in r.stderr.decode().split("\n") if "e2e_json" in l][-1].split("e2e_json ", 1)[1])
                 e2e[ext] = {"reads_per_s": round(2 * n_e2e / j["wall_s"], 1), "wall_s": j["wall_s"], "index_load_s": j["index_s"], "read_parse_s": j["read_parse_s"], "engine_s": j["engine_s"],
                             "format_s": j["format_s"], "write_s": j["write_s"], "batches": j["batches"], "d2h_bytes": j["d2h_bytes"], "out_bytes": os.path.getsize(os.path.join(tmp, "o." + ext))}
-            e2e["note"] = "wall_s = first FASTQ byte to both files closed (three overlapped stages); index_load_s (files -> HBM) is outside it"
+            e2e["note"] = "wall_s = first FASTQ byte to both files closed (four overlapped stages: read+parse | engine | format | write); index_load_s (files -> HBM) is outside it"
     # ---- configs[4] beside it (not `value`): 250 bp reads against edge-2000 anchors, the shape whose DP problems are several hundred
     # anti-diagonals wide, so the wavefront-per-alignment kernels get a timing and a roofline of their own
     cfg5 = None
