@@ -29,12 +29,13 @@ class BgzfWriter {
 	static const size_t kOut = 0x10000 + 64;
 	bool ok_ = true;
 	int threads_ = 1;
+	int level_ = Z_DEFAULT_COMPRESSION;           // htslib's "wb" is zlib's default level too
 	// one member: gzip header with the BC extra field, raw deflate, CRC32, ISIZE (SAMv1 4.1); returns the member size
-	static size_t compress_block(const uint8_t *p, size_t n, uint8_t *out)
+	static size_t compress_block(const uint8_t *p, size_t n, uint8_t *out, int level = Z_DEFAULT_COMPRESSION)
 	{
 		z_stream zs;
 		memset(&zs, 0, sizeof zs);
-		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+		if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
 		zs.next_in = (Bytef *)p, zs.avail_in = (uInt)n;
 		zs.next_out = out + 18, zs.avail_out = (uInt)(kOut - 18 - 8);
 		int rc = deflate(&zs, Z_FINISH);
@@ -62,7 +63,7 @@ private:
 		auto work = [&]() {
 			for (size_t b = next++; b < nb; b = next++) {
 				const size_t o = b * kBlock, m = n - o < kBlock ? n - o : kBlock;
-				len[b] = compress_block(p + o, m, out.data() + b * kOut);
+				len[b] = compress_block(p + o, m, out.data() + b * kOut, level_);
 			}
 		};
 		const int nt = threads_ < 1 ? 1 : (size_t)threads_ > nb ? (int)nb : threads_;
@@ -75,7 +76,7 @@ private:
 		}
 	}
 public:
-	bool open(const char *fn, int threads = 1) { f_ = fopen(fn, "wb"); threads_ = threads; return f_ != nullptr; }
+	bool open(const char *fn, int threads = 1, int level = Z_DEFAULT_COMPRESSION) { f_ = fopen(fn, "wb"); threads_ = threads; level_ = level; return f_ != nullptr; }
 	void write(const void *p, size_t n)
 	{
 		const uint8_t *b = (const uint8_t *)p;
@@ -182,9 +183,9 @@ class BamWriter {
 		return true;
 	}
 public:
-	bool open(const char *fn, const std::string &header_text, const std::vector<BamRef> &refs, int threads = 1)
+	bool open(const char *fn, const std::string &header_text, const std::vector<BamRef> &refs, int threads = 1, int level = Z_DEFAULT_COMPRESSION)
 	{
-		if (!z_.open(fn, threads)) return false;
+		if (!z_.open(fn, threads, level)) return false;
 		std::vector<uint8_t> h = {'B', 'A', 'M', 1};
 		put32(h, (uint32_t)header_text.size());
 		h.insert(h.end(), header_text.begin(), header_text.end());

@@ -49,6 +49,7 @@ struct Opt {
 	long long batch_pairs = 2000000;       // N_NEEDED, rr.cpp:24
 	long long batch_bases = 100000000;     // MAX_read_size, rr.cpp:109 (333 334 pairs of 150 bp: the limit that actually binds)
 	bool sig_all = false, sig_discard = false;   // BAM input: fc_signal's -D / -U
+	int bam_level = -1;                          // zlib level of the BGZF blocks (-1 = zlib's default, what htslib's "wb" uses)
 };
 
 static int usage()
@@ -81,6 +82,7 @@ static int usage()
 	        "        --device            INT  the same for one device\n"
 	        "        --batch             INT  read pairs per batch [2000000]\n"
 	        "        --batch-bases       INT  bases per batch (the reference stops a batch at 100 MB of bases) [100000000]\n"
+	        "        --compress-level    INT  zlib level of the BAM output's BGZF blocks, 0-9 (1 is ~3x faster than the default) [-1 = default, like htslib]\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
 	        "        --trace                  add per-strand seed/chain hashes to --records\n\n");
 	return 1;
@@ -99,13 +101,13 @@ struct OutFile {
 	FILE *sam = nullptr;
 	psvr::BamWriter bam;
 	bool is_bam = false;
-	bool open(const std::string &fn, bool as_bam, const HeaderInfo &H, int threads)
+	bool open(const std::string &fn, bool as_bam, const HeaderInfo &H, int threads, int level = -1)
 	{
 		is_bam = as_bam;
 		if (!as_bam) { sam = fopen(fn.c_str(), "w"); if (sam) { setvbuf(sam, nullptr, _IOFBF, 1 << 22); fputs(H.text.c_str(), sam); } return sam != nullptr; }
 		std::vector<psvr::BamRef> refs;
 		for (size_t i = 0; i < H.names.size(); ++i) refs.push_back({H.names[i], H.lens[i]});
-		return bam.open(fn.c_str(), H.text, refs, threads);
+		return bam.open(fn.c_str(), H.text, refs, threads, level);
 	}
 	// formatted records (SAM lines or encoded BAM records) of a run of pairs, in order
 	void write_raw(const std::vector<uint8_t> &b) { if (b.empty()) return; if (is_bam) bam.write_raw(b.data(), b.size()); else fwrite(b.data(), 1, b.size(), sam); }
@@ -175,7 +177,7 @@ int main(int argc, char **argv)
 	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
 	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
 	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
-	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005},
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006},
 	                             {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {"sort-by-name", 0, 0, 'N'}, {0, 0, 0, 0}};
 	int c;
 	bool sig_by_name = false;
@@ -202,6 +204,7 @@ int main(int argc, char **argv)
 		case 1003: o.batch_pairs = atoll(optarg); break;
 		case 1004: if (!parse_devices(optarg, &o.devices)) { fprintf(stderr, "bad --devices list '%s'\n", optarg); return 1; } break;
 		case 1005: o.batch_bases = atoll(optarg); break;
+		case 1006: o.bam_level = atoi(optarg); if (o.bam_level < -1 || o.bam_level > 9) { fprintf(stderr, "--compress-level wants -1 .. 9\n"); return 1; } break;
 		case 'D': o.sig_all = true; break;
 		case 'U': o.sig_discard = true; break;
 		case 'N': sig_by_name = true; break;
@@ -274,7 +277,7 @@ int main(int argc, char **argv)
 	FastqReader fq;
 	if (!fq.open(fq_path.c_str())) { fprintf(stderr, "%s\n", fq.error().c_str()); abort(); }
 	OutFile fo, fo_ori;
-	if (!fo.open(o.out, !o.sam, H, o.thread_n) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n)) { fprintf(stderr, "fail to open output file\n"); abort(); }
+	if (!fo.open(o.out, !o.sam, H, o.thread_n, o.bam_level) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n, o.bam_level)) { fprintf(stderr, "fail to open output file\n"); abort(); }
 	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
 	fprintf(stderr, "Processing file: [%s].\n", o.reads.c_str());
 
