@@ -231,20 +231,38 @@ PSVR_HD uint64_t window32(const uint64_t *w, uint64_t i)
 	uint64_t a = w[k];
 	return sh ? (a << sh) | (w[k + 1] >> (64 - sh)) : a;
 }
-// number of positions j < len with A[ia + j] != B[ib + j] (both 2-bit packed); stops counting once `cap` is reached
+// number of positions j < len with A[ia + j] != B[ib + j] (both 2-bit packed), at most `cap`.
+// 128 bases per turn: the five words of each sequence a turn needs are requested together and only then looked at -- a loop that
+// loads a window, counts, and decides whether to go on costs one memory round trip per 32 bases (the reference sequence is a random
+// access per piece), and the early exit it buys is just min(count, cap).
 PSVR_HD int mismatches_packed(const uint64_t *A, uint64_t ia, const uint64_t *B, uint64_t ib, int len, int cap)
 {
 	int nm = 0;
-	for (int j = 0; j < len && nm < cap; j += 32) {
-		uint64_t x = window32(A, ia + j) ^ window32(B, ib + j);
-		x = (x | (x >> 1)) & 0x5555555555555555ull;
-		int rem = len - j;
-		if (rem < 32) x &= ~0ull << ((32 - rem) << 1);
+	for (int j = 0; j < len && nm < cap; j += 128) {
+		const uint64_t ka = (ia + (uint64_t)j) >> 5, kb = (ib + (uint64_t)j) >> 5;
+		const unsigned sa = (unsigned)((ia + (uint64_t)j) & 31) << 1, sb = (unsigned)((ib + (uint64_t)j) & 31) << 1;
+		const int rem = len - j, nw = rem >= 128 ? 4 : (rem + 31) >> 5;          // 32-base windows of this turn
+		uint64_t wa[5], wb[5];
 #if defined(__HIP_DEVICE_COMPILE__)
-		nm += __popcll(x);
-#else
-		nm += __builtin_popcountll(x);
+#pragma unroll
 #endif
+		for (int q = 0; q < 5; ++q) { const bool in = q <= nw; wa[q] = in ? A[ka + q] : 0, wb[q] = in ? B[kb + q] : 0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+		for (int q = 0; q < 4; ++q) {
+			if (q >= nw) break;
+			const uint64_t xa = sa ? (wa[q] << sa) | (wa[q + 1] >> (64 - sa)) : wa[q], xb = sb ? (wb[q] << sb) | (wb[q + 1] >> (64 - sb)) : wb[q];
+			uint64_t x = xa ^ xb;
+			x = (x | (x >> 1)) & 0x5555555555555555ull;
+			const int r = rem - 32 * q;
+			if (r < 32) x &= ~0ull << ((32 - r) << 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+			nm += __popcll(x);
+#else
+			nm += __builtin_popcountll(x);
+#endif
+		}
 	}
 	return nm < cap ? nm : cap;
 }
