@@ -849,6 +849,8 @@ struct WalkState {
 	bool is_simple;
 	Seg *seg; int n_seg; int bad; int seg_cap;
 	int n_dp;                    // DP pieces queued by this read so far (local numbering until walk_read assigns the ids)
+	// the most recent DP piece, kept in registers: a read with exactly one (the common case) gets its descriptor written from here
+	Seg *last_seg; int last_q_st, last_qlen, last_ref_st, last_tlen, last_type, last_strand;
 };
 
 PSVR_HD void seg_lit(WalkState &w, int type, int size)
@@ -926,6 +928,7 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 	// allocation (the queue's counter is the hot spot of this stage).  Until then the coordinates ride in two payload slots.
 	if (w.n_seg + 3 > w.seg_cap) { w.bad = 1; return; }
 	Seg *s = w.seg + w.n_seg;
+	w.last_seg = s, w.last_q_st = read_st, w.last_qlen = (int)qlen, w.last_ref_st = ref_st, w.last_tlen = (int)tlen, w.last_type = type, w.last_strand = w.strand;
 	s[0].kind = 1, s[0].a = w.n_dp++, s[0].b = type;
 	s[1].kind = 2, s[1].a = read_st, s[1].b = (int32_t)qlen;
 	s[2].kind = 2, s[2].a = ref_st, s[2].b = (int32_t)tlen;
@@ -946,7 +949,8 @@ PSVR_HD int walk_seg_cap(const Ctx &c, long long read, int k)
 }
 
 // candidate k of `read`; its CandWork slot and its slice of the piece arena were reserved by walk_read
-PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap, int dp_first)
+struct DpLast { Seg *seg; int q_st, qlen, ref_st, tlen, type, strand; };
+PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap, int dp_first, DpLast &last)
 {
 	const ChainCand &cc = c.ccand[read * 12 + k];
 	const int is_rev = cc.direction == kRev;
@@ -958,6 +962,7 @@ PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long lon
 	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
 	w.read_w = c.rb + (read * 2 + is_rev) * (long long)c.wmax, w.packed_ok = c.has_n4[read] == 0;
 	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap, w.n_dp = dp_first;
+	w.last_seg = nullptr;
 	const int BIG = 0x7fffffff;
 	int aln_read_begin = read_l, aln_read_end = read_l, aln_ref_begin = BIG, aln_ref_end = BIG;
 	int last_aln_begin = read_l, last_ref_begin = BIG, unitig_mis = 0;
@@ -1008,6 +1013,7 @@ PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long lon
 	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = rba, cw.bad = w.bad, cw.seg_off = so;
 	if (w.bad) *c.err = 10 + w.bad;
 	stat_add(c, ST_CAND, 1);
+	if (w.last_seg) last.seg = w.last_seg, last.q_st = w.last_q_st, last.qlen = w.last_qlen, last.ref_st = w.last_ref_st, last.tlen = w.last_tlen, last.type = w.last_type, last.strand = w.last_strand;
 	return w.n_dp;
 }
 
@@ -1026,14 +1032,24 @@ PSVR_HDN inline void walk_read(const Ctx &c, long long read)
 	c.rh[read].cand_off = cw0;                       // candidate k of this read lives at cand[cw0 + k]
 	int n_dp = 0;
 	const long long so0 = so;
+	DpLast last;
+	last.seg = nullptr;
 	for (int k = 0; k < nc; ++k) {
 		const int cap = walk_seg_cap(c, read, k);
-		n_dp = walk_candidate(c, read, k, cw0 + k, so, cap, n_dp);
+		n_dp = walk_candidate(c, read, k, cw0 + k, so, cap, n_dp, last);
 		so += cap;
 	}
 	if (n_dp == 0) return;
 	// number the queued DP problems: one reservation for the whole read, then their descriptors
 	const long long id0 = arena_alloc(c.dp, (unsigned long long)n_dp);
+	if (n_dp == 1 && id0 >= 0 && last.seg) {
+		// one piece (most reads that have any): everything its descriptor needs is still in registers -- no walk back through the
+		// pieces just written (a chain of loads from memory this lane stored to a moment ago)
+		DpDesc &d = c.dp.base[id0];
+		d.read = (int32_t)read, d.strand = last.strand, d.q_st = last.q_st, d.qlen = last.qlen, d.ref_st = (uint32_t)last.ref_st, d.tlen = last.tlen, d.type = last.type, d.pad = 0;
+		last.seg->a = (int32_t)id0;
+		return;
+	}
 	so = so0;
 	for (int k = 0; k < nc; ++k) {
 		const CandWork &cw = c.cw.base[cw0 + k];
