@@ -6,7 +6,10 @@ import synth
 
 DATASETS = {
     # cfg-1 style smoke set: 20 INS anchors (edge 500), 2000 pairs of 150 bp
-    "fx1": dict(anchors=dict(n_anchors=20, seed=7), reads={"reads150": dict(n_pairs=2000, seed=13)}),
+    "fx1": dict(anchors=dict(n_anchors=20, seed=7), reads={"reads150": dict(n_pairs=2000, seed=13),
+                                                            # reads of the first three anchors, the FIRST included: the one the reference attributes to
+                                                            # its neighbour (calloc'ed chr_file_n) -- reproduced, and pinned here
+                                                            "anchor0": dict(n_pairs=400, seed=77, anchors=(0, 3))}),
     # tie-breaks / STR / N bases / 250 bp: duplicated flanks and tandem-repeat alleles
     "fx2": dict(anchors=dict(n_anchors=30, seed=21, edge=600, allele=(60, 400), str_frac=0.2, dup_frac=0.3),
                 reads={"reads150": dict(n_pairs=1500, seed=23, str_frac=0.05, n_frac=0.05),
@@ -32,9 +35,11 @@ def anchors_of(name):
 
 def reads_of(name, rname):
     a = anchors_of(name)
-    # anchor 0 is never sampled: the reference mis-assigns it (calloc'ed chr_file_n) and its
-    # left extensions clamp at reference position 0, where the reference reads stale scratch bytes
-    return synth.make_reads(a[1:], **DATASETS[name]["reads"][rname])
+    kw = dict(DATASETS[name]["reads"][rname])
+    # by default anchor 0 is not sampled: the reference mis-assigns it (calloc'ed chr_file_n) and a left extension that
+    # clamps at reference position 0 reads stale scratch bytes there; the sets with an `anchors` range include it on purpose
+    lo, hi = kw.pop("anchors", (1, len(a)))
+    return synth.make_reads(a[lo:hi], **kw)
 
 
 def materialize(name, out_dir):
