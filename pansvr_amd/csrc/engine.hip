@@ -144,6 +144,227 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	}
 }
 
+// prep of short reads (lmax <= 32 W), one LANE per pair, mate 0 then mate 1.  The wavefront-per-read kernel above spends ~280 vector
+// instructions per read and is bound by exactly that (1.5 ms per 2 M reads however its memory round trips are arranged); here the
+// lane keeps the read in registers: a dword of four bases becomes four 2-bit codes by three bit operations, one v_perm_b32 maps the
+// codes back to letters to prove the four were A/C/G/T (anything else -- an 'N' that draws, an 'n', another letter, the read's end --
+// takes the per-base branch), the reverse strand is the packed forward strand bit-reversed in 2-bit groups, complemented and
+// shifted, and the STR screen rolls the 20-mer through the packed words into a private bit set in LDS (word k of lane l at
+// [k * 64 + l]: no bank conflicts).  A read with a lower-case 'n' (code 4, which spills into its neighbour's bits and needs the
+// per-base byte arrays) is redone by prep_read() of aln_device.h, the definition every path is tested against.
+struct __attribute__((packed, aligned(4))) PrepU4 { uint32_t x, y, z, w; };
+// Mate 1's N draws follow ALL of mate 0's draws, and mate 0's chain selection may add tie draws after this kernel has run.  So a mate 1
+// that drew leaves its count marked, with the mate-0 count it started from: k_prep_mate1 (launched when mate 1's turn comes) clears the
+// mark and redoes the read if mate 0's count has moved.
+static const int32_t kPrepMark = 1 << 30;
+
+__device__ __forceinline__ uint64_t rev_groups2(uint64_t x)          // the 32 2-bit groups of x in reverse order
+{
+	const uint64_t t = ((uint64_t)__builtin_bitreverse32((uint32_t)x) << 32) | __builtin_bitreverse32((uint32_t)(x >> 32));
+	return ((t >> 1) & 0x5555555555555555ull) | ((t & 0x5555555555555555ull) << 1);
+}
+
+template <int W, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work, long long n, int bits_log2)
+{
+	extern __shared__ __align__(16) uint32_t prep_bits[];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int nb = 1 << (bits_log2 - 5);                                  // words of a lane's bit set
+	uint32_t *bits = prep_bits + (size_t)wave * nb * 64;
+	const long long wi = blockIdx.x * (long long)BLOCK + threadIdx.x;
+	const bool have = wi < n;
+	const long long slot = have ? pair_of(work, wi) : 0;
+	const bool shadow = c.src && slot >= c.n_pairs;                       // a real pair is its own source
+	const long long sp = shadow ? (long long)c.src[slot] : slot;
+	const long long p_off = have ? c.poff[slot] : 0;
+	int draws0 = 0;
+	unsigned n_act = 0;
+#pragma unroll 1
+	for (int mate = 0; mate < 2; ++mate) {
+		const long long read = slot * 2 + mate, sr = sp * 2 + mate, item = slot * 3 + mate;
+		// every lane of the wavefront, with or without a read, clears its share of the wavefront's bit sets
+		for (int k = lane; k < nb * 16; k += 64) ((uint4 *)bits)[k] = make_uint4(0, 0, 0, 0);
+		__builtin_amdgcn_wave_barrier();
+		if (!have) continue;
+		const uint32_t *ow = (const uint32_t *)(c.ori + sr);                // psvr_ori_t as words: chr_id, ref_bg, read_bg, align_score, {mapq, direction, unmapped, -}
+		const uint32_t o_chr = ow[0], o_score = ow[3], o_unm = (ow[4] >> 16) & 0xffu;
+		const long long bo0 = c.base_off[sr], bo1 = c.base_off[sr + 1];
+		const int L = (int)(bo1 - bo0);
+		const bool unm = o_unm != 0 || o_chr > 24u;
+		const bool act = !(L > 32 * W || L < kLenKmer) && !(!unm && o_score == (uint32_t)(L * c.par.match));
+		c.read_l[read] = L, c.unmapped[read] = unm, c.has_mem[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
+		{
+			uint4 *st = (uint4 *)(c.strand + read * 2);                       // two Strand records: counts and offsets 0, both hashes the FNV basis
+			const uint32_t hl = (uint32_t)1469598103934665603ULL, hh = (uint32_t)(1469598103934665603ULL >> 32);
+			st[0] = make_uint4(0, 0, 0, 0), st[1] = make_uint4(0, 0, 0, 0), st[2] = make_uint4(hl, hh, hl, hh);
+			st[3] = make_uint4(0, 0, 0, 0), st[4] = make_uint4(0, 0, 0, 0), st[5] = make_uint4(hl, hh, hl, hh);
+		}
+		if (!act) { c.is_str[read] = 0, c.rcnt[item] = 0; continue; }
+		++n_act;
+		const long long ro = p_off + (mate ? draws0 : 0);
+		int draws = 0, err = 0;
+		bool any4 = false;
+		// ---- forward strand: 32 bases (eight dwords, at the read's own byte alignment) per packed word.  Groups are converted as if
+		// the read went on (what lies behind base L-1 is cleared per word below); a group with anything but A/C/G/T is left out and noted.
+		const uintptr_t a = (uintptr_t)(c.bases + bo0);
+		const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
+		const uint32_t sh = (uint32_t)(a & 3);
+		uint64_t F[W];
+		uint32_t other[W];
+		uint32_t prev = q[0];
+#pragma unroll
+		for (int w = 0; w < W; ++w) {
+			uint64_t word = 0;
+			uint32_t ot = 0;
+			if (32 * w < L) {
+				const PrepU4 d0 = *(const PrepU4 *)(q + 8 * w + 1), d1 = *(const PrepU4 *)(q + 8 * w + 5);
+				const uint32_t d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+				uint32_t hi = 0, lo = 0;
+#pragma unroll
+				for (int g = 0; g < 8; ++g) {
+					const uint32_t x = __builtin_amdgcn_alignbyte(d[g], prev, sh);
+					prev = d[g];
+					const uint32_t code = ((x >> 1) ^ (x >> 2)) & 0x03030303u;      // A/a 0, C/c 1, G/g 2, T/t 3
+					const uint32_t canon = __builtin_amdgcn_perm(0u, 0x54474341u, code);   // code -> 'A' 'C' 'G' 'T'
+					const bool ok = (x & 0xDFDFDFDFu) == canon;
+					const uint32_t g8 = ok ? ((code << 6) | (code >> 4) | (code >> 14) | (code >> 24)) & 0xffu : 0u;   // first base in the top bits
+					ot |= ok ? 0u : 1u << g;
+					if (g < 4) hi |= g8 << (24 - 8 * g);
+					else lo |= g8 << (56 - 8 * g);
+				}
+				const int keep = L - 32 * w;                                      // > 0 here
+				word = ((uint64_t)hi << 32) | lo;
+				if (keep < 32) word &= ~0ull << (64 - 2 * keep);
+			}
+			F[w] = word, other[w] = ot;
+		}
+		// the noted groups, base by base, in read order (the draws of the 'N's are taken in that order): charToDna5n
+#pragma unroll
+		for (int w = 0; w < W; ++w) {
+			uint32_t ot = other[w];
+			while (ot) {
+				const int g = __builtin_ctz(ot);
+				ot &= ot - 1;
+				const uint32_t x = __builtin_amdgcn_alignbyte(q[8 * w + g + 1], q[8 * w + g], sh);
+				for (int b = 0; b < 4; ++b) {
+					const int i = 32 * w + 4 * g + b;
+					if (i >= L) break;
+					char ch = (char)((x >> (8 * b)) & 0xffu);
+					if (ch == 'N') {
+						const long long k = ro + draws - c.grand_base;
+						int32_t r;
+						if (c.force && draws < (int)c.force[4 * read]) r = c.force[4 * read + 1 + draws];
+						else r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (err = 2, 0);
+						ch = "ACGT"[r % 4];
+						++draws;
+					}
+					const uint64_t code = (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : (ch == 'n') ? 4 : 0;
+					any4 |= code > 3;
+					F[w] |= code << ((31 - (i & 31)) << 1);
+				}
+			}
+		}
+		if (err) *c.err = err;
+		if (mate == 0) draws0 = draws;
+		if (any4) {
+			// code 4 does not fit the scheme above: the reference definition redoes the read (same draws), the exact count decides STR
+			if (mate) c.rcnt[slot * 3] = draws0;
+			prep_read(c, read);
+			if (mate && draws) c.rcnt[item] = kPrepMark | draws | (draws0 << 10);
+			c.is_str[read] = 2;
+			c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;
+			--n_act;
+			continue;
+		}
+		c.has_n4[read] = 0;
+		c.rcnt[item] = (mate && draws) ? kPrepMark | draws | (draws0 << 10) : draws;
+		uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
+#pragma unroll
+		for (int w = 0; w < W + 2; ++w) if (w < c.wmax) w0[w] = w < W ? F[w < W ? w : 0] : 0;
+		// ---- reverse strand: base j is 3 - base (L-1-j).  Shift the forward string right until it ends at the array's end,
+		// reverse the 2-bit groups of the whole array, complement, clear what lies behind base L-1.
+		{
+			uint64_t G[W];
+#pragma unroll
+			for (int w = 0; w < W; ++w) G[w] = F[w];
+			const int s = 2 * (32 * W - L), qw = s >> 6, r = s & 63;
+#pragma unroll
+			for (int step = 1; step < W; step <<= 1) {
+				if (qw & step) {
+#pragma unroll
+					for (int w = W - 1; w >= 0; --w) G[w] = w - step >= 0 ? G[w - step >= 0 ? w - step : 0] : 0;
+				}
+			}
+			if (r) {
+#pragma unroll
+				for (int w = W - 1; w >= 0; --w) G[w] = (G[w] >> r) | (w ? G[w ? w - 1 : 0] << (64 - r) : 0);
+			}
+#pragma unroll
+			for (int w = 0; w < W + 2; ++w) {
+				if (w >= c.wmax) continue;
+				uint64_t v = 0;
+				if (w < W) {
+					const int keep = L - 32 * w;                                    // bases of this word that exist
+					v = ~rev_groups2(G[w < W ? W - 1 - w : 0]);
+					v = keep <= 0 ? 0 : keep >= 32 ? v : v & (~0ull << (64 - 2 * keep));
+				}
+				w1[w] = v;
+			}
+		}
+		// ---- STR screen (rr.cpp:549-598 decides STR when fewer than kn - 15 of the kn 20-mers are distinct, i.e. at least 16 repeats):
+		// every 20-mer sets a hashed bit of the lane's set; one that finds its bit taken is a repeat or a collision, so fewer than
+		// 16 such events prove the read is not STR.  The few reads left (is_str = 2) get the exact count in k_str_detect.
+		const int kn = L - kLenKmer + 1;
+		int verdict = 2;
+		if (kn >= 15) {
+			uint32_t klo = 0, khi = 0;
+			int taken = 0;
+#pragma unroll
+			for (int w = 0; w < W; ++w) {
+				uint64_t cur = F[w];
+				const int jn = L - 32 * w < 32 ? L - 32 * w : 32;
+				for (int j = 0; j < jn; ++j) {
+					const uint32_t code = (uint32_t)(cur >> 62);
+					cur <<= 2;
+					khi = __builtin_amdgcn_alignbit(khi, klo, 30);
+					klo = (klo << 2) | code;
+					if (32 * w + j >= kLenKmer - 1) {
+						const uint32_t h = ((klo + __umul24(khi & 0xffu, 0x00C2B2AFu)) * 0x9E3779B1u) >> (32 - bits_log2);   // any function of the 40 bits will do
+						const uint32_t bit = 1u << (h & 31);
+						const uint32_t old = atomicOr(&bits[(h >> 5) * 64 + lane], bit);
+						taken += (old & bit) != 0;
+					}
+				}
+			}
+			if (taken < 16) verdict = 0;
+		}
+		c.is_str[read] = (uint8_t)verdict;
+		if (verdict == 2) c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;        // a few percent of the reads: k_str_detect runs on these only
+	}
+	if (c.stats) {
+		// one atomic per wavefront (prep_read counted the reads it redid)
+		unsigned tot = n_act;
+		for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
+		if (lane == 0 && tot) stat_add(c, ST_READS, tot);
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *work, long long n)
+{
+	const long long wi = blockIdx.x * (long long)kBlock + threadIdx.x;
+	if (wi >= n) return;
+	const long long slot = pair_of(work, wi);
+	const int32_t v = c.rcnt[slot * 3 + 1];
+	if (!(v & kPrepMark)) return;
+	c.rcnt[slot * 3 + 1] = v & 0x3ff;
+	if (c.rcnt[slot * 3] == ((v >> 10) & 0x3ff)) return;
+	const long long read = slot * 2 + 1;
+	if (c.stats) atomicAdd(c.stats + ST_READS, ~0ull);                       // prep_read counts the read again
+	prep_read(c, read);
+	c.is_str[read] = 2;
+	c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;
+}
+
 // STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are counted in an open-addressing hash
 // table in LDS (64-bit compare-and-swap inserts, linear probing) -- same counts as the reference's per-read std::map /
 // str_detect() in aln_device.h, independent of insertion order.
@@ -748,6 +969,21 @@ struct GpuBE {
 	{
 		if (n <= 0) return;
 		dzero(c.str_cnt, 4);
+		// reads of up to 288 bases: one lane per pair does both mates (mate 1's N draws follow mate 0's, nothing else connects them),
+		// launched with mate 0; the list of reads for the exact STR count then holds both mates' and is empty when mate 1's turn comes
+		if (c.lmax <= 288) {
+			if (mate) {
+				hipLaunchKernelGGL(k_prep_mate1, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n);
+				note(hipGetLastError());
+				return;
+			}
+			t0("k_prep");
+			if (c.lmax <= 160) hipLaunchKernelGGL((k_prep_pair<5, 256>), dim3(grid_for(n, 256)), dim3(256), (size_t)4 * 64 * 256, stream, c, w, n, 11);
+			else hipLaunchKernelGGL((k_prep_pair<9, 128>), dim3(grid_for(n, 128)), dim3(128), (size_t)2 * 64 * 512, stream, c, w, n, 12);
+			t1();
+			note(hipGetLastError());
+			return;
+		}
 		t0("k_prep");
 		// the screen's hashed set: 32 bits per word; for reads up to ~270 bp 8 x tsize bits keep the expected number of chance
 		// collisions at kn / 32 (far below the 16 that would send a read to the exact count); longer reads get the full 32 x tsize

@@ -246,7 +246,7 @@ template <class BE> struct EngineCore {
 		cap_S = S, cap_lm = lm, cap_bases = total_bases, cap_P = P;
 		c.lmax = lm;
 		c.wmax = c.lmax / 32 + 2;
-		d_bases = alloc<char>(total_bases + 16);
+		d_bases = alloc<char>(total_bases + 64);     // slack: the prep kernel loads whole 32-base groups
 		d_off = alloc<long long>(R + 1);
 		d_ori = alloc<psvr_ori_t>(R);
 		const long long RS = 2 * S;                                 // reads incl. shadow slots
@@ -254,7 +254,7 @@ template <class BE> struct EngineCore {
 		c.hoff = alloc<long long>(RS), c.hcnt = alloc<int32_t>(RS), d_nhoff = alloc<long long>(RS);
 		c.active = alloc<uint8_t>(RS), c.unmapped = alloc<uint8_t>(RS), c.is_str = alloc<uint8_t>(RS), c.has_n4 = alloc<uint8_t>(RS);
 		c.has_mem = alloc<uint8_t>(RS);
-		c.str_list = alloc<int32_t>(RS / 2), c.str_cnt = alloc<unsigned int>(4);
+		c.str_list = alloc<int32_t>(RS), c.str_cnt = alloc<unsigned int>(4);
 		c.read_l = alloc<int32_t>(RS);
 		c.bin = alloc<uint8_t>((unsigned long long)RS * 2 * c.lmax);
 		c.rb = alloc<uint64_t>((unsigned long long)RS * 2 * c.wmax);
