@@ -25,7 +25,9 @@ DATASETS = {
     # configs[4] shape: edge-2000 anchors with alleles up to 2 kbp, 250 bp reads, indels up to 40 -- the wide DP problems
     # (extensions of q <= 250 against t = q + 30, 529 anti-diagonals) pinned against the reference objects
     "fx4": dict(anchors=dict(n_anchors=60, seed=51, edge=2000, allele=(60, 2000)),
-                reads={"reads250": dict(n_pairs=2000, seed=53, L=250, frag=(400, 700), maxindel=40, n_frac=0.01, stat=(250, 300, 550, 800))}),
+                reads={"reads250": dict(n_pairs=2000, seed=53, L=250, frag=(400, 700), maxindel=40, n_frac=0.01, stat=(250, 300, 550, 800)),
+                       # reads beyond 288 bases take the engine's wavefront-per-read preparation (the lane-per-pair one keeps a read in registers)
+                       "long400": dict(n_pairs=300, seed=61, L=400, frag=(700, 900), maxindel=20, n_frac=0.03, str_frac=0.05, stat=(400, 600, 800, 1000))}),
 }
 
 
