@@ -1033,7 +1033,7 @@ PSVR_HDN inline void walk_read(const Ctx &c, long long read)
 	for (int k = 0; k < nc; ++k) total += walk_seg_cap(c, read, k);
 	const long long cw0 = arena_alloc(c.cw, (unsigned long long)nc);
 	long long so = arena_alloc(c.seg, (unsigned long long)total);
-	if (cw0 < 0 || so < 0) return;
+	if (cw0 < 0 || so < 0) { c.n_ccand[read] = 0; return; }       // an arena is full: the batch is run again with larger ones; until then this read has no candidates
 	c.rh[read].cand_off = cw0;                       // candidate k of this read lives at cand[cw0 + k]
 	int n_dp = 0;
 	const long long so0 = so;
@@ -1154,9 +1154,10 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 }
 
 // rest of single_end_handler::align (rr.cpp:453-475)
-PSVR_HDN inline void finalize_read(const Ctx &c, long long read)
+// `rr`: the read's header -- c.rh[read] itself, or a copy in registers that the caller stores in one piece (k_finalize_pair);
+// only its cand_off (set by walk_read) is read here
+PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr)
 {
-	psvr_read_hdr_t &rr = c.rh[read];
 	rr.unmapped = c.unmapped[read], rr.early_out = !c.active[read], rr.is_str = c.is_str[read], rr.reserved = 0, rr.reserved2 = 0;
 	rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
 	int n = c.active[read] ? c.n_ccand[read] : 0;
@@ -1184,13 +1185,13 @@ PSVR_HDN inline void finalize_read(const Ctx &c, long long read)
 	}
 	rr.n_result = n;
 }
+PSVR_HDN inline void finalize_read(const Ctx &c, long long read) { finalize_read(c, read, c.rh[read]); }
 
 // PE_score::read_get_best_pairing_results + set_primary_secondary_mate (rr.hpp:476-534)
 struct PeItem { uint32_t align_score, chr_id, ref_bg; int32_t direction, is_ori, sv_id, end_offset; };
 
-PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i)
+PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i, const psvr_read_hdr_t &rr)
 {
-	const psvr_read_hdr_t &rr = c.rh[read];
 	PeItem p;
 	if (i < rr.n_result) {
 		const psvr_cand_t &d = c.cand[rr.cand_off + i];
@@ -1203,12 +1204,13 @@ PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i)
 	return p;
 }
 
-PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
+// h0 / h1: the two reads' headers (c.rh[2 pair], c.rh[2 pair + 1] or copies in registers, see finalize_read)
+PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_read_hdr_t &h1)
 {
 	const long long r0 = pair * 2, r1 = r0 + 1;
 	const long long item = pair * 3 + 2;
 	for (int e = 0; e < 2; ++e) {       // re-runnable: the pairing stage alone is repeated when only its draw offset moved
-		psvr_read_hdr_t &rr = c.rh[r0 + e];
+		psvr_read_hdr_t &rr = e == 0 ? h0 : h1;
 		rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
 	}
 	const long long ro = c.poff[pair] + c.rcnt[pair * 3] + c.rcnt[pair * 3 + 1];
@@ -1219,7 +1221,7 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 	const int nrl = c.par.normal_read_length;
 	int max_same = 1, max_score = 0, cur_isize = 0, m1 = -1, m2 = -1;   // -1 NULL, else item index
 	bool proper = false;
-	int n0 = c.rh[r0].n_result, n1 = c.rh[r1].n_result;
+	int n0 = h0.n_result, n1 = h1.n_result;
 	const int nr0 = n0, nr1 = n1;
 	if (!c.unmapped[r0]) n0++;
 	if (!c.unmapped[r1]) n1++;
@@ -1230,8 +1232,8 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 	};
 	auto store = [&](int i, int j) {   // i / j = -1 for NULL
 		PeItem a, b;
-		if (i >= 0) a = pe_item(c, r0, i);
-		if (j >= 0) b = pe_item(c, r1, j);
+		if (i >= 0) a = pe_item(c, r0, i, h0);
+		if (j >= 0) b = pe_item(c, r1, j, h1);
 		int ISIZE = 0;
 		if (i >= 0 && j >= 0 && a.chr_id == b.chr_id) {
 			int s1p1 = (int)a.ref_bg, s1p2 = s1p1 + (a.is_ori ? 0 : a.end_offset);
@@ -1274,22 +1276,22 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 		const int mine = e == 0 ? m1 : m2, other = e == 0 ? m2 : m1;
 		const int nmine = e == 0 ? nr0 : nr1, nother = e == 0 ? nr1 : nr0;
 		if (mine < 0) continue;
-		psvr_read_hdr_t &rr = c.rh[rd];
+		psvr_read_hdr_t &rr = e == 0 ? h0 : h1;
 		const bool is_ori = mine >= nmine;
 		rr.primary = is_ori ? -2 : mine;
 		rr.secondary = -1;
 		if (is_ori && nmine > 0) rr.secondary = 0;
 		else if (nmine > 1) rr.secondary = mine == 0 ? 1 : 0;          // rst_idx == position after the final sort
-		PeItem me = pe_item(c, rd, mine);
+		PeItem me = pe_item(c, rd, mine, rr);
 		rr.prim_sv_id = me.sv_id;
 		if (other >= 0) {
-			PeItem mt = pe_item(c, e == 0 ? r1 : r0, other);
+			PeItem mt = pe_item(c, e == 0 ? r1 : r0, other, e == 0 ? h1 : h0);
 			(void)nother;
 			if (mt.chr_id != 0xffffffffu) {
 				// The reference handles read 0 first and stores the SV of an ORIGINAL primary in the shared `ori` object
 				// (`c_rst->sv_info_p = c_rst->mate_sv_info_p`, rr.hpp:524-526), so when read 1's turn comes an original mate already
 				// carries the SV it inherited -- from read 1 itself.  Read 0 looks at read 1's original before that assignment.
-				const int32_t mate_sv = (e == 1 && mt.is_ori) ? c.rh[r0].prim_sv_id : mt.sv_id;
+				const int32_t mate_sv = (e == 1 && mt.is_ori) ? h0.prim_sv_id : mt.sv_id;
 				rr.has_mate = 1, rr.mate_chr_id = (int32_t)mt.chr_id, rr.mate_ref_bg = mt.ref_bg, rr.mate_sv_id = mate_sv;
 				if (is_ori) rr.prim_sv_id = mate_sv;
 				continue;
@@ -1298,6 +1300,7 @@ PSVR_HDN inline void pair_reads(const Ctx &c, long long pair)
 		rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_sv_id = -1;
 	}
 }
+PSVR_HDN inline void pair_reads(const Ctx &c, long long pair) { pair_reads(c, pair, c.rh[pair * 2], c.rh[pair * 2 + 1]); }
 
 // the fixed-size ABI record of one read (psvr_read_result_t) from the compact header, the candidate list and the strand
 // bookkeeping; `out` is written completely (unused candidate slots are zero)

@@ -536,8 +536,17 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const long long p = pair_of(work, i);
-	finalize_read(c, 2 * p), finalize_read(c, 2 * p + 1);
-	pair_reads(c, p);
+	// both headers are built in registers and stored once, as six 16-byte words (field by field through c.rh they were some 30 narrow
+	// stores per read, each lane to its own line, and the pairing read them back)
+	psvr_read_hdr_t h[2];
+	h[0].cand_off = c.rh[2 * p].cand_off, h[1].cand_off = c.rh[2 * p + 1].cand_off;
+	finalize_read(c, 2 * p, h[0]), finalize_read(c, 2 * p + 1, h[1]);
+	pair_reads(c, p, h[0], h[1]);
+	static_assert(sizeof(psvr_read_hdr_t) == 48, "header size");
+	const uint4 *src = (const uint4 *)h;
+	uint4 *dst = (uint4 *)(c.rh + 2 * p);
+#pragma unroll
+	for (int k = 0; k < 6; ++k) dst[k] = src[k];
 }
 // compaction of the dirty pairs into the two work lists; one LDS atomic per list and wavefront (ranks inside it from a ballot), one
 // global atomic per list and workgroup

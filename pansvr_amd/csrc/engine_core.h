@@ -274,6 +274,16 @@ template <class BE> struct EngineCore {
 		cap_seg = cap_cw * 16;
 		cap_dp = (unsigned long long)R2 * 4 + 1024;
 		cap_cig = (unsigned long long)R2 * 48 + 4096;
+		// PSVR_ARENA_SHRINK=<n>: start with 1/n of the scratch arenas, so that a small input walks through the overflow -> grow -> re-run
+		// path of every arena (tests)
+		if (const char *e = getenv("PSVR_ARENA_SHRINK")) {
+			const unsigned long long n = (unsigned long long)atoll(e);
+			if (n > 1) {
+				for (unsigned long long *cap : {&cap_us, &cap_cw, &cap_seg, &cap_dp, &cap_cig}) *cap = *cap / n + 64;
+				const unsigned long long slots = (unsigned long long)2 * R2 * kMemSlot;    // fixed per-strand slots: only the bump region behind them shrinks
+				cap_mem = slots + (cap_mem - slots) / n + 64;
+			}
+		}
 		c.stats = alloc<unsigned long long>(16);
 		for (void *p : owned) if (!p) { err = "device allocation failed"; return PSVR_ERR_NOMEM; }
 		free_arenas();
@@ -382,9 +392,15 @@ template <class BE> struct EngineCore {
 		}
 		be.st_walk(c, work, nwork);
 		unsigned long long tops[8];
-		be.d2h(tops, d_tops, 64);
+		int32_t fl[8];
+		be.d2h2(tops, d_tops, 64, fl, d_flags, 32);
 		long long dp_end = (long long)tops[3], cw_end = (long long)tops[4];
-		if (dp_end > (long long)cap_dp || cw_end > (long long)cap_cw) return -1000 - (dp_end > (long long)cap_dp ? 1 : 0) - (cw_end > (long long)cap_cw ? 2 : 0);
+		// An arena that filled up in the stages so far ends the round here: what follows (assembly, the reads' tails) would walk records
+		// that were never written.  Bits: 1 dp, 2 cw, 4 seg, 8 us, 16 mem.
+		{
+			const int full = (dp_end > (long long)cap_dp || fl[3] ? 1 : 0) | (cw_end > (long long)cap_cw || fl[4] ? 2 : 0) | (fl[2] ? 4 : 0) | (fl[1] ? 8 : 0) | (fl[0] ? 16 : 0);
+			if (full) return -1000 - full;
+		}
 		if (dp_end > dp_done) {
 			dp.begin = dp_done, dp.end = dp_end;
 			int rc = be.st_dp(*this);
@@ -475,7 +491,8 @@ template <class BE> struct EngineCore {
 			rc = run_slots(work, nfull + nshadow, dp_done, cw_done);
 			if (beside) be.side_wait();
 			if (rc <= -1000) {
-				int32_t fl[8] = {0, 0, 0, ((-rc - 1000) & 1), ((-rc - 1000) & 2) >> 1, 0, 0, 0};
+				const int full = -rc - 1000;
+				int32_t fl[8] = {(full >> 4) & 1, (full >> 3) & 1, (full >> 2) & 1, full & 1, (full >> 1) & 1, 0, 0, 0};
 				c.stats = stats_ptr;
 				return grow_and_rerun(fl, trace, want_stats, depth);
 			}

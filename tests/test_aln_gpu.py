@@ -178,3 +178,22 @@ def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
         assert open(outs[0] + ext, "rb").read() == open(outs[1] + ext, "rb").read(), ext
     assert os.path.getsize(outs[0] + ".sam") > 10000
     assert open(os.path.join(tmp, "h1.sam"), "rb").read() == open(os.path.join(tmp, "h2.sam"), "rb").read()
+
+
+@pytest.mark.parametrize("shrink", [4, 16])
+def test_gpu_scratch_arena_growth_reruns_the_batch(shrink):
+    """The overflow -> grow -> re-run path of every scratch arena on the GPU (PSVR_ARENA_SHRINK, see test_emu_aln): no stage of a
+    round that overflowed may follow offsets of records that were never written, and the records are the reference's."""
+    w = ac.workdir("fx2")
+    tmp = tempfile.mkdtemp(prefix="psvr_gpu_")
+    rec = os.path.join(tmp, "records.jsonl")
+    cmd = [CLI, "aln", "-S", "-o", os.path.join(tmp, "out.sam"), "-p", os.path.join(tmp, "ori.sam"), "--records", rec, "--trace",
+           os.path.join(ac.golden_dir("fx2"), "idx"), os.path.join(w, "reads150.fq"), os.path.join(w, "header.sam")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PSVR_ARENA_SHRINK=str(shrink)))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"scratch arena overflow" in r.stderr
+    got = [l for l in open(rec).read().split("\n") if l.strip()]
+    want = ac.golden_lines("fx2", "reads150")
+    assert len(got) == len(want)
+    bad = [i for i, (a, b) in enumerate(zip(want, got)) if normalise(a) != normalise(b)]
+    assert not bad, "%d/%d pairs differ; first %d" % (len(bad), len(want), bad[0])

@@ -45,6 +45,24 @@ def test_emulated_engine_matches_reference_records(emu, name, rname):
     assert not bad, "%d/%d pairs differ; first %d:\nref: %s\nemu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
 
 
+@pytest.mark.parametrize("shrink", [4, 16])
+def test_scratch_arena_growth_reruns_the_batch(emu, shrink):
+    """PSVR_ARENA_SHRINK starts the engine with a fraction of its scratch arenas: every arena (MEMs, seeds, pieces, DP descriptors,
+    candidates, CIGAR words) overflows, grows fourfold and the batch runs again -- several times for the smaller start -- and the
+    records are the reference's all the same (engine_core.h grow_and_rerun; the stages of a round that overflowed must not walk
+    records that were never written)."""
+    w = ac.workdir("fx2")
+    env = dict(os.environ, PSVR_ARENA_SHRINK=str(shrink))
+    r = subprocess.run([emu, os.path.join(ac.golden_dir("fx2"), "idx"), os.path.join(w, "reads150.fq"), os.path.join(w, "header.sam"), "--trace"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=env)
+    assert b"scratch arena overflow" in r.stderr
+    got = [l for l in r.stdout.decode().split("\n") if l.strip()]
+    want = ac.golden_lines("fx2", "reads150")
+    assert len(got) == len(want)
+    bad = [i for i, (a, b) in enumerate(zip(want, got)) if normalise(a) != normalise(b)]
+    assert not bad, "%d/%d pairs differ; first %d" % (len(bad), len(want), bad[0])
+
+
 @pytest.mark.parametrize("variant", ["crlf", "no_final_newline", "tiny_batches", "truncated_pair", "gz", "pipe", "pipe_tiny_batches", "threads"])
 def test_fastq_reader_edge_cases(emu, variant):
     """fastq_batch.h's batch reader (memory-mapped or streamed text, line index built on threads, nothing copied but the bases) on
