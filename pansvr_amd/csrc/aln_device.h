@@ -1133,8 +1133,8 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	if (have) { if (n < kCigMax) out[n++] = back; else bad = 1; }
 	int first = 0;
 	if (n > 0 && out[0].size == 0) first = 1;                      // cigar.erase(cigar.begin())
-	psvr_cand_t &pc = c.cand[cwi];                   // == cand[rh.cand_off + cw.k]
-	const ChainCand &cc = c.ccand[(long long)cw.read * 12 + cw.k];
+	psvr_cand_t pc;                                  // built here, stored in one piece: cand[cwi] == cand[rh.cand_off + cw.k]
+	const ChainCand cc = c.ccand[(long long)cw.read * 12 + cw.k];
 	pc.align_score = score > 0 ? (uint32_t)score : 0;
 	pc.chain_score = cc.chain_score;
 	pc.ref_bg = cc.ref_bg - (uint32_t)cw.rba;
@@ -1150,6 +1150,7 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 		for (int i = 0; i < m; ++i) c.cig.base[co + i] = ((uint32_t)(uint16_t)out[first + i].size << 4) | out[first + i].type;
 		pc.n_cigar = (uint32_t)m, pc.cigar_off = co;
 	}
+	c.cand[cwi] = pc;
 	if (bad) *c.err = 20;   // the reference would xassert (abort) or print "ERROR cigar"
 }
 
@@ -1170,18 +1171,20 @@ PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr)
 		cd[j] = x;
 	}
 	if (n > 0 && cd[0].align_score < 40) n = 0;
-	for (int i = 0; i < n; ++i) {
-		int sv = cd[i].chr_id;
+	for (int i = 0; i < n; ++i) {                                        // a record is loaded, changed and stored as a whole
+		psvr_cand_t x = cd[i];
+		const int sv = x.chr_id;
 		const SvDev &s = c.idx.sv[sv];
-		cd[i].sv_id = sv;
-		cd[i].chr_id = (int32_t)s.chr_id;
-		cd[i].ref_bg += s.st_pos;
-		if (cd[i].ref_bg >= 0x7fffffffu) cd[i].ref_bg = 5;
-		cd[i].mapq = 0;
-	}
-	if (n > 0) {
-		int32_t d = (int32_t)(cd[0].align_score - (n > 1 ? cd[1].align_score : 0));
-		cd[0].mapq = (uint8_t)(d > 40 ? 40 : d);
+		x.sv_id = sv;
+		x.chr_id = (int32_t)s.chr_id;
+		x.ref_bg += s.st_pos;
+		if (x.ref_bg >= 0x7fffffffu) x.ref_bg = 5;
+		x.mapq = 0;
+		if (i == 0) {
+			const int32_t d = (int32_t)(x.align_score - (n > 1 ? cd[1].align_score : 0));
+			x.mapq = (uint8_t)(d > 40 ? 40 : d);
+		}
+		cd[i] = x;
 	}
 	rr.n_result = n;
 }
@@ -1266,10 +1269,11 @@ PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_
 	c.rcnt[item] = draws;
 	const bool a_new = m1 >= 0 && m1 < nr0, b_new = m2 >= 0 && m2 < nr1;
 	const bool gain = max_score > 0 && (a_new || b_new);
-	psvr_pair_result_t &pr = c.pres[pair];
+	psvr_pair_result_t pr;
 	pr.max_score = max_score, pr.cur_isize = cur_isize, pr.proper = proper, pr.gain = gain;
 	pr.max1 = m1 < 0 ? -1 : (m1 < nr0 ? m1 : -2);
 	pr.max2 = m2 < 0 ? -1 : (m2 < nr1 ? m2 : -2);
+	c.pres[pair] = pr;
 	if (!gain) return;
 	for (int e = 0; e < 2; ++e) {                                        // set_primary_secondary_mate
 		const long long rd = e == 0 ? r0 : r1;
