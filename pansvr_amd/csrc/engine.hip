@@ -354,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 	}
 }
 
-__global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *work, long long n, int32_t *redo, unsigned int *redo_cnt)
+__global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *work, long long n)
 {
 	const long long wi = blockIdx.x * (long long)kBlock + threadIdx.x;
 	if (wi >= n) return;
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *wor
 	prep_read(c, read);
 	c.is_str[read] = 2;
 	c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;
-	if (redo) redo[atomicAdd(redo_cnt, 1u)] = (int32_t)slot;              // seeded before this redo (st_seed): seeded again
 }
 
 // STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are counted in an open-addressing hash
@@ -438,23 +437,20 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 // Each thread first copies its strand's packed words (wmax x 8 B) into LDS -- row pitch an odd number of 8-byte words, so the
 // lanes of a wavefront spread over the banks -- because every probe and every MEM extension re-reads them; lds_pitch == 0
 // (reads too long for the LDS budget) keeps them in global memory.
-// `n_dev`: optional, the number of work items where the host does not know it (the slots k_prep_mate1 listed); the grid may be smaller
-// than the work then, threads take items in turn.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed(Ctx c, const int32_t *work, long long n, int mate, int lds_pitch, const unsigned int *n_dev)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seed(Ctx c, const int32_t *work, long long n, int mate, int lds_pitch)
 {
 	extern __shared__ __align__(16) uint64_t seed_lds[];
-	if (n_dev) n = (long long)*n_dev;
-	for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < 2 * n; i += (long long)gridDim.x * blockDim.x) {
-		const long long rs = (pair_of(work, i >> 1) * 2 + mate) * 2 + (i & 1);
-		if (lds_pitch) {
-			uint64_t *mine = seed_lds + (size_t)threadIdx.x * lds_pitch;
-			if (c.active[rs >> 1]) {
-				const uint64_t *src = c.rb + rs * (long long)c.wmax;
-				for (int k = 0; k < c.wmax; ++k) mine[k] = src[k];
-			}
-			seed_strand_t<true>(c, rs, mine);
-		} else seed_strand_t<false>(c, rs, nullptr);
-	}
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= 2 * n) return;
+	const long long rs = (pair_of(work, i >> 1) * 2 + mate) * 2 + (i & 1);
+	if (lds_pitch) {
+		uint64_t *mine = seed_lds + (size_t)threadIdx.x * lds_pitch;
+		if (c.active[rs >> 1]) {
+			const uint64_t *src = c.rb + rs * (long long)c.wmax;
+			for (int k = 0; k < c.wmax; ++k) mine[k] = src[k];
+		}
+		seed_strand_t<true>(c, rs, mine);
+	} else seed_strand_t<false>(c, rs, nullptr);
 }
 // K3 chain: merge, expand, sort, sparse chaining DP
 // Compaction of the items a predicate keeps into list[0 .. *cnt): kListItems items per thread (item = block base + k * blockDim + thread,
@@ -949,40 +945,18 @@ struct GpuBE {
 	{
 		if (n) hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, stride, off, v);
 	}
-	// Mate 1's seeding does not wait for mate 0's chaining and selection: the lane-per-pair preparation has both mates' packed words ready,
-	// so mate 1's k_seed goes to a side stream as soon as mate 0's has finished and runs beside k_chain / k_select of mate 0 (those wait
-	// on dependent loads with a fifth of their lanes, k_seed is bound by its divergent loads: 11.55 -> 10.85 ms per step).  The few mate-1
-	// reads that k_prep_mate1 prepares again afterwards (their N draws moved behind mate 0's tie draws) are seeded again.
-	hipEvent_t ev_seed[2] = {nullptr, nullptr};
-	bool seed_ahead = false;                                     // mate 1's seeding is in flight / done on side[1]
-	DevBuf redo;                                                 // [0] count, [4..] slots whose mate 1 was prepared again
-	static bool seed_ahead_wanted() { static const int v = [] { const char *e = getenv("PSVR_SEED_AHEAD"); return e ? atoi(e) : 1; }(); return v != 0; }
 	void st_seed(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n > 0) {
 			int pitch = c.wmax | 1;
 			if ((size_t)pitch * 8 * kBlock > 64 * 1024) pitch = 0;
-			if (mate == 1 && seed_ahead) {
-				// (st_prep has waited for the side stream) only the slots listed by k_prep_mate1
-				hipLaunchKernelGGL(k_seed, dim3(64), dim3(kBlock), (size_t)pitch * 8 * kBlock, stream, c, (const int32_t *)(redo.as<int32_t>() + 4), 0ll, 1, pitch, (const unsigned int *)redo.p);
-				seed_ahead = false;
-			} else {
-				t0("k_seed");
-				hipLaunchKernelGGL(k_seed, dim3(grid_for(2 * n)), dim3(kBlock), (size_t)pitch * 8 * kBlock, stream, c, w, n, mate, pitch, (const unsigned int *)nullptr);
-				t1();
-			}
+			t0("k_seed");
+			hipLaunchKernelGGL(k_seed, dim3(grid_for(2 * n)), dim3(kBlock), (size_t)pitch * 8 * kBlock, stream, c, w, n, mate, pitch);
+			t1();
 			// the list k_chain / k_select of this mate run on
 			note(mem_list.ensure((size_t)(n + 4) * 4));
 			note(hipMemsetAsync(mem_list.p, 0, 4, stream));
 			hipLaunchKernelGGL(k_mem_list, dim3(grid_for(n, kBlock * kListItems)), dim3(kBlock), 0, stream, c, w, n, mate, mem_list.as<int32_t>() + 4, (unsigned int *)mem_list.p);
-			if (mate == 0 && !timing && c.lmax <= 288 && seed_ahead_wanted() && side_streams() && redo.ensure((size_t)(n + 4) * 4) == hipSuccess) {
-				if (!ev_seed[0]) note(hipEventCreateWithFlags(&ev_seed[0], hipEventDisableTiming)), note(hipEventCreateWithFlags(&ev_seed[1], hipEventDisableTiming));
-				note(hipEventRecord(ev_seed[0], stream));
-				note(hipStreamWaitEvent(side[1], ev_seed[0], 0));
-				hipLaunchKernelGGL(k_seed, dim3(grid_for(2 * n)), dim3(kBlock), (size_t)pitch * 8 * kBlock, side[1], c, w, n, 1, pitch, (const unsigned int *)nullptr);
-				note(hipEventRecord(ev_seed[1], side[1]));
-				seed_ahead = true;
-			}
 		}
 		note(hipGetLastError());
 	}
@@ -1013,13 +987,7 @@ struct GpuBE {
 		// launched with mate 0; the list of reads for the exact STR count then holds both mates' and is empty when mate 1's turn comes
 		if (c.lmax <= 288) {
 			if (mate) {
-				int32_t *rl = nullptr;
-				if (seed_ahead) {                                       // mate 1's seeding (side stream) reads what a redo rewrites: it has to be through
-					note(hipStreamWaitEvent(stream, ev_seed[1], 0));
-					note(hipMemsetAsync(redo.p, 0, 4, stream));
-					rl = redo.as<int32_t>() + 4;
-				}
-				hipLaunchKernelGGL(k_prep_mate1, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, rl, (unsigned int *)redo.p);
+				hipLaunchKernelGGL(k_prep_mate1, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n);
 				note(hipGetLastError());
 				return;
 			}
