@@ -108,7 +108,12 @@ template <class BE> struct EngineCore {
 	long long V = 0;                                 // variant slots [P, P+V)
 	long long S = 0;                                 // slots = P real pairs + V variants + window-shadow capacity
 	static const int kWin = 32;                      // offsets evaluated per sensitive pair and round
-	unsigned long long *d_tops = nullptr;     // [8] arena tops + dirty count
+	unsigned long long *d_tops = nullptr;     // [16] dirty counts, totals counters
+	// the six arena tops, each in a cache line of its own (kTopStride words apart): a wavefront's atomic on a line costs ~12 ns however many
+	// lanes take part, and atomics on one line are served one after the other (tools/atomic_rate_bench.hip) -- three counters that the
+	// walk bumps per read shared one line
+	static constexpr int kTopStride = 32;
+	unsigned long long *d_atops = nullptr;
 	int32_t *d_flags = nullptr;               // [8] overflow flags + err
 	unsigned long long cap_mem = 0, cap_us = 0, cap_seg = 0, cap_dp = 0, cap_cw = 0, cap_cig = 0;
 	DpIO dp;
@@ -266,7 +271,7 @@ template <class BE> struct EngineCore {
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
-		d_tops = alloc<unsigned long long>(16), d_flags = alloc<int32_t>(8);
+		d_tops = alloc<unsigned long long>(16), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
 		cap_us = (unsigned long long)R2 * 48 + 65536;
@@ -336,7 +341,7 @@ template <class BE> struct EngineCore {
 		c.seg.base = (Seg *)be.dalloc(cap_seg * sizeof(Seg)), c.dp.base = (DpDesc *)be.dalloc(cap_dp * sizeof(DpDesc));
 		c.cw.base = (CandWork *)be.dalloc(cap_cw * sizeof(CandWork)), c.cig.base = (uint32_t *)be.dalloc(cap_cig * 4);
 		c.cand = (psvr_cand_t *)be.dalloc(cap_cw * sizeof(psvr_cand_t));       // candidate records share the CandWork arena's indices
-		c.mem.top = d_tops + 0, c.us.top = d_tops + 1, c.seg.top = d_tops + 2, c.dp.top = d_tops + 3, c.cw.top = d_tops + 4, c.cig.top = d_tops + 5;
+		c.mem.top = d_atops + 0 * kTopStride, c.us.top = d_atops + 1 * kTopStride, c.seg.top = d_atops + 2 * kTopStride, c.dp.top = d_atops + 3 * kTopStride, c.cw.top = d_atops + 4 * kTopStride, c.cig.top = d_atops + 5 * kTopStride;
 		c.mem.cap = cap_mem, c.us.cap = cap_us, c.seg.cap = cap_seg, c.dp.cap = cap_dp, c.cw.cap = cap_cw, c.cig.cap = cap_cig;
 		c.mem.overflow = d_flags + 0, c.us.overflow = d_flags + 1, c.seg.overflow = d_flags + 2, c.dp.overflow = d_flags + 3, c.cw.overflow = d_flags + 4, c.cig.overflow = d_flags + 5;
 		return c.mem.base && c.us.base && c.path && c.seg.base && c.dp.base && c.cw.base && c.cig.base && c.cand;
@@ -391,10 +396,10 @@ template <class BE> struct EngineCore {
 			be.st_select(c, work, nwork, mate);
 		}
 		be.st_walk(c, work, nwork);
-		unsigned long long tops[8];
+		unsigned long long tops[6 * kTopStride];
 		int32_t fl[8];
-		be.d2h2(tops, d_tops, 64, fl, d_flags, 32);
-		long long dp_end = (long long)tops[3], cw_end = (long long)tops[4];
+		be.d2h2(tops, d_atops, sizeof tops, fl, d_flags, 32);
+		long long dp_end = (long long)tops[3 * kTopStride], cw_end = (long long)tops[4 * kTopStride];
 		// An arena that filled up in the stages so far ends the round here: what follows (assembly, the reads' tails) would walk records
 		// that were never written.  Bits: 1 dp, 2 cw, 4 seg, 8 us, 16 mem.
 		{
@@ -434,7 +439,7 @@ template <class BE> struct EngineCore {
 		if (P == 0) return PSVR_OK;
 		unsigned long long *stats_ptr = c.stats;
 		if (!want_stats) c.stats = nullptr;
-		be.dzero(d_tops, 16 * 8), be.dzero(d_flags, 8 * 4), be.dzero(stats_ptr, 16 * 8);
+		be.dzero(d_tops, 16 * 8), be.dzero(d_atops, 6 * kTopStride * 8), be.dzero(d_flags, 8 * 4), be.dzero(stats_ptr, 16 * 8);
 		unsigned long long mem0 = (unsigned long long)4 * S * kMemSlot;   // bump region starts behind the per-strand slots
 		be.h2d(c.mem.top, &mem0, 8);
 		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
