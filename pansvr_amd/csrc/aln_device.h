@@ -75,11 +75,17 @@ struct VU { uint64_t uid; uint32_t read_pos, uni_pos_off, length1, length2, pos_
 struct USeed { uint32_t read_begin, read_end, seed_id, ref_begin, ref_end, cov; };              // UNI_SEED
 struct PathN { int32_t dist, pre_node; uint32_t brk; uint32_t used; };                          // PATH_t (+ scan break)
 
+// Bump arena.  `nshard` > 1 (GPU backend, pure storage arenas): the arena is cut into nshard equal regions, each with its own counter in
+// its own cache line (kArenaTopStride words apart); a workgroup bumps the counter of region blockIdx % nshard.  Atomics on one line are
+// served one wavefront instruction after the other (~12 ns each, tools/atomic_rate_bench.hip): one counter bumped once per read or
+// strand was what bounded the kernels doing it.
+static const int kArenaTopStride = 32, kArenaMaxShards = 16;
 template <class T> struct Arena {
 	T *base;
 	unsigned long long *top;
 	unsigned long long cap;
 	int *overflow;
+	unsigned int nshard;
 };
 
 PSVR_HD unsigned long long atomic_bump(unsigned long long *p, unsigned long long n)
@@ -95,6 +101,14 @@ PSVR_HD unsigned long long atomic_bump(unsigned long long *p, unsigned long long
 
 template <class T> PSVR_HD long long arena_alloc(const Arena<T> &a, unsigned long long n)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (a.nshard > 1) {
+		const unsigned long long s = blockIdx.x % a.nshard, cap_s = a.cap / a.nshard;
+		const unsigned long long o = atomic_bump(a.top + s * kArenaTopStride, n);
+		if (o + n > cap_s) { *a.overflow = 1; return -1; }
+		return (long long)(s * cap_s + o);
+	}
+#endif
 	unsigned long long o = atomic_bump(a.top, n);
 	if (o + n > a.cap) { *a.overflow = 1; return -1; }
 	return (long long)o;

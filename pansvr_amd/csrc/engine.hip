@@ -825,6 +825,7 @@ __global__ __launch_bounds__(256) void k_dp_fetch(Ctx c, long long begin, long l
 }
 
 struct GpuBE {
+	static constexpr unsigned int kArenaShards = kArenaMaxShards;   // storage arenas: one counter (cache line) per workgroup residue
 	hipStream_t stream = nullptr;
 	hipError_t last = hipSuccess;
 	std::vector<std::pair<std::string, long long>> launches;   // for psvr_engine_stats

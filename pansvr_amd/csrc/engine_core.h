@@ -112,7 +112,7 @@ template <class BE> struct EngineCore {
 	// the six arena tops, each in a cache line of its own (kTopStride words apart): a wavefront's atomic on a line costs ~12 ns however many
 	// lanes take part, and atomics on one line are served one after the other (tools/atomic_rate_bench.hip) -- three counters that the
 	// walk bumps per read shared one line
-	static constexpr int kTopStride = 32;
+	static constexpr int kTopStride = kArenaTopStride * kArenaMaxShards;   // words between two arenas' first counters
 	unsigned long long *d_atops = nullptr;
 	int32_t *d_flags = nullptr;               // [8] overflow flags + err
 	unsigned long long cap_mem = 0, cap_us = 0, cap_seg = 0, cap_dp = 0, cap_cw = 0, cap_cig = 0;
@@ -343,6 +343,8 @@ template <class BE> struct EngineCore {
 		c.cand = (psvr_cand_t *)be.dalloc(cap_cw * sizeof(psvr_cand_t));       // candidate records share the CandWork arena's indices
 		c.mem.top = d_atops + 0 * kTopStride, c.us.top = d_atops + 1 * kTopStride, c.seg.top = d_atops + 2 * kTopStride, c.dp.top = d_atops + 3 * kTopStride, c.cw.top = d_atops + 4 * kTopStride, c.cig.top = d_atops + 5 * kTopStride;
 		c.mem.cap = cap_mem, c.us.cap = cap_us, c.seg.cap = cap_seg, c.dp.cap = cap_dp, c.cw.cap = cap_cw, c.cig.cap = cap_cig;
+		c.mem.nshard = c.dp.nshard = c.cw.nshard = c.cig.nshard = 1;          // mem: fixed slots in front; dp, cw: their ids are ranges the host plans on; cig: downloaded as one piece
+		c.us.nshard = c.seg.nshard = BE::kArenaShards;
 		c.mem.overflow = d_flags + 0, c.us.overflow = d_flags + 1, c.seg.overflow = d_flags + 2, c.dp.overflow = d_flags + 3, c.cw.overflow = d_flags + 4, c.cig.overflow = d_flags + 5;
 		return c.mem.base && c.us.base && c.path && c.seg.base && c.dp.base && c.cw.base && c.cig.base && c.cand;
 	}
@@ -396,10 +398,10 @@ template <class BE> struct EngineCore {
 			be.st_select(c, work, nwork, mate);
 		}
 		be.st_walk(c, work, nwork);
-		unsigned long long tops[6 * kTopStride];
+		unsigned long long tops[kTopStride + 1];                             // from the dp counter to the cw counter
 		int32_t fl[8];
-		be.d2h2(tops, d_atops, sizeof tops, fl, d_flags, 32);
-		long long dp_end = (long long)tops[3 * kTopStride], cw_end = (long long)tops[4 * kTopStride];
+		be.d2h2(tops, d_atops + 3 * kTopStride, sizeof tops, fl, d_flags, 32);
+		long long dp_end = (long long)tops[0], cw_end = (long long)tops[kTopStride];
 		// An arena that filled up in the stages so far ends the round here: what follows (assembly, the reads' tails) would walk records
 		// that were never written.  Bits: 1 dp, 2 cw, 4 seg, 8 us, 16 mem.
 		{

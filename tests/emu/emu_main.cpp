@@ -24,6 +24,7 @@
 using namespace psvr;
 
 struct CpuBE {
+	static constexpr unsigned int kArenaShards = 1;
 	void *dalloc(size_t n) { return calloc(n ? n : 1, 1); }
 	void dfree(void *p) { free(p); }
 	void dzero(void *p, size_t n) { memset(p, 0, n); }
