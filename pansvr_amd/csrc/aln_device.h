@@ -1036,31 +1036,43 @@ PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long lon
 	return w.n_dp;
 }
 
-// all candidates of one read.  The arenas are bump allocators on one counter each: reserving per read instead of per
-// candidate keeps the number of same-address atomics (the limit of this stage) down.
-PSVR_HDN inline void walk_read(const Ctx &c, long long read)
+// all candidates of one read, in three phases with an arena reservation in front of each of the last two, so that a backend can
+// make the reservations where its lanes are together (the GPU kernel reserves per workgroup: the counters of the candidate and DP
+// queues are single lines -- their ids are ranges the host plans on -- and an atomic per read on one line was the limit of this stage):
+//   walk_sizes      candidates and piece slots the read needs
+//   walk_body       (given the candidate and piece reservations) walks the candidates; returns the number of DP problems queued
+//   walk_number_dp  (given the reservation of that many DP ids) writes their descriptors
+struct WalkRead { int nc, total; long long cw0, so0; int n_dp; DpLast last; };
+PSVR_HD void walk_sizes(const Ctx &c, long long read, WalkRead &wr)
 {
-	if (!c.active[read]) return;
+	wr.nc = 0, wr.total = 0, wr.n_dp = 0, wr.last.seg = nullptr;
+	if (read < 0 || !c.active[read]) return;
 	const int nc = c.n_ccand[read];
 	if (nc <= 0) return;
 	int total = 0;
 	for (int k = 0; k < nc; ++k) total += walk_seg_cap(c, read, k);
-	const long long cw0 = arena_alloc(c.cw, (unsigned long long)nc);
-	long long so = arena_alloc(c.seg, (unsigned long long)total);
-	if (cw0 < 0 || so < 0) { c.n_ccand[read] = 0; return; }       // an arena is full: the batch is run again with larger ones; until then this read has no candidates
+	wr.nc = nc, wr.total = total;
+}
+PSVR_HD void walk_body(const Ctx &c, long long read, WalkRead &wr, long long cw0, long long so)
+{
+	if (wr.nc <= 0) return;
+	if (cw0 < 0 || so < 0) { c.n_ccand[read] = 0; wr.nc = 0; return; }       // an arena is full: the batch is run again with larger ones; until then this read has no candidates
 	c.rh[read].cand_off = cw0;                       // candidate k of this read lives at cand[cw0 + k]
+	wr.cw0 = cw0, wr.so0 = so;
 	int n_dp = 0;
-	const long long so0 = so;
-	DpLast last;
-	last.seg = nullptr;
-	for (int k = 0; k < nc; ++k) {
+	for (int k = 0; k < wr.nc; ++k) {
 		const int cap = walk_seg_cap(c, read, k);
-		n_dp = walk_candidate(c, read, k, cw0 + k, so, cap, n_dp, last);
+		n_dp = walk_candidate(c, read, k, cw0 + k, so, cap, n_dp, wr.last);
 		so += cap;
 	}
-	if (n_dp == 0) return;
-	// number the queued DP problems: one reservation for the whole read, then their descriptors
-	const long long id0 = arena_alloc(c.dp, (unsigned long long)n_dp);
+	wr.n_dp = n_dp;
+}
+PSVR_HD void walk_number_dp(const Ctx &c, long long read, const WalkRead &wr, long long id0)
+{
+	if (wr.nc <= 0 || wr.n_dp == 0) return;
+	const int nc = wr.nc, n_dp = wr.n_dp;
+	const long long cw0 = wr.cw0;
+	const DpLast &last = wr.last;
 	if (n_dp == 1 && id0 >= 0 && last.seg) {
 		// one piece (most reads that have any): everything its descriptor needs is still in registers -- no walk back through the
 		// pieces just written (a chain of loads from memory this lane stored to a moment ago)
@@ -1069,7 +1081,7 @@ PSVR_HDN inline void walk_read(const Ctx &c, long long read)
 		last.seg->a = (int32_t)id0;
 		return;
 	}
-	so = so0;
+	long long so = wr.so0;
 	for (int k = 0; k < nc; ++k) {
 		const CandWork &cw = c.cw.base[cw0 + k];
 		Seg *seg = c.seg.base + so;
@@ -1084,6 +1096,17 @@ PSVR_HDN inline void walk_read(const Ctx &c, long long read)
 		}
 		so += walk_seg_cap(c, read, k);
 	}
+}
+PSVR_HDN inline void walk_read(const Ctx &c, long long read)
+{
+	WalkRead wr;
+	walk_sizes(c, read, wr);
+	if (wr.nc <= 0) return;
+	const long long cw0 = arena_alloc(c.cw, (unsigned long long)wr.nc);
+	const long long so = arena_alloc(c.seg, (unsigned long long)wr.total);
+	walk_body(c, read, wr, cw0, so);
+	if (wr.nc <= 0 || wr.n_dp == 0) return;
+	walk_number_dp(c, read, wr, arena_alloc(c.dp, (unsigned long long)wr.n_dp));
 }
 
 struct CigOp { uint8_t type; int16_t size; };
@@ -1104,12 +1127,15 @@ PSVR_HD bool cig_try_merge(CigOp &a, const CigOp &cp, int &bad)
 
 // second half of the per-candidate loop in single_end_handler::align (rr.cpp:445-452): score sum,
 // cigar_tmp reconstruction in push order, reverseGIGAR (rr.hpp:277-301)
-PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
+// in two parts with the reservation of the CIGAR words between them (see walk_read): assemble_compute builds the CIGAR, assemble_store
+// writes it and the candidate record
+struct AsmResult { CigOp out[kCigMax]; int n, first, bad; int32_t score; };
+PSVR_HD void assemble_compute(const Ctx &c, long long cwi, AsmResult &ar)
 {
 	const CandWork &cw = c.cw.base[cwi];
 	const Seg *seg = c.seg.base + cw.seg_off;
 	int32_t score = cw.read_score;
-	CigOp out[kCigMax];
+	CigOp *out = ar.out;
 	int n = 0, bad = cw.bad;
 	bool have = false;
 	CigOp back;
@@ -1147,6 +1173,14 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	if (have) { if (n < kCigMax) out[n++] = back; else bad = 1; }
 	int first = 0;
 	if (n > 0 && out[0].size == 0) first = 1;                      // cigar.erase(cigar.begin())
+	ar.n = n, ar.first = first, ar.bad = bad, ar.score = score;
+}
+PSVR_HD void assemble_store(const Ctx &c, long long cwi, const AsmResult &ar, long long co)
+{
+	const CandWork &cw = c.cw.base[cwi];
+	const CigOp *out = ar.out;
+	const int n = ar.n, first = ar.first, bad = ar.bad;
+	const int32_t score = ar.score;
 	psvr_cand_t pc;                                  // built here, stored in one piece: cand[cwi] == cand[rh.cand_off + cw.k]
 	const ChainCand cc = c.ccand[(long long)cw.read * 12 + cw.k];
 	pc.align_score = score > 0 ? (uint32_t)score : 0;
@@ -1158,7 +1192,6 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	pc.direction = (uint8_t)cc.direction, pc.mapq = 0;
 	for (int i = 0; i < 6; ++i) pc.reserved[i] = 0;
 	const int m = n - first;
-	long long co = arena_alloc(c.cig, (unsigned long long)(m > 0 ? m : 0));
 	pc.n_cigar = 0, pc.cigar_off = 0;
 	if (co >= 0) {
 		for (int i = 0; i < m; ++i) c.cig.base[co + i] = ((uint32_t)(uint16_t)out[first + i].size << 4) | out[first + i].type;
@@ -1166,6 +1199,13 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	}
 	c.cand[cwi] = pc;
 	if (bad) *c.err = 20;   // the reference would xassert (abort) or print "ERROR cigar"
+}
+PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
+{
+	AsmResult ar;
+	assemble_compute(c, cwi, ar);
+	const int m = ar.n - ar.first;
+	assemble_store(c, cwi, ar, arena_alloc(c.cig, (unsigned long long)(m > 0 ? m : 0)));
 }
 
 // rest of single_end_handler::align (rr.cpp:453-475)

@@ -509,16 +509,62 @@ __global__ __launch_bounds__(kBlock) void k_walk_list(Ctx c, const int32_t *work
 		return c.active[r] && c.n_ccand[r] > 0;
 	});
 }
+// One reservation per WORKGROUP on a single-counter arena: every thread of the workgroup calls this at the same place with its amount
+// (0 = nothing); an inclusive scan inside each wavefront, the wavefronts' sums through LDS, one atomic by thread 0.  (Atomics on one
+// line are served one wavefront instruction after the other at ~12 ns: a reservation per read / candidate by every wavefront was
+// 0.3-0.4 ms per step and counter.)  Returns the caller's offset, or -1 for everybody when the arena is full.
+template <class T> __device__ __forceinline__ long long block_arena_alloc(const Arena<T> &a, unsigned long long n)
+{
+	__shared__ unsigned long long wsum[kBlock / 64];
+	__shared__ long long bbase;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+	unsigned long long x = n;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned long long y = __shfl_up(x, o);
+		if (lane >= o) x += y;
+	}
+	if (lane == 63) wsum[wave] = x;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long tot = 0;
+		for (int w = 0; w < nw; ++w) { const unsigned long long t = wsum[w]; wsum[w] = tot; tot += t; }
+		long long b = 0;
+		if (tot) {
+			const unsigned long long o = atomicAdd(a.top, tot);
+			b = (long long)o;
+			if (o + tot > a.cap) { *a.overflow = 1; b = -1; }
+		}
+		bbase = b;
+	}
+	__syncthreads();
+	const long long b = bbase;
+	const unsigned long long mine = wsum[wave] + x - n;
+	__syncthreads();                                                       // wsum / bbase may be written again by the next call
+	return b < 0 ? -1 : b + (long long)mine;
+}
 __global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
 	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
-	if (i >= (long long)*cnt) return;
-	walk_read(c, list[i]);
+	const long long read = i < (long long)*cnt ? (long long)list[i] : -1;  // no early exit: the reservations are made by the whole workgroup
+	WalkRead wr;
+	walk_sizes(c, read, wr);
+	const long long cw0 = block_arena_alloc(c.cw, (unsigned long long)wr.nc);
+	const long long so = wr.nc > 0 ? arena_alloc(c.seg, (unsigned long long)wr.total) : 0;   // (16 counters: per lane)
+	walk_body(c, read, wr, cw0, so);
+	const long long id0 = block_arena_alloc(c.dp, (unsigned long long)(wr.nc > 0 ? wr.n_dp : 0));
+	walk_number_dp(c, read, wr, id0);
 }
-__global__ __launch_bounds__(64) void k_assemble(Ctx c, long long begin, long long end)
+__global__ __launch_bounds__(kBlock) void k_assemble(Ctx c, long long begin, long long end)
 {
-	long long i = begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < end) assemble_candidate(c, i);
+	const long long i = begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	const bool have = i < end;
+	AsmResult ar;
+	ar.n = ar.first = 0;
+	if (have) assemble_compute(c, i, ar);
+	const int m = ar.n - ar.first;
+	const long long co = block_arena_alloc(c.cig, (unsigned long long)(m > 0 ? m : 0));
+	if (have) assemble_store(c, i, ar, co);
 }
 __global__ __launch_bounds__(kBlock) void k_finalize(Ctx c, const int32_t *work, long long n)
 {
@@ -1089,7 +1135,7 @@ struct GpuBE {
 	}
 	void st_assemble(const Ctx &c, long long b, long long e)
 	{
-		if (e > b) { t0("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b, 64)), dim3(64), 0, stream, c, b, e); t1(); }
+		if (e > b) { t0("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(grid_for(e - b)), dim3(kBlock), 0, stream, c, b, e); t1(); }
 		note(hipGetLastError());
 	}
 	DevBuf scan_tmp;
