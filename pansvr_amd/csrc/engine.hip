@@ -164,6 +164,34 @@ __device__ __forceinline__ uint64_t rev_groups2(uint64_t x)          // the 32 2
 	return ((t >> 1) & 0x5555555555555555ull) | ((t & 0x5555555555555555ull) << 1);
 }
 
+// Appends up to two entries per thread to a list with ONE atomic per workgroup (every thread calls it at the same place; see
+// block_arena_alloc below for why: an atomic per wavefront instruction on the one counter line costs ~12 ns, and appends out of
+// divergent code are an instruction per handful of lanes).
+__device__ __forceinline__ void block_list_append2(int32_t *list, unsigned int *cnt, int32_t e0, int32_t e1)
+{
+	__shared__ unsigned int wsum2[kBlock / 64];
+	__shared__ unsigned int bbase2;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+	const unsigned int n = (e0 >= 0) + (e1 >= 0);
+	unsigned int x = n;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned int y = __shfl_up(x, o);
+		if (lane >= o) x += y;
+	}
+	if (lane == 63) wsum2[wave] = x;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned int tot = 0;
+		for (int w = 0; w < nw; ++w) { const unsigned int t = wsum2[w]; wsum2[w] = tot; tot += t; }
+		bbase2 = tot ? atomicAdd(cnt, tot) : 0u;
+	}
+	__syncthreads();
+	unsigned int at = bbase2 + wsum2[wave] + x - n;
+	if (e0 >= 0) list[at++] = e0;
+	if (e1 >= 0) list[at] = e1;
+}
+
 template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work, long long n, int bits_log2)
 {
@@ -179,6 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 	const long long p_off = have ? c.poff[slot] : 0;
 	int draws0 = 0;
 	unsigned n_act = 0;
+	int32_t listed[2] = {-1, -1};                                         // reads for the exact STR count, appended by the workgroup at the end
 #pragma unroll 1
 	for (int mate = 0; mate < 2; ++mate) {
 		const long long read = slot * 2 + mate, sr = sp * 2 + mate, item = slot * 3 + mate;
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 			prep_read(c, read);
 			if (mate && draws) c.rcnt[item] = kPrepMark | draws | (draws0 << 10);
 			c.is_str[read] = 2;
-			c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;
+			listed[mate] = (int32_t)read;
 			--n_act;
 			continue;
 		}
@@ -344,8 +373,9 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 			if (taken < 16) verdict = 0;
 		}
 		c.is_str[read] = (uint8_t)verdict;
-		if (verdict == 2) c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;        // a few percent of the reads: k_str_detect runs on these only
+		if (verdict == 2) listed[mate] = (int32_t)read;                                // a few percent of the reads: k_str_detect runs on these only
 	}
+	block_list_append2(c.str_list, c.str_cnt, listed[0], listed[1]);
 	if (c.stats) {
 		// one atomic per wavefront (prep_read counted the reads it redid)
 		unsigned tot = n_act;
