@@ -25,7 +25,8 @@ __device__ __forceinline__ long long pair_of(const int32_t *work, long long i) {
 // ---- stage kernels: one thread per item; the read-level stages run per mate ------------------------
 // prep (prep_read in aln_device.h), one wavefront per read: coalesced base loads, N draws ordered by a ballot
 // prefix, codes of both strands staged in LDS, then one lane per packed 32-base word (no per-base read-modify-write).
-__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate, int tsize, int per_wave)
+// `n_dev`: optional, the number of work items where only the device knows it (the slots k_prep_mate1 lists); wavefronts take items in turn
+__global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, long long n, int mate, int tsize, int per_wave, const unsigned int *n_dev)
 {
 	extern __shared__ __align__(16) uint8_t prep_lds[];
 	// charToDna5n as a 128-entry table at the start of the workgroup's LDS (one ds_read instead of a compare chain per base)
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	__syncthreads();
 	const uint8_t *lut = prep_lds;
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
-	const long long wi = blockIdx.x * (long long)(kBlock / 64) + wave;
-	if (wi >= n) return;
+	if (n_dev) n = (long long)*n_dev;
+	for (long long wi = blockIdx.x * (long long)(kBlock / 64) + wave; wi < n; wi += (long long)gridDim.x * (kBlock / 64)) {
 	const long long slot = pair_of(work, wi), read = slot * 2 + mate;
 	uint8_t *fw = prep_lds + 128 + (size_t)wave * per_wave, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
 	uint64_t *pw = (uint64_t *)(rv + c.lmax);                            // forward strand's packed words (for the STR screen)
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 		if (L > kMaxReadLen) *c.err = 1;
 	}
 	if (lane < 2) { Strand &st = c.strand[read * 2 + lane]; st.mem_n = st.us_n = 0; st.mem_off = st.us_off = 0; st.seed_hash = st.chain_hash = 1469598103934665603ULL; }
-	if (!act) { if (lane == 0) c.rcnt[item] = 0; return; }
+	if (!act) { if (lane == 0) c.rcnt[item] = 0; continue; }
 	const char *s = c.bases + bo0;
 	uint8_t *b0 = c.bin + (read * 2) * (long long)c.lmax, *b1 = b0 + c.lmax;
 	uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	if (lane == 0) {
 		c.is_str[read] = (uint8_t)verdict; c.rcnt[item] = draws; if (c.stats) stat_add(c, ST_READS, 1);
 		if (verdict == 2) c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;      // a few percent of the reads: k_str_detect runs on these only
+	}
+	__builtin_amdgcn_wave_barrier();                                         // the wavefront's LDS is reused by its next read
 	}
 }
 
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 	}
 }
 
-__global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *work, long long n)
+__global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *work, long long n, int32_t *redo, unsigned int *redo_cnt)
 {
 	const long long wi = blockIdx.x * (long long)kBlock + threadIdx.x;
 	if (wi >= n) return;
@@ -393,11 +396,8 @@ __global__ __launch_bounds__(kBlock) void k_prep_mate1(Ctx c, const int32_t *wor
 	if (!(v & kPrepMark)) return;
 	c.rcnt[slot * 3 + 1] = v & 0x3ff;
 	if (c.rcnt[slot * 3] == ((v >> 10) & 0x3ff)) return;
-	const long long read = slot * 2 + 1;
-	if (c.stats) atomicAdd(c.stats + ST_READS, ~0ull);                       // prep_read counts the read again
-	prep_read(c, read);
-	c.is_str[read] = 2;
-	c.str_list[atomicAdd(c.str_cnt, 1u)] = (int32_t)read;
+	if (c.stats) atomicAdd(c.stats + ST_READS, ~0ull);                       // the read is counted again when it is prepared again
+	redo[atomicAdd(redo_cnt, 1u)] = (int32_t)slot;                           // (a handful per million pairs) -> k_prep, one wavefront per read
 }
 
 // STR detection (rr.cpp:549-598), one wavefront per read: the read's 20-mers are counted in an open-addressing hash
@@ -1056,31 +1056,39 @@ struct GpuBE {
 		while (tsize < 2 * c.lmax) tsize <<= 1;
 		return tsize;
 	}
+	DevBuf redo;                                                 // [0] count, [4..] slots whose mate 1 is prepared again
+	// below this many slots a round is latency, not throughput: the wavefront-per-read kernel is through sooner (PSVR_PREP_PAIR_MIN: tests)
+	static long long prep_pair_min() { static const long long v = [] { const char *e = getenv("PSVR_PREP_PAIR_MIN"); return e ? atoll(e) : 65536ll; }(); return v; }
+	void launch_prep_wave(const Ctx &c, const int32_t *w, long long n, int mate, const unsigned int *n_dev, unsigned grid)
+	{
+		// the screen's hashed set: 32 bits per word; for reads up to ~270 bp 8 x tsize bits keep the expected number of chance
+		// collisions at kn / 32 (far below the 16 that would send a read to the exact count); longer reads get the full 32 x tsize
+		const int tsize = c.lmax <= 288 ? str_tsize(c) / 4 : str_tsize(c);
+		const size_t per_wave = ((size_t)2 * c.lmax + (size_t)c.wmax * 8 + (size_t)tsize * 4 + 15) & ~(size_t)15;
+		hipLaunchKernelGGL(k_prep, dim3(grid), dim3(kBlock), (size_t)128 + (size_t)(kBlock / 64) * per_wave, stream, c, w, n, mate, tsize, (int)per_wave, n_dev);
+	}
 	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		if (n <= 0) return;
 		dzero(c.str_cnt, 4);
-		// reads of up to 288 bases: one lane per pair does both mates (mate 1's N draws follow mate 0's, nothing else connects them),
-		// launched with mate 0; the list of reads for the exact STR count then holds both mates' and is empty when mate 1's turn comes
-		if (c.lmax <= 288) {
-			if (mate) {
-				hipLaunchKernelGGL(k_prep_mate1, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n);
-				note(hipGetLastError());
-				return;
-			}
+		// reads of up to 288 bases, a round that fills the chip: one lane per pair does both mates (mate 1's N draws follow mate 0's, nothing
+		// else connects them), launched with mate 0; the list of reads for the exact STR count then holds both mates'.  When mate 1's turn
+		// comes, k_prep_mate1 lists the few mate-1 reads whose draws have moved behind mate 0's tie draws since, and the wavefront-per-read
+		// kernel prepares those again.
+		if (c.lmax <= 288 && n >= prep_pair_min() && redo.ensure((size_t)(n + 4) * 4) == hipSuccess) {
 			t0("k_prep");
-			if (c.lmax <= 160) hipLaunchKernelGGL((k_prep_pair<5, 256>), dim3(grid_for(n, 256)), dim3(256), (size_t)4 * 64 * 256, stream, c, w, n, 11);
+			if (mate) {
+				note(hipMemsetAsync(redo.p, 0, 4, stream));
+				hipLaunchKernelGGL(k_prep_mate1, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, redo.as<int32_t>() + 4, (unsigned int *)redo.p);
+				launch_prep_wave(c, (const int32_t *)(redo.as<int32_t>() + 4), 0, 1, (const unsigned int *)redo.p, 64);
+			} else if (c.lmax <= 160) hipLaunchKernelGGL((k_prep_pair<5, 256>), dim3(grid_for(n, 256)), dim3(256), (size_t)4 * 64 * 256, stream, c, w, n, 11);
 			else hipLaunchKernelGGL((k_prep_pair<9, 128>), dim3(grid_for(n, 128)), dim3(128), (size_t)2 * 64 * 512, stream, c, w, n, 12);
 			t1();
 			note(hipGetLastError());
 			return;
 		}
 		t0("k_prep");
-		// the screen's hashed set: 32 bits per word; for reads up to ~270 bp 8 x tsize bits keep the expected number of chance
-		// collisions at kn / 32 (far below the 16 that would send a read to the exact count); longer reads get the full 32 x tsize
-		const int tsize = c.lmax <= 288 ? str_tsize(c) / 4 : str_tsize(c);
-		const size_t per_wave = ((size_t)2 * c.lmax + (size_t)c.wmax * 8 + (size_t)tsize * 4 + 15) & ~(size_t)15;
-		hipLaunchKernelGGL(k_prep, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), (size_t)128 + (size_t)(kBlock / 64) * per_wave, stream, c, w, n, mate, tsize, (int)per_wave);
+		launch_prep_wave(c, w, n, mate, nullptr, grid_for(n, kBlock / 64));
 		t1();
 		note(hipGetLastError());
 	}

@@ -180,6 +180,25 @@ def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
     assert open(os.path.join(tmp, "h1.sam"), "rb").read() == open(os.path.join(tmp, "h2.sam"), "rb").read()
 
 
+@pytest.mark.parametrize("name,rname", [("fx2", "reads150"), ("fx2", "reads250"), ("fx3", "ragged"), ("fx3", "lower"), ("fx1", "anchor0")])
+def test_gpu_lane_per_pair_preparation_on_the_golden_sets(name, rname):
+    """The engine prepares the reads of a round with one lane per pair (k_prep_pair) only when the round is large enough to fill the
+    chip; PSVR_PREP_PAIR_MIN=1 sends these small sets down that path too: N draws in order, lower-case n (redone by the reference
+    definition), ragged lengths, 250-base reads (nine packed words), and the mate-1 reads prepared again after mate 0's tie draws."""
+    w = ac.workdir(name)
+    tmp = tempfile.mkdtemp(prefix="psvr_gpu_")
+    rec = os.path.join(tmp, "records.jsonl")
+    cmd = [CLI, "aln", "-S", "-o", os.path.join(tmp, "out.sam"), "-p", os.path.join(tmp, "ori.sam"), "--records", rec, "--trace",
+           os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PSVR_PREP_PAIR_MIN="1"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = [l for l in open(rec).read().split("\n") if l.strip()]
+    want = ac.golden_lines(name, rname)
+    assert len(got) == len(want)
+    bad = [i for i, (a, b) in enumerate(zip(want, got)) if normalise(a) != normalise(b)]
+    assert not bad, "%d/%d pairs differ; first %d:\nref: %s\ngpu: %s" % (len(bad), len(want), bad[0], want[bad[0]], got[bad[0]])
+
+
 @pytest.mark.parametrize("shrink", [4, 16])
 def test_gpu_scratch_arena_growth_reruns_the_batch(shrink):
     """The overflow -> grow -> re-run path of every scratch arena on the GPU (PSVR_ARENA_SHRINK, see test_emu_aln): no stage of a
