@@ -1306,6 +1306,7 @@ struct GpuBE {
 		// kernel.  Not while kernels are being timed.
 		const bool fan = !timing && n_other + (team.T.n_classes ? 1 : 0) > 1 && side_streams();
 		int used = 0;
+		bool side2_forked = false;
 		if (fan) PSVR_HIP(hipEventRecord(ev_fork, stream));
 		for (const Launch3 &L : ls) {
 			if (L.kind == PSVR_DP_KIND_STRIP) continue;
@@ -1314,8 +1315,14 @@ struct GpuBE {
 				// a round without the team kernel leaves this stream idle: its first two launches (the largest classes: wavefronts that run
 				// for ~0.3 ms each) go to side streams, everything else runs here beside them (the side streams share few hardware queues:
 				// dealt round-robin the short kernels queued up behind the long ones, 0.62 ms for what is 0.35 ms of critical path)
-				if (!team.T.n_classes && used >= 2) ++used;
-				else {
+				if (!team.T.n_classes && used >= 2) {
+					// the short ones alternate between this stream and a third side stream
+					if (used & 1) {
+						if (!side2_forked) { PSVR_HIP(hipStreamWaitEvent(side[2], ev_fork, 0)); side2_forked = true; }
+						s2 = side[2];
+					}
+					++used;
+				} else {
 					const int k = used % kSide;
 					if (used < kSide) PSVR_HIP(hipStreamWaitEvent(side[k], ev_fork, 0));
 					s2 = side[k], ++used;
@@ -1327,7 +1334,7 @@ struct GpuBE {
 			t1();
 			PSVR_HIP(hipGetLastError());
 		}
-		if (!team.T.n_classes && used > 2) used = 2;                   // (only two side streams were used)
+		if (!team.T.n_classes && used > 2) used = side2_forked ? 3 : 2;   // (the side streams that were used)
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipEventRecord(ev_join[k], side[k]));
 		B.idx = plan_idx.as<int32_t>();
 		if (team.T.n_classes) { t0("extd2_team_kernel"); team.launch(stream, B, dpP); t1(); PSVR_HIP(hipGetLastError()); }
