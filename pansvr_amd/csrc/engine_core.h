@@ -445,12 +445,9 @@ template <class BE> struct EngineCore {
 		unsigned long long mem0 = (unsigned long long)4 * S * kMemSlot;   // bump region starts behind the per-strand slots
 		be.h2d(c.mem.top, &mem0, 8);
 		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
-		// initial guess: nobody draws
-		be.fill_i64(c.poff, S, 1, 0, grand_pos);
-		be.fill_i64(c.hoff, S, 2, 0, hrand_pos[0]);
-		be.fill_i64(c.hoff, S, 2, 1, hrand_pos[1]);
-		be.dzero(c.rcnt, 3 * S * 4), be.dzero(c.hcnt, 2 * S * 4), be.dzero(d_ctot, S * 4), be.dzero(d_hprev, 2 * S * 4), be.dzero(d_sens, P), be.dzero(d_mask, P);
-		be.fill_iota(d_src, S);
+		// initial guess: nobody draws.  (One pass over the slots: poff = grand_pos, hoff = the two random_r positions, rcnt = hcnt = ctot = hprev =
+		// sens = mask = 0, src = identity -- a dozen fills and memsets of their own were 0.1 ms of launches per run.)
+		be.run_init(c.poff, c.hoff, c.rcnt, c.hcnt, d_ctot, d_hprev, d_sens, d_mask, d_src, S, P, grand_pos, hrand_pos[0], hrand_pos[1]);
 		c.src = d_src, c.force = d_force;
 		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
 		if (V) be.h2d(d_src + P, h_vsrc.data(), V * 4);
@@ -510,12 +507,13 @@ template <class BE> struct EngineCore {
 			be.st_totals(c, work, nfull + nshadow, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);
 			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, true);
 			unsigned long long nnew_chg[2] = {0, 0};           // newly count-sensitive pairs; did any evaluated slot draw a different number than last time?
-			be.d2h(nnew_chg, d_tops + 8, 16);
+			const bool want_vcnt = vcnt.empty() && V && work == nullptr;   // the variant slots' draw counts ride on the same synchronisation
+			if (want_vcnt) { vcnt.resize(3 * V); be.d2h2(nnew_chg, d_tops + 8, 16, vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
+			else be.d2h(nnew_chg, d_tops + 8, 16);
 			const unsigned long long nnew = nnew_chg[0];
 			// A re-run round in which every slot drew exactly as often as at its previous evaluation leaves every offset where it is: the
 			// streams are consistent, the bookkeeping below would find nothing dirty.
 			if (work != nullptr && nnew == 0 && nnew_chg[1] == 0 && nshadow == 0 && wins.empty()) break;
-			if (vcnt.empty() && V && work == nullptr) { vcnt.resize(3 * V); be.d2h(vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
 			// window tables of the pairs evaluated with offset shadows this round
 			if (nshadow > 0) {
 				std::vector<int32_t> tot(nshadow);
