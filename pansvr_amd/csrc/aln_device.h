@@ -56,10 +56,6 @@ struct DevIndex {
 	// 1 bit per first-level bucket (32 MiB, stays resident in the 256 MiB Infinity Cache): set iff the bucket holds a k-mer.
 	// ~85 % of all probes (wrong strand, unrelated reads, mismatching positions) end here without touching the 2 GiB table.
 	const uint32_t *occ;
-	// optional coarse form of `occ`, small enough for an XCD's 4 MiB L2: bit g is set iff any of the buckets g << occ2_shift ..
-	// holds a k-mer.  A clear bit answers the probe from L2; only set bits go on to the bitmap (one 64-byte sector from the
-	// Infinity Cache / HBM per probe otherwise -- what the seeding kernel is bound by).
-	const uint32_t *occ2; uint32_t occ2_shift;
 	// optional: uid_hint[b] = last unipath that starts at or before position b << uid_shift, so the unipath of a position is found by
 	// bisecting between two neighbouring hints (a couple of loads) instead of over all n_seqf starts (14+ dependent loads per MEM)
 	const uint32_t *uid_hint; uint32_t uid_shift;
@@ -222,7 +218,6 @@ PSVR_HD bool bucket_occupied(const DevIndex &ix, uint64_t h)
 	(void)ix, (void)h;
 	return true;
 #else
-	if (ix.occ2) { const uint64_t g = h >> ix.occ2_shift; if (!((ix.occ2[g >> 5] >> (g & 31)) & 1u)) return false; }
 	return !ix.occ || ((ix.occ[h >> 5] >> (h & 31)) & 1u);
 #endif
 }

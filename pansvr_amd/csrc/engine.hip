@@ -1376,26 +1376,10 @@ __global__ void k_build_occupancy(const uint64_t *hash, uint32_t *occ, long long
 	occ[w] = bits;
 }
 
-// coarse occupancy: output bit g = OR of the 2^shift bitmap bits g << shift .. (shift 3..5: a byte, half-word or word of occ)
-__global__ void k_build_occupancy2(const uint32_t *occ, uint32_t *occ2, long long nwords2, int shift)
-{
-	const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (w >= nwords2) return;
-	uint32_t bits = 0;
-	const int per = 1 << shift;                                   // bitmap bits per output bit
-	for (int b = 0; b < 32; ++b) {
-		const long long first = (w * 32 + b) * per;               // first bitmap bit of the group (per <= 32: inside one word)
-		const uint32_t word = occ[first >> 5];
-		const uint32_t m = per == 32 ? ~0u : ((1u << per) - 1u) << (first & 31);
-		bits |= (uint32_t)((word & m) != 0) << b;
-	}
-	occ2[w] = bits;
-}
-
 struct psvr_index {
 	int device = 0;
 	HostIndex host;          // small tables + strings stay on the host too (SAM formatting)
-	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, occ2, uid_hint;
+	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, uid_hint;
 	DevIndex dev;
 	int64_t bytes = 0;
 };
@@ -1459,20 +1443,6 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32
 	PSVR_HIP(hipGetLastError());
 	PSVR_HIP(hipDeviceSynchronize());
 	d.occ = ix->occ.as<uint32_t>();
-	{
-		// PSVR_OCC2_SHIFT: 0 = no coarse filter, 3..5 = 4 / 2 / 1 MiB
-		const char *e = getenv("PSVR_OCC2_SHIFT");
-		const int shift = e ? atoi(e) : 0;
-		if (shift >= 3 && shift <= 5) {
-			const long long nw2 = nwords >> shift;
-			PSVR_HIP(ix->occ2.alloc(nw2 * 4));
-			ix->bytes += nw2 * 4;
-			hipLaunchKernelGGL(k_build_occupancy2, dim3((unsigned)((nw2 + 255) / 256)), dim3(256), 0, nullptr, d.occ, ix->occ2.as<uint32_t>(), nw2, shift);
-			PSVR_HIP(hipGetLastError());
-			PSVR_HIP(hipDeviceSynchronize());
-			d.occ2 = ix->occ2.as<uint32_t>(), d.occ2_shift = (uint32_t)shift;
-		}
-	}
 	// bracket table for the unipath-of-position search (aln_device.h mem_for_hit): one entry per 1024 positions
 	{
 		const uint32_t sh = 10;
@@ -1582,7 +1552,7 @@ extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_
 		ix->bytes += (int64_t)s0.bytes;
 	};
 	cp(ix->ref_seq, src->ref_seq), cp(ix->seq, src->seq), cp(ix->seqf, src->seqf), cp(ix->pos, src->pos), cp(ix->posp, src->posp), cp(ix->hash, src->hash);
-	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->occ2, src->occ2), cp(ix->uid_hint, src->uid_hint);
+	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->uid_hint, src->uid_hint);
 	if (he == hipSuccess) he = hipDeviceSynchronize();
 	if (he != hipSuccess) { delete ix; return set_error(PSVR_ERR_DEVICE, "psvr_index_clone: %s", hipGetErrorString(he)); }
 	DevIndex &d = ix->dev;
@@ -1590,7 +1560,7 @@ extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_
 	d.ref_seq = ix->ref_seq.as<uint64_t>(), d.seq = ix->seq.as<uint64_t>(), d.seqf = ix->seqf.as<uint64_t>(), d.pos = ix->pos.as<uint64_t>();
 	d.posp = ix->posp.as<uint64_t>(), d.hash = ix->hash.as<uint64_t>(), d.off = ix->off.as<uint64_t>(), d.kmer = ix->kmer.as<uint32_t>();
 	d.chr_end_n = ix->chr_end.as<uint32_t>(), d.chr_search_index = ix->chr_idx.as<uint32_t>(), d.sv = ix->sv.as<SvDev>();
-	d.occ = ix->occ.as<uint32_t>(), d.occ2 = ix->occ2.p ? ix->occ2.as<uint32_t>() : nullptr, d.uid_hint = ix->uid_hint.as<uint32_t>();
+	d.occ = ix->occ.as<uint32_t>(), d.uid_hint = ix->uid_hint.as<uint32_t>();
 	*out = ix;
 	return PSVR_OK;
 }
