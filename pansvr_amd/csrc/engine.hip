@@ -624,8 +624,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *
 #pragma unroll
 	for (int k = 0; k < 6; ++k) dst[k] = src[k];
 }
-// compaction of the dirty pairs into the two work lists; one LDS atomic per list and wavefront (ranks inside it from a ballot), one
-// global atomic per list and workgroup
+// compaction of the dirty pairs into the two work lists: kDirtyItems pairs per thread (pair = workgroup base + k * blockDim + thread, the
+// loads stay coalesced), ranks inside a wavefront from ballots, one LDS atomic per list, wavefront and k, and ONE global atomic per list
+// and workgroup -- the two counters sit in different cache lines, and a workgroup per 256 pairs bumped both: 3906 x 2 x 12 ns was the
+// kernel's 92 us whatever the data (tools/atomic_rate_bench.hip)
+static const int kDirtyItems = 8;
 __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt,
                                                   int32_t *outp, unsigned long long *cntp)
 {
@@ -633,24 +636,35 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 	__shared__ unsigned long long b_full, b_pair;
 	if (threadIdx.x == 0) n_full = n_pair = 0;
 	__syncthreads();
-	long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	int d = p < c.n_pairs ? mark_dirty(c, p, noff, nhoff) : 0;
-	const unsigned long long m2 = __ballot(d == 2), m1 = __ballot(d == 1), below = (1ull << (threadIdx.x & 63)) - 1;
-	unsigned int w2 = 0, w1 = 0;
-	if ((threadIdx.x & 63) == 0) {
-		if (m2) w2 = atomicAdd(&n_full, (unsigned int)__popcll(m2));
-		if (m1) w1 = atomicAdd(&n_pair, (unsigned int)__popcll(m1));
+	const long long base = blockIdx.x * (long long)(kBlock * kDirtyItems);
+	const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1;
+	int d[kDirtyItems];
+	unsigned int me[kDirtyItems];
+#pragma unroll
+	for (int k = 0; k < kDirtyItems; ++k) {
+		const long long p = base + (long long)k * kBlock + threadIdx.x;
+		d[k] = p < c.n_pairs ? mark_dirty(c, p, noff, nhoff) : 0;
+		const unsigned long long m2 = __ballot(d[k] == 2), m1 = __ballot(d[k] == 1);
+		unsigned int w2 = 0, w1 = 0;
+		if ((threadIdx.x & 63) == 0) {
+			if (m2) w2 = atomicAdd(&n_full, (unsigned int)__popcll(m2));
+			if (m1) w1 = atomicAdd(&n_pair, (unsigned int)__popcll(m1));
+		}
+		w2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w2), w1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w1);
+		me[k] = d[k] == 2 ? w2 + (unsigned int)__popcll(m2 & below) : w1 + (unsigned int)__popcll(m1 & below);
 	}
-	w2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w2), w1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)w1);
-	const unsigned int me = d == 2 ? w2 + (unsigned int)__popcll(m2 & below) : w1 + (unsigned int)__popcll(m1 & below);
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		b_full = n_full ? atomicAdd(cnt, (unsigned long long)n_full) : 0;
 		b_pair = n_pair ? atomicAdd(cntp, (unsigned long long)n_pair) : 0;
 	}
 	__syncthreads();
-	if (d == 2) out[b_full + me] = (int32_t)p;
-	else if (d == 1) outp[b_pair + me] = (int32_t)p;
+#pragma unroll
+	for (int k = 0; k < kDirtyItems; ++k) {
+		const long long p = base + (long long)k * kBlock + threadIdx.x;
+		if (d[k] == 2) out[b_full + me[k]] = (int32_t)p;
+		else if (d[k] == 1) outp[b_pair + me[k]] = (int32_t)p;
+	}
 }
 // one wavefront per adopted pair (adopt_variant in aln_device.h)
 __global__ __launch_bounds__(kBlock) void k_adopt(Ctx c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff)
@@ -1215,7 +1229,7 @@ struct GpuBE {
 	}
 	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
 	{
-		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp);
+		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs, kBlock * kDirtyItems)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp);
 		note(hipGetLastError());
 	}
 

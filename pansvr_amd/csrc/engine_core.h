@@ -271,7 +271,7 @@ template <class BE> struct EngineCore {
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
-		d_tops = alloc<unsigned long long>(16), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
+		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
 		cap_us = (unsigned long long)R2 * 48 + 65536;
@@ -605,11 +605,13 @@ template <class BE> struct EngineCore {
 				stats.adopted += (long long)adopt_pair.size();
 				adopt_pair.clear(), adopt_slot.clear();
 			}
-			be.dzero(d_tops + 6, 16);
-			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 6, d_workp, d_tops + 7);
-			unsigned long long nd[2] = {0, 0};
+			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
+			be.dzero(d_tops + 32, 17 * 8);
+			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48);
+			unsigned long long nd17[17];
 			int32_t flags[8];
-			be.d2h2(nd, d_tops + 6, 16, flags, d_flags, 32);
+			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 32);
+			const unsigned long long nd[2] = {nd17[0], nd17[16]};
 			if (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5]) { c.stats = stats_ptr; return grow_and_rerun(flags, trace, want_stats, depth); }
 			if (flags[6] == 2 || flags[6] == 3) {      // a rand table ran out: extend and restart the batch
 				be.dzero(d_flags, 32);
