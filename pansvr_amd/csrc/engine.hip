@@ -1326,7 +1326,7 @@ struct GpuBE {
 		TeamLaunch team;
 		size_t n_other = 0;
 		for (const Launch3 &L : ls) {
-			if (L.kind == PSVR_DP_KIND_STRIP) team.add(dp_class_of(L.lds) + 1, L.first, L.count);
+			if (L.kind == PSVR_DP_KIND_STRIP) team.add(dp_class_of(L.lds) + 1, L.first, L.count, (int)qmax[dp_class_of(L.lds)]);
 			else ++n_other;
 		}
 		// The launches of a round work on disjoint problems, and all but the team kernel's are short of wavefronts (the thread-per-alignment

@@ -65,6 +65,9 @@ struct TeamPlan {
 	int32_t first_block[PSVR_DP_NUM_LDS_CLASSES + 1];
 	int32_t n_strips16[PSVR_DP_NUM_LDS_CLASSES];
 	long long first_slot[PSVR_DP_NUM_LDS_CLASSES], count[PSVR_DP_NUM_LDS_CLASSES];
+	// scratch of class c's wavefront w at ws_base[c] + w * ws_need[c] when ws_need[c] != 0 (the planner knows the class's longest query);
+	// 0: the wavefront bumps DpBatch::ws_top (16 k wavefronts on one counter line: ~12 ns each, the first generation queues up)
+	unsigned long long ws_base[PSVR_DP_NUM_LDS_CLASSES], ws_need[PSVR_DP_NUM_LDS_CLASSES];
 };
 template <int LANES> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip
 // the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement

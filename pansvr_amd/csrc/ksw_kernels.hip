@@ -521,8 +521,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	const int R = qmax + SW - 1, NR = qmax + SW * n_strips + 1;
 	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES);
 	unsigned long long base = 0;
-	if (lane == 0) base = atomicAdd(B.ws_top, need);
-	base = (unsigned long long)uni64((long long)base);
+	if (T.ws_need[cls]) base = T.ws_base[cls] + (unsigned long long)((int)blockIdx.x - T.first_block[cls]) * T.ws_need[cls];   // need <= ws_need: the class's longest query bounds this wavefront's
+	else {
+		if (lane == 0) base = atomicAdd(B.ws_top, need);
+		base = (unsigned long long)uni64((long long)base);
+	}
 	psvr_extz_t *out = B.ez + pid;
 	EzAcc ez;
 	ez.reset();

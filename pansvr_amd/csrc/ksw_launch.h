@@ -47,12 +47,18 @@ inline void dp_launch_kind(int kind, int variant, unsigned count, int lds, hipSt
 struct TeamLaunch {
 	TeamPlan T;
 	TeamLaunch() { T.n_classes = 0; T.first_block[0] = 0; }
-	void add(int n_strips16, long long first_slot, long long count)
+	unsigned long long ws_next = 0;
+	// qmax: the longest query of the class if the caller knows it (scratch offsets are then computed, not bumped), else 0
+	void add(int n_strips16, long long first_slot, long long count, int qmax = 0)
 	{
 		const int c = T.n_classes++;
 		T.n_strips16[c] = n_strips16, T.first_slot[c] = first_slot, T.count[c] = count;
-		const int pb = 64 / dp_team_lanes(n_strips16);
-		T.first_block[c + 1] = T.first_block[c] + (int)((count + pb - 1) / pb);
+		const int lanes = dp_team_lanes(n_strips16), pb = 64 / lanes;
+		const int blocks = (int)((count + pb - 1) / pb);
+		T.first_block[c + 1] = T.first_block[c] + blocks;
+		T.ws_need[c] = qmax > 0 ? dp_team_ws_bytes(qmax, n_strips16, lanes) : 0;
+		T.ws_base[c] = ws_next;
+		ws_next += T.ws_need[c] * (unsigned long long)blocks;
 	}
 	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
 	{
