@@ -1737,7 +1737,6 @@ extern "C" int psvr_engine_set_stream_pos(psvr_engine_t *e, const int64_t pos[3]
 	PSVR_HIP(hipSetDevice(e->ix->device));            // commit() reads device memory
 	if (!e->committed) { e->core.commit(); e->committed = true; }
 	e->core.grand_pos = pos[0], e->core.hrand_pos[0] = pos[1], e->core.hrand_pos[1] = pos[2];
-	e->core.grand_dev_n = e->core.hrand_dev_n = 0;
 	return PSVR_OK;
 }
 

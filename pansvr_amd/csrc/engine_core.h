@@ -90,6 +90,9 @@ template <class BE> struct EngineCore {
 	RandStream grand, hrand[2];
 	long long grand_pos = 0, hrand_pos[2] = {0, 0};     // draws consumed by earlier batches
 	long long grand_dev_n = 0, hrand_dev_n = 0;
+	// the device tables hold a WINDOW of the host streams: entries [base, base + n).  A run, a rebase or a new batch whose needs lie inside the
+	// window keeps it (a shard that moves behind its predecessors' draws, the next batch of a pipeline: no 28 MB upload, no hipFree)
+	long long grand_dev_base = 0, hrand_dev_base[2] = {0, 0}, grand_dev_cap = 0, hrand_dev_cap = 0;
 	int32_t *d_grand = nullptr, *d_hrand[2] = {nullptr, nullptr};
 	// device buffers owned here
 	std::vector<void *> owned;
@@ -140,7 +143,7 @@ template <class BE> struct EngineCore {
 		d_grand = d_hrand[0] = d_hrand[1] = nullptr;
 		memset(&dp, 0, sizeof dp);
 		dp_cap_q = dp_cap_t = dp_cap_c = dp_cap_n = 0;
-		grand_dev_n = hrand_dev_n = 0;
+		grand_dev_n = hrand_dev_n = 0, grand_dev_cap = hrand_dev_cap = 0;
 	}
 
 	void init(const DevIndex &ix, const psvr_aln_params_t &par)
@@ -160,28 +163,38 @@ template <class BE> struct EngineCore {
 
 	bool upload_rand(long long need_g, long long need_h)
 	{
-		if (grand_dev_n < need_g) {
-			long long n = need_g + need_g / 2 + 4096;
+		const long long margin = 1 << 20;                                   // entries beyond what this run needs: room for the position to move
+		if (!(d_grand && grand_pos >= grand_dev_base && grand_pos + need_g <= grand_dev_base + grand_dev_n)) {
+			const long long n = need_g + need_g / 2 + 4096 + margin;
 			grand.ensure(grand_pos + n);
-			if (d_grand) be.dfree(d_grand);
-			d_grand = (int32_t *)be.dalloc(n * 4);
-			if (!d_grand) return false;
+			if (n > grand_dev_cap || !d_grand) {
+				if (d_grand) be.dfree(d_grand);
+				d_grand = (int32_t *)be.dalloc(n * 4);
+				if (!d_grand) return false;
+				grand_dev_cap = n;
+			}
 			be.h2d(d_grand, grand.host.data() + grand_pos, n * 4);
-			grand_dev_n = n;
+			grand_dev_base = grand_pos, grand_dev_n = n;
 		}
-		if (hrand_dev_n < need_h) {
-			long long n = need_h + need_h / 2 + 4096;
+		bool hok = d_hrand[0] && d_hrand[1];
+		for (int k = 0; k < 2 && hok; ++k) hok = hrand_pos[k] >= hrand_dev_base[k] && hrand_pos[k] + need_h <= hrand_dev_base[k] + hrand_dev_n;
+		if (!hok) {
+			const long long n = need_h + need_h / 2 + 4096 + margin;
 			for (int k = 0; k < 2; ++k) {
 				hrand[k].ensure(hrand_pos[k] + n);
-				if (d_hrand[k]) be.dfree(d_hrand[k]);
-				d_hrand[k] = (int32_t *)be.dalloc(n * 4);
-				if (!d_hrand[k]) return false;
+				if (n > hrand_dev_cap || !d_hrand[k]) {
+					if (d_hrand[k]) be.dfree(d_hrand[k]);
+					d_hrand[k] = (int32_t *)be.dalloc(n * 4);
+					if (!d_hrand[k]) return false;
+				}
 				be.h2d(d_hrand[k], hrand[k].host.data() + hrand_pos[k], n * 4);
+				hrand_dev_base[k] = hrand_pos[k];
 			}
+			if (n > hrand_dev_cap) hrand_dev_cap = n;
 			hrand_dev_n = n;
 		}
-		c.grand = d_grand, c.grand_n = grand_dev_n, c.grand_base = grand_pos;
-		for (int k = 0; k < 2; ++k) c.hrand[k] = d_hrand[k], c.hrand_base[k] = hrand_pos[k];
+		c.grand = d_grand, c.grand_n = grand_dev_n, c.grand_base = grand_dev_base;
+		for (int k = 0; k < 2; ++k) c.hrand[k] = d_hrand[k], c.hrand_base[k] = hrand_dev_base[k];
 		c.hrand_n = hrand_dev_n;
 		return true;
 	}
@@ -468,7 +481,6 @@ template <class BE> struct EngineCore {
 		if (!have_run || P == 0) { grand_pos = g, hrand_pos[0] = h0, hrand_pos[1] = h1; return PSVR_OK; }
 		if (g == grand_pos && h0 == hrand_pos[0] && h1 == hrand_pos[1]) return PSVR_OK;
 		grand_pos = g, hrand_pos[0] = h0, hrand_pos[1] = h1;
-		grand_dev_n = hrand_dev_n = 0;                   // the device tables are relative to the stream position
 		unsigned long long *stats_ptr = c.stats;
 		if (!want_stats) c.stats = nullptr;
 		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
@@ -678,7 +690,6 @@ template <class BE> struct EngineCore {
 		long long e[3];
 		stream_end(e);
 		grand_pos = e[0], hrand_pos[0] = e[1], hrand_pos[1] = e[2];
-		grand_dev_n = hrand_dev_n = 0;          // tables are relative to the stream position: refresh on next run
 		have_run = false;
 	}
 };
