@@ -381,7 +381,7 @@ def main():
                 "data": "synthetic", "config": {"workload": "configs[1]: %d synthetic 150 bp PE signal read pairs per GPU vs %d-anchor SV reference (%.1f Mbp), `panSVR aln` hot path"
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step,
-                                                 "parallelism": "shard%d x %d engine(s) per GPU (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, K, "none" if world == 1 else "all-gather of 3 int64 per rank over %s, %d iteration(s)/step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
+                                                 "parallelism": "shard%d x %d engine(s) per GPU (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, K, "none" if world == 1 else "all-gather of 6 int64 per rank over %s, %d per step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
                                                  "engines_per_gpu": K, "in_process_rebases": group_rebases,
                                                  "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},

@@ -2,7 +2,7 @@
 
 Pairs are independent given the replicated index, so rank r simply takes the r-th contiguous block (concatenating the
 ranks' outputs restores input order).  The only coupling is the reference's single rand()/random_r draw sequence:
-shard r starts where shard r-1 ended.  `resolve_stream_order` finds those positions with one tiny all-gather per
+shard r starts where shard r-1 ended.  `resolve_stream_order` finds those positions with one tiny all-gather (six integers) per
 iteration: every rank runs (or rebases) its shard at its current start position, all ranks exchange how many draws their
 shards consumed, and each recomputes its start as first + sum of the draws of the ranks before it -- until no start
 moves (normally two iterations: draw counts almost never depend on the start position)."""
@@ -35,17 +35,16 @@ def resolve_stream_order(first_pos, run_at, rebase_to, device=None, max_iter=16)
     end = run_at(start)
     it = 1
     while True:
-        used = [e - s for e, s in zip(end, start)]
-        every = all_gather_i64(used, device)
-        new_start = [int(first_pos[k]) + sum(every[q][k] for q in range(rank)) for k in range(3)]
-        moved = new_start != start
-        flags = all_gather_i64([1 if moved else 0], device)
-        if not any(f[0] for f in flags):
+        # one collective per iteration: every rank's draw counts AND the start it ran from, so that each rank can tell for itself whether
+        # any rank has to move (the ranks must agree on when to stop)
+        every = all_gather_i64([e - s for e, s in zip(end, start)] + start, device)
+        starts = [[int(first_pos[k]) + sum(every[p][k] for p in range(q)) for k in range(3)] for q in range(len(every))]
+        if all(starts[q] == every[q][3:6] for q in range(len(every))):
             return start, end, it
         if it >= max_iter:
             raise RuntimeError("stream-order resolution did not converge")
-        if moved:
-            start = new_start
+        if starts[rank] != start:
+            start = starts[rank]
             end = rebase_to(start)
         it += 1
 
