@@ -671,16 +671,12 @@ template <class BE> struct EngineCore {
 	{
 		out[0] = grand_pos, out[1] = hrand_pos[0], out[2] = hrand_pos[1];
 		if (P == 0) return;
-		long long lo; int32_t lc;
-		be.d2h(&lo, c.poff + (P - 1), 8);
-		be.d2h(&lc, d_ctot + (P - 1), 4);
-		out[0] = lo + lc;
-		for (int k = 0; k < 2; ++k) {
-			long long ho; int32_t hc;
-			be.d2h(&ho, c.hoff + (2 * (P - 1) + k), 8);
-			be.d2h(&hc, c.hcnt + (2 * (P - 1) + k), 4);
-			out[1 + k] = ho + hc;
-		}
+		// the last pair's offset + draw count of each stream (one readback: poff[P-1], then hoff / hcnt of the pair are neighbours)
+		long long lo, ho[2];
+		int32_t lc, hc[2];
+		be.d2h2(&lo, c.poff + (P - 1), 8, &lc, d_ctot + (P - 1), 4);
+		be.d2h2(ho, c.hoff + 2 * (P - 1), 16, hc, c.hcnt + 2 * (P - 1), 8);
+		out[0] = lo + lc, out[1] = ho[0] + hc[0], out[2] = ho[1] + hc[1];
 	}
 
 	// advance the rand streams past this batch (the reference's generators keep running across batches)
