@@ -220,6 +220,7 @@ typedef struct psvr_read_result {
 	uint32_t mate_ref_bg;
 	int32_t prim_sv_id, mate_sv_id;         /* SV:Z / MV:Z anchors of the primary record */
 	uint32_t n_seed[2];                     /* trace: UNI_SEEDs per strand */
+	uint32_t reserved1;                     /* 0 (the alignment hole in front of the 64-bit fields, named so that every byte of a record is written) */
 	uint64_t seed_hash[2], chain_hash[2];   /* trace: FNV-1a of the sorted seeds / chaining DP per strand */
 	psvr_cand_t cand[PSVR_MAX_RESULT];
 } psvr_read_result_t;

@@ -12,7 +12,7 @@ CAND_DTYPE = np.dtype([("align_score", "<u4"), ("chain_score", "<u4"), ("ref_bg"
                        ("max_index", "<u4"), ("n_cigar", "<u4"), ("cigar_off", "<i8"), ("direction", "u1"), ("mapq", "u1"), ("reserved", "u1", 6)], align=True)
 READ_DTYPE = np.dtype([("n_result", "<i4"), ("unmapped", "u1"), ("early_out", "u1"), ("is_str", "u1"), ("reserved", "u1"),
                        ("primary", "<i4"), ("secondary", "<i4"), ("has_mate", "<i4"), ("mate_chr_id", "<i4"), ("mate_ref_bg", "<u4"),
-                       ("prim_sv_id", "<i4"), ("mate_sv_id", "<i4"), ("n_seed", "<u4", 2), ("seed_hash", "<u8", 2), ("chain_hash", "<u8", 2),
+                       ("prim_sv_id", "<i4"), ("mate_sv_id", "<i4"), ("n_seed", "<u4", 2), ("reserved1", "<u4"), ("seed_hash", "<u8", 2), ("chain_hash", "<u8", 2),
                        ("cand", CAND_DTYPE, 12)], align=True)
 HDR_DTYPE = np.dtype([("n_result", "<i4"), ("unmapped", "u1"), ("early_out", "u1"), ("is_str", "u1"), ("reserved", "u1"),
                       ("primary", "<i4"), ("secondary", "<i4"), ("has_mate", "<i4"), ("mate_chr_id", "<i4"), ("mate_ref_bg", "<u4"),

@@ -1363,7 +1363,7 @@ PSVR_HD void materialize_read(const Ctx &c, long long read, psvr_read_result_t *
 	psvr_read_result_t &o = *out;
 	o.n_result = h.n_result, o.unmapped = h.unmapped, o.early_out = h.early_out, o.is_str = h.is_str, o.reserved = 0;
 	o.primary = h.primary, o.secondary = h.secondary, o.has_mate = h.has_mate, o.mate_chr_id = h.mate_chr_id, o.mate_ref_bg = h.mate_ref_bg;
-	o.prim_sv_id = h.prim_sv_id, o.mate_sv_id = h.mate_sv_id;
+	o.prim_sv_id = h.prim_sv_id, o.mate_sv_id = h.mate_sv_id, o.reserved1 = 0;
 	for (int s = 0; s < 2; ++s) {
 		const Strand &st = c.strand[read * 2 + s];
 		o.n_seed[s] = st.us_n, o.seed_hash[s] = st.seed_hash, o.chain_hash[s] = st.chain_hash;

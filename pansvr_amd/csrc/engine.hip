@@ -1734,8 +1734,9 @@ extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
 extern "C" int psvr_engine_set_stream_pos(psvr_engine_t *e, const int64_t pos[3])
 {
 	if (!e || !pos) return set_error(PSVR_ERR_ARG, "psvr_engine_set_stream_pos: null argument");
-	PSVR_HIP(hipSetDevice(e->ix->device));            // commit() reads device memory
-	if (!e->committed) { e->core.commit(); e->committed = true; }
+	PSVR_HIP(hipSetDevice(e->ix->device));
+	// (what commit() would do -- read where the last run ended and move there -- minus the readbacks: the position is given)
+	e->core.have_run = false, e->committed = true;
 	e->core.grand_pos = pos[0], e->core.hrand_pos[0] = pos[1], e->core.hrand_pos[1] = pos[2];
 	return PSVR_OK;
 }

@@ -87,5 +87,10 @@ def test_three_rank_sharding_on_the_engine_equals_one_engine():
         for x in (a, b):
             for fld in ("seed_hash", "chain_hash", "n_seed"):
                 x[fld] = 0
-        assert canon(a, cig) == canon(b, cc), "read records of rank %d differ" % r
+        ca, cb = canon(a, cig), canon(b, cc)
+        if ca != cb:                                  # say which read and which fields before failing
+            ra, rb = np.frombuffer(ca[0], dtype=a.dtype), np.frombuffer(cb[0], dtype=b.dtype)
+            bad = [i for i in range(len(ra)) if ra[i].tobytes() != rb[i].tobytes()]
+            detail = "cigar words differ only" if not bad else "first of %d reads: %d (pair %d) one=%r shard=%r" % (len(bad), bad[0], lo + bad[0] // 2, ra[bad[0]], rb[bad[0]])
+            raise AssertionError("read records of rank %d differ: %s" % (r, detail))
     eng.close(), index.close()
