@@ -24,7 +24,7 @@ def all_gather_i64(vec, device=None):
         return [t.tolist()]
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
-    return [o.tolist() for o in out]
+    return torch.stack(out).tolist()          # one readback for all ranks' values (a .tolist() per rank is a device synchronisation each)
 
 
 def resolve_stream_order(first_pos, run_at, rebase_to, device=None, max_iter=16):
