@@ -183,6 +183,9 @@ struct Ctx {
 	Arena<Seg> seg; Arena<DpDesc> dp; Arena<CandWork> cw; Arena<uint32_t> cig;
 	// DP results
 	const psvr_extz_t *dp_ez; const uint32_t *dp_cig;
+	// the reference's per-handler scratch buffer as earlier reads left it ([mate][1600], see stale_compare); stale_open: set when a
+	// compare needed a position this read's own calls had not written
+	const uint8_t *tseq_in; int32_t *stale_open;
 	int32_t trace;
 	int32_t *err;                // sticky error word (reference would xassert/abort)
 	unsigned long long *stats;   // [16] work counters
@@ -858,7 +861,7 @@ struct WalkState {
 	const uint8_t *read_str;
 	const uint64_t *read_w;      // the same strand 2-bit packed (exact unless the read holds a lower-case 'n', code 4)
 	bool packed_ok;
-	long long read; int strand;
+	long long read; int strand; int k;
 	int32_t read_score; uint32_t total_q_len;
 	bool is_simple;
 	Seg *seg; int n_seg; int bad; int seg_cap;
@@ -887,6 +890,8 @@ PSVR_HD int walk_mismatch(WalkState &w, int read_st, int read_ed, int ref_st, in
 	return nm > 3 ? 3 : nm;
 }
 
+PSVR_HDN inline int stale_compare(const Ctx &c, long long read, int k, int strand, int read_st, int qlen, int ref_st, int tlen);
+
 // KSW_ALN_handler::alignment (rr.cpp:910-986): simple pieces are scored here, DP pieces are queued
 PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, int ref_ed, int type)
 {
@@ -901,20 +906,18 @@ PSVR_HD void walk_alignment(WalkState &w, int read_st, int read_ed, int ref_st, 
 		w.is_simple = true;
 		nm = qlen + tlen;
 	} else if (qlen == tlen || type != 2) {
-		if (w.packed_ok && tlen >= qlen) {
+		if (tlen < qlen) {
+			// only a left extension clamped at reference position 0 gets here (a right extension's window is qlen + 30, an end-to-end
+			// piece is compared when qlen == tlen): the reference goes on comparing against what its scratch buffer still holds
+			nm = (uint32_t)stale_compare(c, w.read, w.k, w.strand, read_st, (int)qlen, ref_st, (int)tlen);
+		} else if (w.packed_ok) {
 			// the reference counts position-wise mismatches up to 6; a left extension compares the reversed sequences, i.e. the
 			// read piece against the LAST qlen bases of the reference window
 			nm = (uint32_t)mismatches_packed(w.read_w, (uint64_t)read_st, c.idx.ref_seq, (uint64_t)ref_st + (type == 0 ? tlen - qlen : 0), (int)qlen, 6);
-		} else if (type == 0) {   // left extension compares the reversed sequences
-			for (uint32_t i = 0; i < qlen && nm < 6; ++i) {
-				int tb = i < tlen ? base_at(c.idx.ref_seq, (uint64_t)ref_st + (tlen - 1 - i)) : 0;
-				nm += w.read_str[read_st + (qlen - 1 - i)] != tb;
-			}
+		} else if (type == 0) {   // left extension compares the reversed sequences (reads with a lower-case 'n': the per-base bytes exist)
+			for (uint32_t i = 0; i < qlen && nm < 6; ++i) nm += w.read_str[read_st + (qlen - 1 - i)] != base_at(c.idx.ref_seq, (uint64_t)ref_st + (tlen - 1 - i));
 		} else {
-			for (uint32_t i = 0; i < qlen && nm < 6; ++i) {
-				int tb = i < tlen ? base_at(c.idx.ref_seq, (uint64_t)ref_st + i) : 0;
-				nm += w.read_str[read_st + i] != tb;
-			}
+			for (uint32_t i = 0; i < qlen && nm < 6; ++i) nm += w.read_str[read_st + i] != base_at(c.idx.ref_seq, (uint64_t)ref_st + i);
 		}
 		if (nm == 1 || (nm < 6 && ((nm << 3) < qlen))) w.is_simple = true;
 	}
@@ -962,9 +965,11 @@ PSVR_HD int walk_seg_cap(const Ctx &c, long long read, int k)
 	return cap > kSegMax ? kSegMax : cap;
 }
 
-// candidate k of `read`; its CandWork slot and its slice of the piece arena were reserved by walk_read
-struct DpLast { Seg *seg; int q_st, qlen, ref_st, tlen, type, strand; };
-PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap, int dp_first, DpLast &last)
+// The traversal of get_ksw_score (rr.cpp:308-400) for candidate k of `read`: which pieces of the chain are checked for mismatches
+// (get_misMatch), which are aligned (alignment: right extension first, end-to-end pieces, the left extension last) and which gap
+// penalties apply.  Its control flow depends on the chain alone, not on what the sink answers, so the same traversal serves the walk
+// proper (WalkSink) and the replay of a candidate's reference-window calls (StaleSink, below).
+template <class Sink> PSVR_HD void chain_calls(const Ctx &c, long long read, int k, Sink &sk)
 {
 	const ChainCand &cc = c.ccand[read * 12 + k];
 	const int is_rev = cc.direction == kRev;
@@ -972,14 +977,9 @@ PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long lon
 	const USeed *va = c.us.base + st.us_off;
 	const PathN *dp = c.path + st.us_off;
 	const int read_l = c.read_l[read];
-	WalkState w;
-	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev;
-	w.read_w = c.rb + (read * 2 + is_rev) * (long long)c.wmax, w.packed_ok = c.has_n4[read] == 0;
-	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap, w.n_dp = dp_first;
-	w.last_seg = nullptr;
 	const int BIG = 0x7fffffff;
 	int aln_read_begin = read_l, aln_read_end = read_l, aln_ref_begin = BIG, aln_ref_end = BIG;
-	int last_aln_begin = read_l, last_ref_begin = BIG, unitig_mis = 0;
+	int last_aln_begin = read_l, last_ref_begin = BIG;
 	for (int node = (int)cc.max_index; node != -1;) {
 		int mrb = (int)va[node].read_begin, mre = (int)va[node].read_end, mfb = (int)va[node].ref_begin, mfe = (int)va[node].ref_end;
 		aln_read_begin = aln_read_begin < mre ? aln_read_begin : mre;
@@ -987,21 +987,16 @@ PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long lon
 		if (aln_read_begin <= aln_read_end) {
 			if (aln_read_end < last_aln_begin) {
 				int ml = last_aln_begin - aln_read_end;
-				unitig_mis += walk_mismatch(w, aln_read_end, aln_read_end + ml, last_ref_begin, last_ref_begin + ml);
-				seg_lit(w, 0, ml);
+				sk.mismatch(aln_read_end, aln_read_end + ml, last_ref_begin, last_ref_begin + ml);
 			}
 			last_aln_begin = aln_read_begin;
 			if (aln_ref_end == BIG) {
 				aln_ref_end = aln_ref_begin + (aln_read_end - aln_read_begin) + 30;
-				walk_alignment(w, aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 1);
-			} else walk_alignment(w, aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 2);
+				sk.alignment(aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 1);
+			} else sk.alignment(aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 2);
 		} else {
 			int dr = aln_read_end - aln_read_begin, df = aln_ref_end - aln_ref_begin;
-			if (dr != df) {
-				int dl = df - dr, a = dl > 0 ? dl : -dl;
-				int s1 = c.par.gap_open + (a - 1) * c.par.gap_ex, s2 = c.par.gap_open2 + (a - 1) * c.par.gap_ex2;
-				w.read_score -= s1 < s2 ? s1 : s2;
-			}
+			if (dr != df) sk.gap(df - dr);
 		}
 		aln_read_end = mrb, last_ref_begin = mfb, aln_ref_end = mfb;
 		int nx = dp[node].pre_node;
@@ -1010,21 +1005,114 @@ PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long lon
 	}
 	if (aln_read_end < last_aln_begin) {
 		int ml = last_aln_begin - aln_read_end;
-		unitig_mis += walk_mismatch(w, aln_read_end, aln_read_end + ml, last_ref_begin, last_ref_begin + ml);
-		seg_lit(w, 0, ml);
+		sk.mismatch(aln_read_end, aln_read_end + ml, last_ref_begin, last_ref_begin + ml);
 	}
 	aln_read_begin = 0, aln_ref_begin = 0;
-	int rba = 0;
 	if (aln_read_begin < aln_read_end) {
 		aln_ref_begin = aln_ref_end - (aln_read_end - aln_read_begin) - 30;
 		aln_ref_begin = aln_ref_begin > 0 ? aln_ref_begin : 0;
-		walk_alignment(w, aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end, 0);
-		if (aln_ref_end > aln_ref_begin) rba = w.is_simple ? aln_ref_end - aln_ref_begin - 30 : aln_ref_end - aln_ref_begin;
+		sk.left(aln_read_begin, aln_read_end, aln_ref_begin, aln_ref_end);
 	}
+}
+
+// ---- the reference's scratch buffer ------------------------------------------------------------
+// KSW_ALN_handler keeps ONE 1600-byte buffer `tseq` per handler (one handler per mate at -t 1): every get_misMatch / alignment call
+// writes the first tlen bytes (get_refseq; reversed for a left extension) and nothing else, rr.cpp:899,918-925.  When a left
+// extension is clamped at reference position 0 and its window is shorter than the read piece (0 < tlen < qlen), the simple-compare
+// loop (rr.cpp:939) reads positions tlen..qlen-1 of that buffer: what EARLIER calls left there -- position i holds the byte the
+// latest call with tlen' > i wrote.  StaleSink replays the calls of one candidate onto a window [lo, lo + 64) of the buffer.
+struct StaleSink {
+	const Ctx *c;
+	int lo;                      // window start; 64 positions, 2 bits each (reference codes are 0..3)
+	uint64_t code_lo, code_hi;   // positions lo..lo+31, lo+32..lo+63
+	uint64_t have;               // bit i: position lo + i written by a replayed call
+	bool skip_left;              // the candidate under evaluation: its own left extension is the call being answered
+	PSVR_HD void put(uint32_t ref_st, int tlen, bool rev)
+	{
+		const int hi = tlen < lo + 64 ? tlen : lo + 64;
+		for (int i = lo; i < hi; ++i) {
+			const uint64_t b = (uint64_t)base_at(c->idx.ref_seq, (uint64_t)ref_st + (uint64_t)(rev ? tlen - 1 - i : i));
+			const int j = i - lo, sh = (j & 31) << 1;
+			if (j < 32) code_lo = (code_lo & ~(3ull << sh)) | (b << sh);
+			else code_hi = (code_hi & ~(3ull << sh)) | (b << sh);
+			have |= 1ull << j;
+		}
+	}
+	PSVR_HD static int tlen_of(int ref_st, int ref_ed, bool &ok) { const int t = ref_ed < ref_st ? 0 : ref_ed - ref_st; ok = t < 1600; return t; }
+	PSVR_HD void mismatch(int, int, int ref_st, int ref_ed) { bool ok; const int t = tlen_of(ref_st, ref_ed, ok); if (ok) put((uint32_t)ref_st, t, false); }
+	PSVR_HD void alignment(int, int, int ref_st, int ref_ed, int) { bool ok; const int t = tlen_of(ref_st, ref_ed, ok); if (ok) put((uint32_t)ref_st, t, false); }
+	PSVR_HD void left(int, int, int ref_st, int ref_ed) { if (skip_left) return; bool ok; const int t = tlen_of(ref_st, ref_ed, ok); if (ok) put((uint32_t)ref_st, t, true); }
+	PSVR_HD void gap(int) {}
+	PSVR_HD int at(int i) const { const int j = i - lo, sh = (j & 31) << 1; return (int)(((j < 32 ? code_lo : code_hi) >> sh) & 3); }
+};
+
+// the compare of rr.cpp:939 for candidate k's clamped left extension: positions < tlen against the (reversed) window, the rest
+// against the scratch buffer as the calls so far have left it.  Resolved here: what this read's own earlier calls wrote (candidates
+// 0..k-1 in full, candidate k up to its left extension).  A position none of them reached keeps c.tseq_in (what earlier reads of
+// this mate left: see engine_core.h) and is counted in c.stale_open.
+PSVR_HDN inline int stale_compare(const Ctx &c, long long read, int k, int strand, int read_st, int qlen, int ref_st, int tlen)
+{
+	const bool bytes = c.has_n4[read] != 0;
+	const uint8_t *rs = c.bin + (read * 2 + strand) * (long long)c.lmax;
+	const uint64_t *rw = c.rb + (read * 2 + strand) * (long long)c.wmax;
+	auto qrev = [&](int i) { const int p = read_st + (qlen - 1 - i); return bytes ? (int)rs[p] : base_at(rw, (uint64_t)p); };
+	int nm = 0;
+	for (int i = 0; i < tlen && nm < 6; ++i) nm += qrev(i) != base_at(c.idx.ref_seq, (uint64_t)ref_st + (uint64_t)(tlen - 1 - i));
+	for (int lo = tlen; lo < qlen && nm < 6; lo += 64) {
+		StaleSink sk;
+		sk.c = &c, sk.lo = lo, sk.code_lo = sk.code_hi = 0, sk.have = 0;
+		for (int kk = 0; kk <= k; ++kk) { sk.skip_left = kk == k; chain_calls(c, read, kk, sk); }
+		const int hi = qlen < lo + 64 ? qlen : lo + 64;
+		for (int i = lo; i < hi && nm < 6; ++i) {
+			int b;
+			if ((sk.have >> (i - lo)) & 1) b = sk.at(i);
+			else {
+				b = c.tseq_in ? (int)c.tseq_in[(read & 1) * 1600 + i] : 0;
+				if (c.stale_open) *c.stale_open = 1;
+			}
+			nm += qrev(i) != b;
+		}
+	}
+	return nm;
+}
+
+// candidate k of `read`; its CandWork slot and its slice of the piece arena were reserved by walk_read
+struct DpLast { Seg *seg; int q_st, qlen, ref_st, tlen, type, strand; };
+struct WalkSink {
+	WalkState w;
+	int unitig_mis, rba;
+	PSVR_HD void mismatch(int read_st, int read_ed, int ref_st, int ref_ed) { unitig_mis += walk_mismatch(w, read_st, read_ed, ref_st, ref_ed); seg_lit(w, 0, read_ed - read_st); }
+	PSVR_HD void alignment(int read_st, int read_ed, int ref_st, int ref_ed, int type) { walk_alignment(w, read_st, read_ed, ref_st, ref_ed, type); }
+	PSVR_HD void left(int read_st, int read_ed, int ref_st, int ref_ed)
+	{
+		walk_alignment(w, read_st, read_ed, ref_st, ref_ed, 0);
+		if (ref_ed > ref_st) rba = w.is_simple ? ref_ed - ref_st - 30 : ref_ed - ref_st;
+	}
+	PSVR_HD void gap(int dl)
+	{
+		const Ctx &c = *w.c;
+		const int a = dl > 0 ? dl : -dl;
+		const int s1 = c.par.gap_open + (a - 1) * c.par.gap_ex, s2 = c.par.gap_open2 + (a - 1) * c.par.gap_ex2;
+		w.read_score -= s1 < s2 ? s1 : s2;
+	}
+};
+PSVR_HDN inline int walk_candidate(const Ctx &c, long long read, int k, long long cwi, long long so, int seg_cap, int dp_first, DpLast &last)
+{
+	const ChainCand &cc = c.ccand[read * 12 + k];
+	const int is_rev = cc.direction == kRev;
+	const int read_l = c.read_l[read];
+	WalkSink sk;
+	WalkState &w = sk.w;
+	w.c = &c, w.read_str = c.bin + (read * 2 + is_rev) * (long long)c.lmax, w.read = read, w.strand = is_rev, w.k = k;
+	w.read_w = c.rb + (read * 2 + is_rev) * (long long)c.wmax, w.packed_ok = c.has_n4[read] == 0;
+	w.read_score = 0, w.total_q_len = 0, w.is_simple = false, w.seg = c.seg.base + so, w.n_seg = 0, w.bad = 0, w.seg_cap = seg_cap, w.n_dp = dp_first;
+	w.last_seg = nullptr;
+	sk.unitig_mis = 0, sk.rba = 0;
+	chain_calls(c, read, k, sk);
 	w.read_score += (int32_t)((read_l - (int)w.total_q_len) * c.par.match);
-	w.read_score -= unitig_mis * (c.par.match + c.par.mismatch);
+	w.read_score -= sk.unitig_mis * (c.par.match + c.par.mismatch);
 	CandWork &cw = c.cw.base[cwi];
-	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = rba, cw.bad = w.bad, cw.seg_off = so;
+	cw.read = (int32_t)read, cw.k = k, cw.n_seg = w.n_seg, cw.read_score = w.read_score, cw.rba = sk.rba, cw.bad = w.bad, cw.seg_off = so;
 	if (w.bad) *c.err = 10 + w.bad;
 	stat_add(c, ST_CAND, 1);
 	if (w.last_seg) last.seg = w.last_seg, last.q_st = w.last_q_st, last.qlen = w.last_qlen, last.ref_st = w.last_ref_st, last.tlen = w.last_tlen, last.type = w.last_type, last.strand = w.last_strand;

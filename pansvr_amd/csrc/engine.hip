@@ -573,7 +573,8 @@ template <class T> __device__ __forceinline__ long long block_arena_alloc(const 
 	__syncthreads();                                                       // wsum / bbase may be written again by the next call
 	return b < 0 ? -1 : b + (long long)mine;
 }
-__global__ __launch_bounds__(kBlock) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
+// (four wavefronts per SIMD: the rare scratch-buffer replay of stale_compare must not cost the common path a wavefront)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
 	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
 	const long long read = i < (long long)*cnt ? (long long)list[i] : -1;  // no early exit: the reservations are made by the whole workgroup
@@ -1841,9 +1842,9 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
 	const RunStats &s = e->core.stats;
 	snprintf(buf, n,
-	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
-	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();

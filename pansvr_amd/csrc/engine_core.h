@@ -78,7 +78,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 };
 
 struct RunStats {
-	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0;
+	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0;
 	unsigned long long counters[16] = {0};
 };
 
@@ -117,7 +117,7 @@ template <class BE> struct EngineCore {
 	// walk bumps per read shared one line
 	static constexpr int kTopStride = kArenaTopStride * kArenaMaxShards;   // words between two arenas' first counters
 	unsigned long long *d_atops = nullptr;
-	int32_t *d_flags = nullptr;               // [8] overflow flags + err
+	int32_t *d_flags = nullptr;               // [8] six overflow flags, the error word, [7] stale_open (aln_device.h stale_compare)
 	unsigned long long cap_mem = 0, cap_us = 0, cap_seg = 0, cap_dp = 0, cap_cw = 0, cap_cig = 0;
 	DpIO dp;
 	long long dp_cap_q = 0, dp_cap_t = 0, dp_cap_c = 0, dp_cap_n = 0;
@@ -306,7 +306,7 @@ template <class BE> struct EngineCore {
 		for (void *p : owned) if (!p) { err = "device allocation failed"; return PSVR_ERR_NOMEM; }
 		free_arenas();
 		if (!alloc_arenas()) { err = "device allocation failed (arenas)"; return PSVR_ERR_NOMEM; }
-		c.err = d_flags + 6;
+		c.err = d_flags + 6, c.stale_open = d_flags + 7;
 		be.h2d(d_bases, bases + b0, total_bases);
 		be.h2d(d_off, base_off, (R + 1) * 8);
 		be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
@@ -415,6 +415,7 @@ template <class BE> struct EngineCore {
 		int32_t fl[8];
 		be.d2h2(tops, d_atops + 3 * kTopStride, sizeof tops, fl, d_flags, 32);
 		long long dp_end = (long long)tops[0], cw_end = (long long)tops[kTopStride];
+		if (fl[7]) stats.stale_open = 1;
 		// An arena that filled up in the stages so far ends the round here: what follows (assembly, the reads' tails) would walk records
 		// that were never written.  Bits: 1 dp, 2 cw, 4 seg, 8 us, 16 mem.
 		{
@@ -624,6 +625,7 @@ template <class BE> struct EngineCore {
 			int32_t flags[8];
 			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 32);
 			const unsigned long long nd[2] = {nd17[0], nd17[16]};
+			if (flags[7]) stats.stale_open = 1;
 			if (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5]) { c.stats = stats_ptr; return grow_and_rerun(flags, trace, want_stats, depth); }
 			if (flags[6] == 2 || flags[6] == 3) {      // a rand table ran out: extend and restart the batch
 				be.dzero(d_flags, 32);

@@ -28,6 +28,18 @@ DATASETS = {
                 reads={"reads250": dict(n_pairs=2000, seed=53, L=250, frag=(400, 700), maxindel=40, n_frac=0.01, stat=(250, 300, 550, 800)),
                        # reads beyond 288 bases take the engine's wavefront-per-read preparation (the lane-per-pair one keeps a read in registers)
                        "long400": dict(n_pairs=300, seed=61, L=400, frag=(700, 900), maxindel=20, n_frac=0.03, str_frac=0.05, stat=(400, 600, 800, 1000))}),
+    # the three reference branches no other set reaches, on one anchor set: 34 anchors, 27 of them with alleles that hold 300 copies each
+    # of one 30 bp element (a unipath with 8100 > POS_N_MAX_LEVEL2 positions: expand_seed returns and drops the seeds behind it,
+    # deBGA_index.cpp:224), long unique flanks for reads of 1100-1500 bases whose single extension exceeds 10^6 DP cells (the made-up
+    # CIGAR of align_non_splice, read_realignment.cpp:874-887), and reads over the very start of the reference (left extension clamped
+    # at position 0 with a window shorter than the read piece: the stale-scratch compare of read_realignment.cpp:939).
+    # The index is not committed (0.5 Mbp): tests build it with `panSVR index` and check the files against the SHA-256 of the
+    # reference builder's (tests/golden/fx5/idx.sha256).
+    "fx5": dict(index="sha256", anchors=dict(n_anchors=34, seed=71, edge=900, allele=(800, 1600), repeat_len=30, repeat_copies=300, repeat_spacer=24, repeat_anchors=27),
+                reads={"hicopy": dict(n_pairs=400, seed=73, L=150, frag=(300, 420), center_frac=0.8, miss_frac=0.05, anchors=(1, 27)),
+                       "long": dict(kind="sparse_long", n_pairs=150, seed=79, anchors=(27, 34)),
+                       "clamp0": dict(kind="clamp0", n_pairs=300, seed=83),
+                       "clamp0s": dict(kind="clamp0", n_pairs=400, seed=89, small=True)}),
 }
 
 
@@ -41,6 +53,11 @@ def reads_of(name, rname):
     # by default anchor 0 is not sampled: the reference mis-assigns it (calloc'ed chr_file_n) and a left extension that
     # clamps at reference position 0 reads stale scratch bytes there; the sets with an `anchors` range include it on purpose
     lo, hi = kw.pop("anchors", (1, len(a)))
+    kind = kw.pop("kind", None)
+    if kind == "sparse_long":
+        return synth.make_sparse_long_reads(a[lo:hi], **kw)
+    if kind == "clamp0":
+        return synth.make_clamp0_reads(a, **kw)
     return synth.make_reads(a[lo:hi], **kw)
 
 

@@ -18,10 +18,13 @@ def rand_dna(rng, n):
     return ACGT[rng.randint(0, 4, size=n)].tobytes()
 
 
-def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, dup_frac=0.0, repeat_len=0):
+def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, dup_frac=0.0, repeat_len=0, repeat_copies=1, repeat_spacer=24, repeat_anchors=None):
     """INS anchors named ID_chr_st_len_TYPE_bp1_bp2_end_vcfid (get_anchor_ref.hpp:322-323).
     str_frac: fraction of anchors whose allele is a short tandem repeat; dup_frac: fraction of anchors that
-    re-use the previous anchor's left flank (identical flanks => tied chains)."""
+    re-use the previous anchor's left flank (identical flanks => tied chains); repeat_len: one element shared by every allele;
+    repeat_copies > 1: every allele holds that many copies of it, `repeat_spacer` unique bases apart (n_anchors x repeat_copies
+    positions of one unipath: beyond POS_N_MAX_LEVEL2 = 8000 expand_seed gives up, deBGA_index.cpp:224); repeat_anchors: only the
+    first so many anchors hold the element."""
     rng = np.random.RandomState(seed)
     out = []
     prev_left = None
@@ -37,7 +40,11 @@ def make_anchors(n_anchors, seed=7, edge=500, allele=(60, 300), str_frac=0.0, du
             al = (unit * (alen // len(unit) + 1))[:alen]
         else:
             al = rand_dna(rng, alen)
-        if repeat_len:
+        if repeat_anchors is not None and i >= repeat_anchors:
+            pass
+        elif repeat_len and repeat_copies > 1:
+            al = al[:alen // 2] + b"".join(repeat + rand_dna(rng, repeat_spacer) for _ in range(repeat_copies)) + al[alen // 2:]
+        elif repeat_len:
             al = al[:alen // 2] + repeat + al[alen // 2:]
         right = rand_dna(rng, edge)
         seq = left + al + right
@@ -160,6 +167,103 @@ def _make_reads(anchors, n_pairs, seed, L, frag, maxindel, miss_frac, n_frac, st
             c += "FLAG_%d_20_CIGAR_%s_MATE_0_%d_%d_TAG_NM:i:3_" % (flag, cigar, mpos, isize if fwd else -isize)
             qual = bytes(33 + rng.randint(20, 41, size=Lk).astype(np.uint8))
             recs.append((names, c, ends[e].decode(), qual.decode()))
+    return recs
+
+
+def _sub(rng, b, p):
+    b[p] = b"ACGT"[(b"ACGT".index(b[p]) + 1 + rng.randint(3)) % 4]
+
+
+def _pair_records(rng, p, ends, st_pos, off, flen, stat, prefix="s"):
+    """Two FASTQ records of one pair in fc_signal's wire format (original alignment: 40S<L-40>M, score 140)."""
+    recs = []
+    swap = rng.random_sample() < 0.5
+    pos1, pos2 = st_pos + off, st_pos + off + max(0, flen - len(ends[1]))
+    for k in range(2):
+        e = k ^ int(swap)
+        fwd = e == 0
+        Lk = len(ends[e])
+        pos, mpos = (pos1, pos2) if fwd else (pos2, pos1)
+        flag = (0x40 if k == 0 else 0x80) | 0x1 | (0 if fwd else 0x10) | (0x20 if fwd else 0)
+        c = "0_%d_40_140_20_20_0_0_%d_%sNNY_%sNNY_" % (pos, flen, "F" if fwd else "R", "R" if fwd else "F")
+        if p == 0 and k == 0 and stat is not None:
+            c += "STAT_%d_%d_%d_%d_" % stat
+        c += "FLAG_%d_20_CIGAR_40S%dM_MATE_0_%d_%d_TAG_NM:i:3_" % (flag, Lk - 40, mpos, flen if fwd else -flen)
+        qual = bytes(33 + rng.randint(20, 41, size=Lk).astype(np.uint8))
+        recs.append(("%s%07d" % (prefix, p), c, ends[e].decode(), qual.decode()))
+    return recs
+
+
+def make_sparse_long_reads(anchors, n_pairs, seed, L=(1100, 1500), keep=(60, 160), period=(9, 16), stat=(1400, 1500, 2200, 3000)):
+    """Long reads of which only one end seeds: the other L - keep bases carry a substitution every `period` bases (no 20-mer
+    survives), so the candidate is one seed cluster plus ONE extension of ~1000+ bases with far more than 6 mismatches -- the DP
+    problem of more than 10^6 cells that align_non_splice answers with a made-up <qlen>I<tlen>N CIGAR (read_realignment.cpp:874-887).
+    A third of the reads keep both ends (two extensions short enough for the DP, a 10^6-cell end-to-end gap cannot arise: chained
+    seeds are at most 50 / 400 read bases apart), a few are exact."""
+    rng = np.random.RandomState(seed)
+    recs = []
+    for p in range(n_pairs):
+        name, seq = anchors[rng.randint(len(anchors))]
+        st_pos = int(name.split("_")[2])
+        ends = []
+        L0 = [int(rng.randint(L[0], L[1] + 1)) for _ in range(2)]
+        flen = min(len(seq) - 2, max(L0) + rng.randint(50, 400))
+        off = rng.randint(0, len(seq) - flen - 1)
+        fragment = seq[off:off + flen]
+        for e in range(2):
+            Lr = min(L0[e], flen)
+            src = fragment[:Lr] if e == 0 else revcomp(fragment[flen - Lr:flen])
+            b = bytearray(src)
+            mode = rng.randint(0, 7)              # 0-2 keep the head, 3-5 keep the tail, 6 exact
+            k = int(rng.randint(keep[0], keep[1] + 1))
+            if mode < 6:
+                lo, hi = (k, Lr) if mode < 3 else (0, Lr - k)
+                if mode % 3 == 2:                 # both ends seed: mutate only the middle
+                    lo, hi = k, Lr - k
+                q = lo + int(rng.randint(0, period[0]))
+                while q < hi:
+                    _sub(rng, b, q)
+                    q += int(rng.randint(period[0], period[1] + 1))
+            ends.append(bytes(b))
+        recs += _pair_records(rng, p, ends, st_pos, off, flen, stat, "l")
+    return recs
+
+
+def make_clamp0_reads(anchors, n_pairs, seed, L=150, stat=(150, 200, 400, 600), small=False):
+    """Reads over the START of the first anchor, i.e. of the whole concatenated reference: a left extension there is clamped at
+    reference position 0 (read_realignment.cpp:323 `MAX(aln_ref_begin, 0)`), and when the read reaches further left than the
+    reference (an overhang of unrelated bases, an insertion near the start) the window is SHORTER than the read piece: the reference
+    then compares the piece's remaining bases with whatever its 1600-byte scratch buffer holds from earlier calls
+    (KSW_ALN_handler::alignment, read_realignment.cpp:939).  Every read here starts at anchor offset 0..12 with 0..40 foreign
+    bases in front and one or two edits within the first 30 anchor bases, so that the first seed starts a little inside; mates
+    come from 150-400 bases further in.  Both orientations.  `small`: overhangs of 1-4 bases behind a single substitution -- the
+    pieces whose outcome (scored as a plain match run, or handed to the DP) hangs on what the stale bytes happen to be."""
+    rng = np.random.RandomState(seed)
+    name, seq = anchors[0]
+    st_pos = int(name.split("_")[2])
+    recs = []
+    for p in range(n_pairs):
+        over = int(rng.randint(1, 5)) if small else int(rng.randint(0, 41))
+        a0 = int(rng.randint(0, 3)) if small else int(rng.randint(0, 13))
+        body = bytearray(seq[a0:a0 + L - over])
+        for _ in range(1 if small else int(rng.randint(1, 3))):
+            q = int(rng.randint(3, 40)) if small else int(rng.randint(1, 30))
+            kind = 0 if small else rng.randint(0, 4)
+            if kind < 2:
+                _sub(rng, body, q)
+            elif kind == 2:
+                del body[q:q + int(rng.randint(1, 4))]
+            else:
+                body[q:q] = rand_dna(rng, int(rng.randint(1, 4)))
+        r0 = (rand_dna(rng, over) + bytes(body))[:L]
+        flen = int(rng.randint(300, 551))
+        m = bytearray(seq[a0 + flen - L:a0 + flen])
+        if rng.random_sample() < 0.5:
+            _sub(rng, m, int(rng.randint(L)))
+        ends = [r0, revcomp(bytes(m))]
+        if rng.random_sample() < 0.3:             # both reads turned over: the overhanging read then aligns through its reverse strand
+            ends = [revcomp(r0), bytes(m)]
+        recs += _pair_records(rng, p, ends, st_pos, a0, flen, stat, "c")
     return recs
 
 

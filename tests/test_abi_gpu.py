@@ -36,7 +36,7 @@ def _inputs(name="fx2", rname="reads150", limit=600):
 def _index(name="fx2", device=0):
     from pansvr_amd import aln
     names = [l.split("SN:")[1].split("\t")[0] for l in synth.header_text().split("\n") if l.startswith("@SQ")]
-    return aln.Index(index_fixture.load_arrays(os.path.join(ac.golden_dir(name), "idx")), names, device=device)
+    return aln.Index(index_fixture.load_arrays(ac.index_dir(name)), names, device=device)
 
 
 def test_align_batch_equals_upload_run_download_and_the_reference():

@@ -22,7 +22,7 @@ def test_gpu_engine_matches_reference_records(name, rname):
     tmp = tempfile.mkdtemp(prefix="psvr_gpu_")
     rec = os.path.join(tmp, "records.jsonl")
     cmd = [CLI, "aln", "-S", "-o", os.path.join(tmp, "out.sam"), "-p", os.path.join(tmp, "ori.sam"), "--records", rec, "--trace",
-           os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+           ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [l for l in open(rec).read().split("\n") if l.strip()]
@@ -51,7 +51,7 @@ def test_gpu_cli_bam_output_equals_sam_text():
     name, rname = "fx2", "reads150"
     w = ac.workdir(name)
     tmp = tempfile.mkdtemp(prefix="psvr_bam_")
-    base = [os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+    base = [ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
     for mode, ext in (["-S"], "sam"), ([], "bam"):
         r = subprocess.run([CLI, "aln"] + mode + ["-o", os.path.join(tmp, "out." + ext), "-p", os.path.join(tmp, "ori." + ext)] + base,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -81,7 +81,7 @@ def test_gpu_cli_scoring_options_match_reference(score):
     rec = os.path.join(tmp, "records.jsonl")
     M, m, O, E, P, F, z = score
     cmd = [CLI, "aln", "-S", "-M", str(M), "-m", str(m), "-O", str(O), "-E", str(E), "-P", str(P), "-F", str(F), "-z", str(z), "-o", os.path.join(tmp, "o.sam"), "-p",
-           os.path.join(tmp, "p.sam"), "--records", rec, "--trace", os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+           os.path.join(tmp, "p.sam"), "--records", rec, "--trace", ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [normalise(l) for l in open(rec).read().split("\n") if l.strip()]
@@ -96,7 +96,7 @@ def _run_cli(tmp, tag, name, rname, extra):
     w = ac.workdir(name)
     o = os.path.join(tmp, tag)
     r = subprocess.run([CLI, "aln", "-S", "-t", "4", "-o", o + ".sam", "-p", o + ".ori.sam", "--records", o + ".jsonl"] + extra +
-                       [os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                       [ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return o, r.stderr.decode()
 
@@ -189,7 +189,7 @@ def test_gpu_lane_per_pair_preparation_on_the_golden_sets(name, rname):
     tmp = tempfile.mkdtemp(prefix="psvr_gpu_")
     rec = os.path.join(tmp, "records.jsonl")
     cmd = [CLI, "aln", "-S", "-o", os.path.join(tmp, "out.sam"), "-p", os.path.join(tmp, "ori.sam"), "--records", rec, "--trace",
-           os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
+           ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PSVR_PREP_PAIR_MIN="1"))
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [l for l in open(rec).read().split("\n") if l.strip()]

@@ -36,7 +36,7 @@ def emu():
 @pytest.mark.parametrize("name,rname", CASES)
 def test_emulated_engine_matches_reference_records(emu, name, rname):
     w = ac.workdir(name)
-    out = subprocess.run([emu, os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--trace"],
+    out = subprocess.run([emu, ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--trace"],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
     got = [l for l in out.split("\n") if l.strip()]
     want = ac.golden_lines(name, rname)

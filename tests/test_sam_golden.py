@@ -30,7 +30,7 @@ def golden_text(name, rname, ext):
 def test_formatter_writes_the_reference_sam_files(emu, name, rname):
     w = ac.workdir(name)
     tmp = tempfile.mkdtemp(prefix="psvr_samg_")
-    r = subprocess.run([emu, os.path.join(ac.golden_dir(name), "idx"), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--no-records",
+    r = subprocess.run([emu, ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--no-records",
                         "--sam", os.path.join(tmp, "o.sam"), "--ori-sam", os.path.join(tmp, "p.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-1000:]
     for got_fn, ext in (("o.sam", ".sam.gz"), ("p.sam", ".ori.sam.gz")):

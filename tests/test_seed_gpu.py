@@ -34,7 +34,7 @@ def test_known_answers_are_consistent_with_the_index_fixtures():
     """(no GPU) the ranges the reference printed, recomputed from the fixture arrays with numpy: the 22-mers of bucket kmer >> 12
     whose stored low bits >> 4 equal kmer & 0xfff."""
     for name, s in load_kat().items():
-        d = os.path.join(ac.golden_dir(name), "idx")
+        d = ac.index_dir(name)
         sp = np.fromfile(os.path.join(d, "unipath_g.hash.sparse"), dtype=np.uint32).reshape(-1, 2)      # (bucket, count) of the non-empty buckets
         ids, start = sp[:, 0].astype(np.int64), np.concatenate([[0], np.cumsum(sp[:, 1].astype(np.int64))])
         kg = np.fromfile(os.path.join(d, "unipath_g.kmer"), dtype=np.uint32)
@@ -57,7 +57,7 @@ def test_seed_entry_points_match_the_reference_functions():
     names = [l.split("SN:")[1].split("\t")[0] for l in synth.header_text().split("\n") if l.startswith("@SQ")]
     total_mems = 0
     for name, s in load_kat().items():
-        index = aln.Index(index_fixture.load_arrays(os.path.join(ac.golden_dir(name), "idx")), names, device=0)
+        index = aln.Index(index_fixture.load_arrays(ac.index_dir(name)), names, device=0)
         probes = s["probes"]
         n = len(probes)
         kmers = np.array([p["kmer"] for p in probes], dtype=np.uint64)
