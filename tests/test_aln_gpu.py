@@ -180,7 +180,7 @@ def test_gpu_cli_reads_name_sorted_bam_like_the_two_commands():
     assert open(os.path.join(tmp, "h1.sam"), "rb").read() == open(os.path.join(tmp, "h2.sam"), "rb").read()
 
 
-@pytest.mark.parametrize("name,rname", [("fx2", "reads150"), ("fx2", "reads250"), ("fx3", "ragged"), ("fx3", "lower"), ("fx1", "anchor0")])
+@pytest.mark.parametrize("name,rname", [("fx2", "reads150"), ("fx2", "reads250"), ("fx3", "ragged"), ("fx3", "lower"), ("fx1", "anchor0"), ("fx5", "clamp0s"), ("fx5", "hicopy")])
 def test_gpu_lane_per_pair_preparation_on_the_golden_sets(name, rname):
     """The engine prepares the reads of a round with one lane per pair (k_prep_pair) only when the round is large enough to fill the
     chip; PSVR_PREP_PAIR_MIN=1 sends these small sets down that path too: N draws in order, lower-case n (redone by the reference
