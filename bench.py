@@ -265,7 +265,7 @@ def main():
 
     roofline, cpu, e2e = None, None, None
     if rank == 0:
-        bytes_per_read, seed_bytes_per_read = None, None
+        bytes_per_read, seed_bytes_per_read, own_bytes = None, None, None
         base = [idx_dir, fq, os.path.join(tmp, "header.sam")]
         if n_cpu > 0:
             # algorithmic bytes per read, counted by the oracle on a part of the CPU sample; the executables report the
@@ -276,6 +276,10 @@ def main():
             cs = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
             bytes_per_read = cs["bytes"]["total"] / (2.0 * n_port)
             seed_bytes_per_read = (cs["bytes"]["probe"] + cs["bytes"]["hit"] + cs["bytes"]["read"]) / (2.0 * n_port)
+            # each kernel's OWN share of the algorithmic bytes (SURVEY 8(d) terms, per read): bases in -> prep; hash probes + MEM hits -> seeding;
+            # unipath positions -> chaining; reference windows -> walk + fetch; ksw_extz_t + CIGAR out -> the DP kernels; candidate records -> assembly + tails
+            b = {k: v / (2.0 * n_port) for k, v in cs["bytes"].items()}
+            own_bytes = {"k_prep": b["read"], "k_seed": b["probe"] + b["hit"], "k_chain": b["pos"], "k_walk+k_dp_fetch": b["ref"], "extd2_*": b["dp_out"], "k_assemble+k_finalize_pair": b["cand"]}
             port_rate = round(2 * n_port / align_seconds(r.stderr.decode()), 1)
             cpu = {"value": port_rate, "unit": "reads/s", "cores": 1, "kind": "port",
                    "sample": "first %d pairs of the same workload, oracle/aln_oracle (scalar C++ restatement, -t 1 equivalent), index load excluded" % n_port}
@@ -317,6 +321,31 @@ def main():
                         "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
                         "whole_step": {"achieved": round(bytes_per_read * 2 * args.pairs / (step_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
                                        "note": "the whole path's algorithmic bytes over the whole step (per GPU), for scale: the step is latency / issue bound"}}
+        if roofline is not None and own_bytes is not None:
+            # per-kernel table, measured live (HIP events of the timed pass): own algorithmic bytes, time, GB/s and fraction of the HBM peak; for the
+            # DP kernels also cells/s against the vector-issue bound.  Bound: profiles/r01j_valu_op_rates.txt prices a wavefront instruction at ~2.3
+            # SIMD-cycles (add / sub / logic / right shift / mov) or ~4.2 (max / min / compare / left shift / three-operand / DPP); the cell update of
+            # ksw_team_step.inc is 36 vector instructions (14 of the dearer kind) = ~110 cycles per 64 cells and SIMD, i.e. 1024 SIMDs x 2.4 GHz x 64 / 110.
+            groups = {"k_prep": ["k_prep"], "k_seed": ["k_seed"], "k_chain": ["k_chain"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
+                      "k_assemble+k_finalize_pair": ["k_assemble", "k_finalize_pair"], "extd2_*": [k for k in kern if k.startswith("extd2_")]}
+            issue_bound = 1024 * 2.4e9 * 64 / 110.0
+            rows = []
+            for g, names in groups.items():
+                ms = sum(kern[k]["ms"] for k in names if k in kern)
+                if ms <= 0:
+                    continue
+                gbs = own_bytes[g] * 2 * args.pairs / (ms * 1e-3) / 1e9
+                row = {"kernels": g, "own_alg_bytes_per_read": round(own_bytes[g], 1), "ms_per_step": round(ms, 4), "achieved_GBps": round(gbs, 2), "frac_of_hbm_peak": round(gbs / 8000.0, 6)}
+                if g == "extd2_*":
+                    row["cells_per_s"] = round(st["dp_cells"] / (ms * 1e-3), 1)
+                    row["valu_issue_bound_cells_per_s"] = round(issue_bound, 1)
+                    row["frac_of_issue_bound"] = round(st["dp_cells"] / (ms * 1e-3) / issue_bound, 4)
+                    row["note"] = "sum over all DP launches of a step as if they ran one after the other (timed pass); integer DP is vector-issue bound, the byte fraction says little"
+                rows.append(row)
+            rows.append({"kernels": "others (" + ", ".join(sorted(k for k in kern if not any(k in v for v in groups.values()))) + ")",
+                         "ms_per_step": round(sum(v["ms"] for k, v in kern.items() if not any(k in n for n in groups.values())), 4), "own_alg_bytes_per_read": 0.0})
+            roofline["kernels"] = rows
+            roofline["traffic_source"] = "profiles (committed rocprofv3 --pmc passes), not this run"
         # ---- the drop-in command end to end: FASTQ file in, both record files out (index load reported separately)
         if n_e2e:
             cli = os.path.join(ROOT, "pansvr_amd", "bin", "panSVR")
@@ -366,11 +395,15 @@ def main():
                     "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(k5.items(), key=lambda kv: -kv[1]["ms"])}}
             dp_ms = sum(wide.values())
             if dp_ms > 0 and s5["dp_problems"]:
-                mean_cells = s5["dp_cells"] / s5["dp_problems"]
-                dp_bytes = s5["dp_problems"] * (2 * mean_cells ** 0.5 + 30 + 56 + 4 * 6)      # q + t (~ 2 sqrt(cells) + 30), ez (56 B), ~6 CIGAR words
+                # counted by the engine: the query + target bytes its DP launches read (dp_seq_bytes); out: one ksw_extz_t (56 B) per problem and
+                # its CIGAR words (<= the candidates' merged CIGAR words + one per problem, counted from the download)
+                _, _, cig5 = eng5.download()
+                dp_bytes = s5.get("dp_seq_bytes", 0) + s5["dp_problems"] * (56 + 4) + 4 * int(len(cig5))
+                del cig5
                 cfg5["dp_roofline"] = {"bound": "hbm", "kernels": "all extd2_* launches of a step", "achieved": round(dp_bytes / (dp_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                                       "frac": round(dp_bytes / (dp_ms * 1e-3) / 1e9 / 8000.0, 6), "cells_per_s": round(s5["dp_cells"] / (dp_ms * 1e-3), 1),
-                                       "note": "integer DP: issue-bound, the byte roofline is far away; cells/s is the figure to watch"}
+                                       "frac": round(dp_bytes / (dp_ms * 1e-3) / 1e9 / 8000.0, 6), "alg_bytes": int(dp_bytes), "cells_per_s": round(s5["dp_cells"] / (dp_ms * 1e-3), 1),
+                                       "frac_of_issue_bound": round(s5["dp_cells"] / (dp_ms * 1e-3) / (1024 * 2.4e9 * 64 / 110.0), 4),
+                                       "note": "bytes counted by the engine (sequences in, ksw_extz_t + CIGAR out); integer DP is vector-issue bound: cells/s against 1024 SIMDs x 2.4 GHz x 64 lanes / ~110 cycles per cell update is the figure to watch"}
             eng5.close(), index5.close()
         except Exception as ex:
             cfg5 = {"error": repr(ex)}
@@ -386,7 +419,7 @@ def main():
                                                  "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,
-                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "candidates", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
+                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "dp_seq_bytes", "stale_open", "candidates", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)
     if eng is not None:

@@ -8,7 +8,8 @@
  *
  * Seam B2 (kernel):  psvr_extd2_batch*  replaces  ksw_extd2_sse   (src/kswlib/ksw2.h:63-64)
  *                    psvr_extz2_batch   replaces  ksw_extz2_sse   (src/kswlib/ksw2.h:57-58)
- * Seam B3 (seeding): psvr_seed_batch    replaces  deBGA_INDEX::search_kmer / UNITIG_MEM_search
+ * Seam B3 (seeding): psvr_seed_search_kmer_batch, psvr_seed_mem_batch
+ *                                       replace   deBGA_INDEX::search_kmer / UNITIG_MEM_search
  *                                                 (src/deBGA_index.hpp:205-208; built copy
  *                                                  src/PanSVgenerateVCF/deBGA_index.hpp:198-201)
  * Seam B1 (batch):   psvr_engine_*      replaces  kt_for(worker_for -> align_read_pair)

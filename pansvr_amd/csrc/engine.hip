@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kBlock) void k_prep(Ctx c, const int32_t *work, lon
 	const uint8_t *lut = prep_lds;
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	if (n_dev) n = (long long)*n_dev;
-	for (long long wi = blockIdx.x * (long long)(kBlock / 64) + wave; wi < n; wi += (long long)gridDim.x * (kBlock / 64)) {
+	const int wpb = (int)(blockDim.x >> 6);                           // wavefronts per workgroup: fewer for long reads (their LDS share grows with the read length)
+	for (long long wi = blockIdx.x * (long long)wpb + wave; wi < n; wi += (long long)gridDim.x * wpb) {
 	const long long slot = pair_of(work, wi), read = slot * 2 + mate;
 	uint8_t *fw = prep_lds + 128 + (size_t)wave * per_wave, *rv = fw + c.lmax;   // codes of both strands, zero-padded to lmax
 	uint64_t *pw = (uint64_t *)(rv + c.lmax);                            // forward strand's packed words (for the STR screen)
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(kBlock) void k_str_detect(Ctx c, const int32_t *wor
 	const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;   // per-read values are wave-uniform: keep them in SGPRs
 	// the reads k_prep's screen could not clear (a few percent), from its list; the grid is a fixed number of wavefronts
 	const unsigned n_list = *c.str_cnt;
-	for (unsigned e = blockIdx.x * (unsigned)(kBlock / 64) + (unsigned)wave; e < n_list; e += gridDim.x * (unsigned)(kBlock / 64)) {
+	const unsigned wpb = blockDim.x >> 6;
+	for (unsigned e = blockIdx.x * wpb + (unsigned)wave; e < n_list; e += gridDim.x * wpb) {
 	const long long read = c.str_list[e];
 	unsigned long long *key = (unsigned long long *)(str_lds + (size_t)wave * (size_t)per_wave);   // keys | counts | seed_list staging
 	unsigned int *cnt = (unsigned int *)(key + tsize);
@@ -1083,13 +1085,22 @@ struct GpuBE {
 	DevBuf redo;                                                 // [0] count, [4..] slots whose mate 1 is prepared again
 	// below this many slots a round is latency, not throughput: the wavefront-per-read kernel is through sooner (PSVR_PREP_PAIR_MIN: tests)
 	static long long prep_pair_min() { static const long long v = [] { const char *e = getenv("PSVR_PREP_PAIR_MIN"); return e ? atoll(e) : 65536ll; }(); return v; }
+	// wavefronts per workgroup (4, 2 or 1) whose LDS shares fit the 64 KB a launch may ask for without further ado: reads of up to
+	// MAX_READ_LEN = 1600 bases need ~20 KB (prep) / ~50 KB (exact STR count) per wavefront
+	static int waves_for_lds(size_t per_wave, size_t fixed)
+	{
+		int w = kBlock / 64;
+		while (w > 1 && fixed + (size_t)w * per_wave > (size_t)64 * 1024) w >>= 1;
+		return w;
+	}
 	void launch_prep_wave(const Ctx &c, const int32_t *w, long long n, int mate, const unsigned int *n_dev, unsigned grid)
 	{
 		// the screen's hashed set: 32 bits per word; for reads up to ~270 bp 8 x tsize bits keep the expected number of chance
 		// collisions at kn / 32 (far below the 16 that would send a read to the exact count); longer reads get the full 32 x tsize
 		const int tsize = c.lmax <= 288 ? str_tsize(c) / 4 : str_tsize(c);
 		const size_t per_wave = ((size_t)2 * c.lmax + (size_t)c.wmax * 8 + (size_t)tsize * 4 + 15) & ~(size_t)15;
-		hipLaunchKernelGGL(k_prep, dim3(grid), dim3(kBlock), (size_t)128 + (size_t)(kBlock / 64) * per_wave, stream, c, w, n, mate, tsize, (int)per_wave, n_dev);
+		const int wpb = waves_for_lds(per_wave, 128);
+		hipLaunchKernelGGL(k_prep, dim3(grid * (unsigned)(kBlock / 64 / wpb)), dim3(64 * wpb), (size_t)128 + (size_t)wpb * per_wave, stream, c, w, n, mate, tsize, (int)per_wave, n_dev);
 	}
 	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
@@ -1122,10 +1133,11 @@ struct GpuBE {
 		const int tsize = str_tsize(c);
 		// per wave: tsize keys (8 B) + tsize counts (4 B); the seed_list staging (<= lmax bytes) reuses the space behind them
 		const size_t per_wave = (size_t)tsize * 12 + (((size_t)c.lmax + 15) & ~(size_t)15);
-		const size_t lds = (size_t)(kBlock / 64) * per_wave;
+		const int wpb = waves_for_lds(per_wave, 0);
+		const size_t lds = (size_t)wpb * per_wave;
 		t0("k_str_detect");
 		const long long waves = n < 8192 ? n : 8192;                      // each takes list entries in turn
-		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(waves, kBlock / 64)), dim3(kBlock), lds, stream, c, w, n, mate, tsize, (int)per_wave);
+		hipLaunchKernelGGL(k_str_detect, dim3(grid_for(waves, wpb)), dim3(64 * wpb), lds, stream, c, w, n, mate, tsize, (int)per_wave);
 		t1();
 		note(hipGetLastError());
 	}
@@ -1283,6 +1295,7 @@ struct GpuBE {
 			memcpy(hist, hb, 4096), memcpy(qmax, hb + 4096, 128), memcpy(tot, hb + 4224, 24);
 		}
 		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
+		core.stats.dp_seq_bytes += tot[0] + tot[1];                   // query + target bytes the DP launches of this round read
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
 		// scratch of the strip kernel: every wavefront bump-allocates what its 64 problems need; bound per class by its longest query
@@ -1842,9 +1855,9 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
 	const RunStats &s = e->core.stats;
 	snprintf(buf, n,
-	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"candidates\":%lld,"
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"dp_seq_bytes\":%lld,\"candidates\":%lld,"
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
-	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.dp_seq_bytes, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();

@@ -78,7 +78,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 };
 
 struct RunStats {
-	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0;
+	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0, dp_seq_bytes = 0;
 	unsigned long long counters[16] = {0};
 };
 

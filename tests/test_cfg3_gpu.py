@@ -29,10 +29,11 @@ N_PAIRS = int(os.environ.get("PSVR_CFG3_PAIRS", "25000000"))
 N_ANCHORS, ANCHOR_SEED, READ_SEED, PREFIX = 10000, 11, 17, 200000
 
 
-def build_tools(tmp):
+def build_tools():
     out = {}
+    bindir = tempfile.mkdtemp(prefix="psvr_cfg3_bin_")                 # not under /dev/shm: it may be mounted noexec
     for name in ("gen_signal_fastq", "sam_check"):
-        exe = os.path.join(tmp, name)
+        exe = os.path.join(bindir, name)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(TOOLS, name + ".cpp"), "-lpthread"])
         out[name] = exe
     return out
@@ -55,7 +56,7 @@ def test_configs2_at_its_stated_size_through_a_pipe():
     tmp = tempfile.mkdtemp(prefix="psvr_cfg3_", dir=shm)
     procs = []
     try:
-        t = build_tools(tmp)
+        t = build_tools()
         ncore = os.cpu_count() or 1
         fa, idx, hdr = os.path.join(tmp, "anchors.fa"), os.path.join(tmp, "idx"), os.path.join(tmp, "header.sam")
         with open(fa, "wb") as f:
