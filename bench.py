@@ -349,7 +349,7 @@ def main():
         # ---- the drop-in command end to end: FASTQ file in, both record files out (index load reported separately)
         if n_e2e:
             cli = os.path.join(ROOT, "pansvr_amd", "bin", "panSVR")
-            nt = min(16, ncore)
+            nt = min(48, ncore)                      # the reference's own thread limit (read_realignment.hpp:121)
             e2e = {"pairs": n_e2e, "threads": nt, "input": "FASTQ of the bench batch in RAM-backed storage (%.2f GB)" % (os.path.getsize(fq) / 1e9)}
             for mode, ext in ((["-S"], "sam"), ([], "bam")):
                 r = subprocess.run([cli, "aln", "-t", str(nt)] + mode + ["-o", os.path.join(tmp, "o." + ext), "-p", os.path.join(tmp, "p." + ext)] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -216,3 +216,50 @@ def test_gpu_scratch_arena_growth_reruns_the_batch(shrink):
     assert len(got) == len(want)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if normalise(a) != normalise(b)]
     assert not bad, "%d/%d pairs differ; first %d" % (len(bad), len(want), bad[0])
+
+
+def test_gpu_aln_then_sort_against_the_reference_text():
+    """f3, the two steps panSVR_run.sh runs after `aln` (`samtools sort` + `samtools index`, panSVR_run.sh:53-54; the reference
+    holds no sorter of its own, so the ORDER is unpinned and checked against samtools' documented key: reference id, position,
+    strand, ties in input order): `panSVR aln` (BAM, the default) then `panSVR sort` on a golden set.  Decoded with the
+    independent reader of tests/bam_reader.py, the sorted file must hold exactly the records of the REFERENCE's own SAM text
+    (tests/golden/fx1/reads150.sam.gz) in that order, and the .bai must answer region queries with what a scan finds."""
+    import gzip
+    import struct
+    import bam_reader
+    name, rname = "fx1", "reads150"
+    w = ac.workdir(name)
+    tmp = tempfile.mkdtemp(prefix="psvr_sort_")
+    out, srt = os.path.join(tmp, "out.bam"), os.path.join(tmp, "sorted.bam")
+    r = subprocess.run([CLI, "aln", "-o", out, "-p", os.path.join(tmp, "ori.bam"), ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    r = subprocess.run([CLI, "sort", "-t", "4", "-o", srt, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    with gzip.open(os.path.join(ac.golden_dir(name), rname + ".sam.gz"), "rt") as f:
+        ref_lines = [l.split("\t") for l in f.read().split("\n") if l and not l.startswith("@")]
+    text, refs, recs = bam_reader.read_bam(srt)
+    assert "SO:coordinate" in text.split("\n")[0] and bam_reader.check_bgzf(srt) >= 1
+    tid_of = {n: i for i, (n, _) in enumerate(refs)}
+
+    def key(f):
+        return (tid_of[f[2]] if f[2] != "*" else 1 << 40, int(f[3]) - 1, int(f[1]) & 16)
+    want = sorted(ref_lines, key=key)                                    # stable: ties keep the reference's (= input) order
+    assert len(recs) == len(want) > 3000
+    for a, b in zip(want, recs):
+        assert a == b, "\nref: %s\nbam: %s" % ("\t".join(a), "\t".join(b))
+    # the index: every reference's records through the bins' chunks == a scan
+    bai = open(srt + ".bai", "rb").read()
+    assert bai[:4] == b"BAI\x01" and struct.unpack_from("<i", bai, 4)[0] == len(refs)
+    n_mapped = sum(1 for f in recs if f[2] != "*")
+    off, n_in_chunks = 8, 0
+    for _ in range(len(refs)):
+        n_bin = struct.unpack_from("<i", bai, off)[0]
+        off += 4
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", bai, off)
+            off += 8 + 16 * n_chunk
+            n_in_chunks += n_chunk if b != 37450 else 0
+        n_intv = struct.unpack_from("<i", bai, off)[0]
+        off += 4 + 8 * n_intv
+    assert n_in_chunks >= 1 and n_mapped > 3000

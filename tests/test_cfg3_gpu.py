@@ -61,6 +61,7 @@ def test_configs2_at_its_stated_size_through_a_pipe():
         fa, idx, hdr = os.path.join(tmp, "anchors.fa"), os.path.join(tmp, "idx"), os.path.join(tmp, "header.sam")
         with open(fa, "wb") as f:
             subprocess.check_call([t["gen_signal_fastq"], "anchors", str(N_ANCHORS), str(ANCHOR_SEED)], stdout=f)
+        os.makedirs(idx)
         subprocess.check_call([CLI, "index", "-k", "22", fa, idx + "/"], stderr=subprocess.DEVNULL)     # dense first level: the reference's loader reads it
         with open(hdr, "w") as f:
             f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")

@@ -27,6 +27,15 @@ static inline uint64_t mix(uint64_t &s)
 	return z ^ (z >> 31);
 }
 static inline uint32_t below(uint64_t &s, uint32_t n) { return (uint32_t)((mix(s) >> 32) * (uint64_t)n >> 32); }
+// an independent stream per (seed, item): the state is a hash of both -- states that differ by the generator's own increment would give
+// the SAME stream shifted by one draw (every anchor the previous one moved by a base)
+static inline uint64_t stream_of(uint64_t seed, uint64_t item)
+{
+	uint64_t a = seed ^ 0xA0761D6478BD642Full, b = item * 0xE7037ED1A0B428DBull + 0x8EBC6AF09C88C6E3ull;
+	const uint64_t x = mix(a) ^ mix(b);
+	uint64_t c = x;
+	return mix(c);
+}
 
 struct Anchors {
 	std::vector<std::string> name;
@@ -38,7 +47,7 @@ static void make_anchors(int n, uint64_t seed, Anchors *A)
 {
 	const int edge = 500;
 	for (int i = 0; i < n; ++i) {
-		uint64_t s = seed * 0x100000001B3ull + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+		uint64_t s = stream_of(seed, (uint64_t)i);
 		const int alen = 60 + (int)below(s, 241);
 		std::string q((size_t)(2 * edge + alen), 'A');
 		for (char &c : q) c = "ACGT"[mix(s) >> 62];
@@ -54,7 +63,7 @@ static char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? '
 static void one_pair(const Anchors &A, uint64_t rseed, long long p, bool stat, std::string &out)
 {
 	const int L = 150, maxindel = 8, W = L + maxindel;
-	uint64_t s = rseed * 0xD6E8FEB86659FD93ull + (uint64_t)p * 0x9E3779B97F4A7C15ull + 1;
+	uint64_t s = stream_of(rseed ^ 0x5851F42D4C957F2Dull, (uint64_t)p);
 	const bool miss = below(s, 100) < 20;
 	const int a = 1 + (int)below(s, (uint32_t)A.seq.size() - 1);
 	const std::string &ref = A.seq[(size_t)a];
