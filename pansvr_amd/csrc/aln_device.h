@@ -1483,12 +1483,27 @@ PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, cons
 }
 
 // A pair with N bases takes over the records of the variant slot that was evaluated with exactly the residues its draws yield
-// (engine_core.h: only when that slot drew nothing else, so its result does not depend on where in the stream it stands).
+// (engine_core.h: only when that slot's two reads drew nothing else, so their results do not depend on where in the stream they stand).
 // `part` of `parts` workers copy the two read records word by word; worker 0 also moves the counters and the offset.
+// A slot whose PAIRING stage drew (tied pair scores, rr.hpp:553) is adopted as well: those draws follow the reads' and their number
+// does not depend on their values (a tie leaves max_score where it is), so worker 0 takes the slot's read records and runs the pairing
+// again where the pair really stands in the stream -- a third of the pairs with N bases, which used to run again from their first stage.
 // Declined (nothing touched) when the slot sampled positions with random_r: that result depends on the other streams' offsets.
 PSVR_HD void adopt_variant(const Ctx &c, long long pair, long long slot, const long long *noff, int part, int parts)
 {
 	if (c.hcnt[2 * slot] != 0 || c.hcnt[2 * slot + 1] != 0) return;
+	const bool repair = c.rcnt[3 * slot + 2] != 0;
+	if (repair) {
+		if (part != 0) return;
+		for (int k = 0; k < 4; ++k) c.strand[4 * pair + k] = c.strand[4 * slot + k];
+		c.rcnt[3 * pair] = c.rcnt[3 * slot], c.rcnt[3 * pair + 1] = c.rcnt[3 * slot + 1];
+		c.hcnt[2 * pair] = c.hcnt[2 * pair + 1] = 0;
+		c.poff[pair] = noff[pair];
+		psvr_read_hdr_t h0 = c.rh[2 * slot], h1 = c.rh[2 * slot + 1];   // (cand_off keeps pointing at the variant slot's candidates: they are this pair's now)
+		pair_reads(c, pair, h0, h1);                                     // draws from poff[pair] + the two reads' counts; sets rcnt[3 pair + 2], pres[pair]
+		c.rh[2 * pair] = h0, c.rh[2 * pair + 1] = h1;
+		return;
+	}
 	// the two headers (cand_off keeps pointing at the variant slot's candidates: they are this pair's now) and the trace hashes
 	const uint32_t *src = (const uint32_t *)(c.rh + 2 * slot);
 	uint32_t *dst = (uint32_t *)(c.rh + 2 * pair);

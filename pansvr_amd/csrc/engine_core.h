@@ -445,6 +445,7 @@ template <class BE> struct EngineCore {
 	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
 	std::vector<char> is_special;                     // a special pair whose prediction failed falls back to the window method
 	std::vector<int32_t> adopted, adopt_pair, adopt_slot;   // per special pair: the variant slot whose records it carries (-1 none); this walk's new adoptions
+	std::vector<long long> adopted_at;                      // ... and the stream offset it was adopted at (a slot whose pairing draws is adopted again when the pair moves)
 	long long dp_done = 0, cw_done = 0;
 	bool have_run = false;
 
@@ -468,7 +469,7 @@ template <class BE> struct EngineCore {
 		if (!h_sp_idx.empty()) be.scatter_u8(d_mask, h_sp_idx.data(), (long long)h_sp_idx.size(), 1);
 		dp_done = 0, cw_done = 0;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
-		adopted.assign(special.size(), -1), adopt_pair.clear(), adopt_slot.clear();
+		adopted.assign(special.size(), -1), adopted_at.assign(special.size(), -1), adopt_pair.clear(), adopt_slot.clear();
 		have_run = true;
 		int rc = iterate(trace, want_stats, depth, stats_ptr, false);
 		return rc;
@@ -590,10 +591,11 @@ template <class BE> struct EngineCore {
 						for (int j = 0; j < sp.n2; ++j) code |= (grand.host[t + c1 + j] & 3) << sh2, sh2 += 2;
 						const int32_t *vc = &vcnt[3 * (sp.vslot - P + code)];
 						D = vc[0] + vc[1] + vc[2];
-						// Nothing but the forced residues was drawn in that variant slot: its records ARE this pair's at any offset
-						// (adopted below instead of running the pair again where its draws have moved to)
-						if (vc[0] == sp.n1 && vc[1] == sp.n2 && vc[2] == 0 && adopted[si] != sp.vslot + code) {
-							adopted[si] = sp.vslot + code;
+						// The two reads of that variant slot drew nothing but the forced residues: their records ARE this pair's at any offset
+						// (adopted below instead of running the pair again where its draws have moved to).  If the slot's pairing stage drew
+						// too, the adoption runs the pairing again at the pair's offset (adopt_variant): again whenever the offset moves.
+						if (vc[0] == sp.n1 && vc[1] == sp.n2 && (adopted[si] != sp.vslot + code || (vc[2] != 0 && adopted_at[si] != t))) {
+							adopted[si] = sp.vslot + code, adopted_at[si] = t;
 							adopt_pair.push_back(s), adopt_slot.push_back(sp.vslot + code);
 						}
 					} else if (wi < wins.size() && wins[wi].pair == s) {

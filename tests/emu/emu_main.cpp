@@ -90,7 +90,7 @@ struct CpuBE {
 	{
 		for (long long p = 0; p < c.n_pairs; ++p) {
 			int d = mark_dirty(c, p, noff, nhoff);
-			if (d == 2) out[(*cnt)++] = (int32_t)p;
+			if (d == 2) { out[(*cnt)++] = (int32_t)p; if (getenv("EMU_DEBUG_DIRTY")) fprintf(stderr, "DIRTY2 pair %lld r %d %d %d h %d %d\n", p, c.rcnt[3*p], c.rcnt[3*p+1], c.rcnt[3*p+2], c.hcnt[2*p], c.hcnt[2*p+1]); }
 			else if (d == 1) outp[(*cntp)++] = (int32_t)p;
 		}
 	}
