@@ -1464,22 +1464,54 @@ PSVR_HD void materialize_read(const Ctx &c, long long read, psvr_read_result_t *
 
 // which pairs consumed draws from an offset that the scan of the actual draw counts has since moved?
 // Also adopts the new offsets.  (engine_core.h, "rand() order")  Real pairs only.
-PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, const long long *nhoff)
+PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, const long long *nhoff, const uint8_t *has_n)
 {
-	int dirty = 0;                   // 0 clean, 1 only the pairing stage must be repeated, 2 the whole pair
+	int dirty = 0;                   // 0 clean, 1 only the pairing stage must be repeated, 2 the whole pair, 3 chain selection + pairing (reselect_pair)
 	// (everything is requested before anything is looked at: a dozen words per pair, one round trip instead of five in a row)
 	const long long po = c.poff[pair], no = noff[pair];
 	const int32_t r0 = c.rcnt[pair * 3], r1 = c.rcnt[pair * 3 + 1], r2 = c.rcnt[pair * 3 + 2];
 	const int32_t h0 = c.hcnt[pair * 2], h1 = c.hcnt[pair * 2 + 1];
 	const long long ho0 = c.hoff[pair * 2], ho1 = c.hoff[pair * 2 + 1], nh0 = nhoff[pair * 2], nh1 = nhoff[pair * 2 + 1];
 	if (po != no) {
-		if (r0 > 0 || r1 > 0) dirty = 2;
+		// draws of a read without N bases are tie draws of its chain selection (rr.cpp:247): everything in front of the selection
+		// stands whatever the offset is
+		if (r0 > 0 || r1 > 0) dirty = (has_n && !has_n[pair]) ? 3 : 2;
 		else if (r2 > 0) dirty = 1;
 		c.poff[pair] = no;
 	}
 	if ((h0 > 0 && ho0 != nh0) || (h1 > 0 && ho1 != nh1)) dirty = 2;
 	c.hoff[pair * 2] = nh0, c.hoff[pair * 2 + 1] = nh1;
 	return dirty;
+}
+
+// A pair whose reads hold no N: its draws in front of the pairing stage are the tie draws of sort_output.  At another offset the
+// ties are resolved by other values, which changes the ORDER in which tied chains are taken -- and hardly ever the candidate list that
+// comes out (it is sorted by score and chain index afterwards).  So the selection alone runs again at the new offset; if both reads'
+// lists are what they were, every later stage's result stands and only the pairing has to follow (returns 1), otherwise the pair
+// runs again from the start (returns 2).  `save`: room for one read's previous list.
+PSVR_HD int reselect_pair(const Ctx &c, long long pair, ChainCand *save)
+{
+	bool same = true;
+	for (int mate = 0; mate < 2; ++mate) {
+		const long long read = pair * 2 + mate, item = pair * 3 + mate;
+		if (!c.active[read]) continue;
+		const int n_old = c.n_ccand[read];
+		ChainCand *cc = c.ccand + read * 12;
+		for (int i = 0; i < n_old; ++i) save[i] = cc[i];
+		for (int o = 0; o < 2; ++o) {                                     // sort_output marks the chains it has taken
+			const Strand &st = c.strand[read * 2 + o];
+			PathN *pa = c.path + st.us_off;
+			for (uint32_t i = 0; i < st.us_n; ++i) pa[i].used = 0;
+		}
+		c.rcnt[item] = 0;                                                 // no N draws: select_read adds its tie draws
+		select_read(c, read);
+		if (c.n_ccand[read] != n_old) same = false;
+		for (int i = 0; i < n_old && same; ++i) {
+			const ChainCand &a = save[i], &b = cc[i];
+			if (a.chain_score != b.chain_score || a.max_index != b.max_index || a.read_bg != b.read_bg || a.ref_bg != b.ref_bg || a.chr_id != b.chr_id || a.direction != b.direction) same = false;
+		}
+	}
+	return same ? 1 : 2;
 }
 
 // A pair with N bases takes over the records of the variant slot that was evaluated with exactly the residues its draws yield

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *
 // kernel's 92 us whatever the data (tools/atomic_rate_bench.hip)
 static const int kDirtyItems = 8;
 __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt,
-                                                  int32_t *outp, unsigned long long *cntp)
+                                                  int32_t *outp, unsigned long long *cntp, const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, unsigned long long cap3)
 {
 	__shared__ unsigned int n_full, n_pair;
 	__shared__ unsigned long long b_full, b_pair;
@@ -646,7 +646,11 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 #pragma unroll
 	for (int k = 0; k < kDirtyItems; ++k) {
 		const long long p = base + (long long)k * kBlock + threadIdx.x;
-		d[k] = p < c.n_pairs ? mark_dirty(c, p, noff, nhoff) : 0;
+		d[k] = p < c.n_pairs ? mark_dirty(c, p, noff, nhoff, has_n) : 0;
+		if (d[k] == 3) {                                                          // (a few hundred per million pairs: tied chains) -> k_reselect
+			const unsigned long long at = atomicAdd(cnt3, 1ull);
+			if (at < cap3) out3[at] = (int32_t)p, d[k] = 0; else d[k] = 2;         // no room to keep its lists for the comparison: the pair runs in full
+		}
 		const unsigned long long m2 = __ballot(d[k] == 2), m1 = __ballot(d[k] == 1);
 		unsigned int w2 = 0, w1 = 0;
 		if ((threadIdx.x & 63) == 0) {
@@ -667,6 +671,18 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 		const long long p = base + (long long)k * kBlock + threadIdx.x;
 		if (d[k] == 2) out[b_full + me[k]] = (int32_t)p;
 		else if (d[k] == 1) outp[b_pair + me[k]] = (int32_t)p;
+	}
+}
+// the pairs of the third list (reselect_pair in aln_device.h): one thread each, over a list whose length only the device knows;
+// a pair whose candidate lists stand joins the pairing-only list, another the list of full re-runs
+__global__ __launch_bounds__(64) void k_reselect(Ctx c, const int32_t *list, const unsigned long long *n_list, unsigned long long cap3, ChainCand *save, int32_t *out,
+                                                 unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
+{
+	const unsigned long long n = *n_list < cap3 ? *n_list : cap3;
+	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+		const long long p = list[i];
+		if (reselect_pair(c, p, save + i * 12) == 1) outp[atomicAdd(cntp, 1ull)] = (int32_t)p;
+		else out[atomicAdd(cnt, 1ull)] = (int32_t)p;
 	}
 }
 // one wavefront per adopted pair (adopt_variant in aln_device.h)
@@ -1240,9 +1256,12 @@ struct GpuBE {
 		h2d(tmp_idx.p, idx, n * 4);
 		hipLaunchKernelGGL(k_scatter_u8, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, v);
 	}
-	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
+	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp,
+	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3)
 	{
-		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs, kBlock * kDirtyItems)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp);
+		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs, kBlock * kDirtyItems)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp, has_n, out3, cnt3, (unsigned long long)cap3);
+		// the tie-only pairs, resolved on the spot (their number stays on the device: a fixed small grid walks the list)
+		hipLaunchKernelGGL(k_reselect, dim3(64), dim3(64), 0, stream, c, (const int32_t *)out3, (const unsigned long long *)cnt3, (unsigned long long)cap3, save, out, cnt, outp, cntp);
 		note(hipGetLastError());
 	}
 

@@ -105,6 +105,10 @@ template <class BE> struct EngineCore {
 	char *d_bases = nullptr; long long *d_off = nullptr; psvr_ori_t *d_ori = nullptr;   // the uploaded batch
 	long long cap_S = 0, cap_bases = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
 	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
+	uint8_t *d_hasn = nullptr;                       // per pair: a read of it draws for N bases (its draws are not just chain-selection ties)
+	int32_t *d_resel = nullptr; ChainCand *d_resel_save = nullptr;   // pairs whose chain selection runs again on its own (reselect_pair); the list they are compared with
+	std::vector<int32_t> h_n_idx;                    // pairs with N draws (built by upload())
+	static const long long kReselCap = 1 << 16;      // tie-only pairs a round can resolve on the spot; beyond that they run in full
 	int32_t *d_cmask = nullptr;                      // totals with the host-resolved pairs masked out
 	struct Special { int32_t pair; uint8_t n1, n2; int32_t vslot, nvar; };
 	std::vector<Special> special;                    // pairs with 1..3 N draws, ascending
@@ -231,11 +235,13 @@ template <class BE> struct EngineCore {
 			};
 			const int nt = P >= 200000 ? 8 : 1;
 			std::vector<std::vector<Special>> part((size_t)nt);
+			std::vector<std::vector<int32_t>> npart((size_t)nt);
 			auto scan = [&](int t) {
 				const long long p0 = P * t / nt, p1 = P * (t + 1) / nt;
 				for (long long p = p0; p < p1; ++p) {
 					int nn[2];
 					n_of(p, nn);
+					if (nn[0] + nn[1] >= 1) npart[(size_t)t].push_back((int32_t)p);
 					if (nn[0] + nn[1] >= 1 && nn[0] + nn[1] <= 3) part[(size_t)t].push_back(Special{(int32_t)p, (uint8_t)nn[0], (uint8_t)nn[1], 0, 1 << (2 * (nn[0] + nn[1]))});
 				}
 			};
@@ -245,6 +251,8 @@ template <class BE> struct EngineCore {
 			for (std::thread &t : th) t.join();
 			for (auto &v : part)
 				for (Special sp : v) { sp.vslot = (int32_t)(P + V); special.push_back(sp); V += sp.nvar; }
+			h_n_idx.clear();
+			for (auto &v : npart) h_n_idx.insert(h_n_idx.end(), v.begin(), v.end());
 		}
 		const long long shadow_cap = P / 16 + 8192;
 		S = P + V + shadow_cap;
@@ -284,6 +292,7 @@ template <class BE> struct EngineCore {
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
+		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel_save = alloc<ChainCand>(12 * (P < kReselCap ? P : kReselCap));
 		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
@@ -339,6 +348,8 @@ template <class BE> struct EngineCore {
 			}
 			be.dzero(d_force, (size_t)8 * S);
 			if (V) be.h2d(d_force + (size_t)8 * P, force.data(), force.size());
+			be.dzero(d_hasn, (size_t)P);
+			if (!h_n_idx.empty()) be.scatter_u8(d_hasn, h_n_idx.data(), (long long)h_n_idx.size(), 1);
 		}
 	}
 
@@ -621,8 +632,8 @@ template <class BE> struct EngineCore {
 				adopt_pair.clear(), adopt_slot.clear();
 			}
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
-			be.dzero(d_tops + 32, 17 * 8);
-			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48);
+			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 8);
+			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, d_resel_save, P < kReselCap ? P : kReselCap);
 			unsigned long long nd17[17];
 			int32_t flags[8];
 			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 32);

@@ -86,12 +86,20 @@ struct CpuBE {
 		long long acc = base;
 		for (long long i = 0; i < n; ++i) { out[off + i * stride] = acc; acc += cnt[off + i * stride]; }
 	}
-	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
+	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp,
+	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3)
 	{
 		for (long long p = 0; p < c.n_pairs; ++p) {
-			int d = mark_dirty(c, p, noff, nhoff);
-			if (d == 2) { out[(*cnt)++] = (int32_t)p; if (getenv("EMU_DEBUG_DIRTY")) fprintf(stderr, "DIRTY2 pair %lld r %d %d %d h %d %d\n", p, c.rcnt[3*p], c.rcnt[3*p+1], c.rcnt[3*p+2], c.hcnt[2*p], c.hcnt[2*p+1]); }
+			int d = mark_dirty(c, p, noff, nhoff, has_n);
+			if (d == 3 && (long long)*cnt3 >= cap3) d = 2;
+			if (d == 3) out3[(*cnt3)++] = (int32_t)p;
+			else if (d == 2) out[(*cnt)++] = (int32_t)p;
 			else if (d == 1) outp[(*cntp)++] = (int32_t)p;
+		}
+		for (unsigned long long i = 0; i < *cnt3; ++i) {
+			const long long p = out3[i];
+			if (reselect_pair(c, p, save + i * 12) == 1) outp[(*cntp)++] = (int32_t)p;
+			else out[(*cnt)++] = (int32_t)p;
 		}
 	}
 	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff) { for (long long i = 0; i < n; ++i) adopt_variant(c, pairs[i], slots[i], noff, 0, 1); }
