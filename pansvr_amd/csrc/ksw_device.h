@@ -69,20 +69,28 @@ struct TeamPlan {
 	// 0: the wavefront bumps DpBatch::ws_top (16 k wavefronts on one counter line: ~12 ns each, the first generation queues up)
 	unsigned long long ws_base[PSVR_DP_NUM_LDS_CLASSES], ws_need[PSVR_DP_NUM_LDS_CLASSES];
 };
-template <int LANES> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip
+template <int LANES, int CPL> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip
 // the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 // lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips
+// A team = PSVR_DP_TEAM_LANES lanes, each with PSVR_DP_TEAM_CPL target columns of a strip in registers (strip width = their product).
+// 4 x 4 was the first shape; 2 x 8 keeps the 16-column strips (same share of ramp slots) but spends a step's fixed cost -- neighbour
+// exchange, boundary records, per-diagonal maximum, query window: ~100 of a step's ~245 vector instructions -- on eight cells instead
+// of four, and puts 32 alignments in a wavefront (the one-lane-per-alignment passes behind the sweep use twice the lanes).
+// (2 x 4, 8-column strips: fewer ramp slots but twice the strips, 5.7 vs 4.9 ms when it was tried.)
 #ifndef PSVR_DP_TEAM_LANES
-#define PSVR_DP_TEAM_LANES 4      /* 2 (8-column strips, 32 alignments per wavefront) wastes less of the diagonal ramps but leaves too few wavefronts on the bench workload: 5.7 vs 4.9 ms */
+#define PSVR_DP_TEAM_LANES 2
+#endif
+#ifndef PSVR_DP_TEAM_CPL
+#define PSVR_DP_TEAM_CPL 8
 #endif
 __host__ __device__ inline int dp_team_lanes(int n_strips16) { return PSVR_DP_TEAM_LANES; }
 // scratch bytes one wavefront of the team kernel needs for alignments with at most qmax query bases in that class
-__host__ __device__ inline unsigned long long dp_team_ws_bytes(int qmax, int n_strips16, int lanes)
+__host__ __device__ inline unsigned long long dp_team_ws_bytes(int qmax, int n_strips16, int lanes, int cpl = PSVR_DP_TEAM_CPL)
 {
-	const int sw = 4 * lanes, pb = 64 / lanes, n_strips = (n_strips16 * 16 + sw - 1) / sw;
-	// direction dwords, then per diagonal and alignment: two boundary dwords (ping-pong) + D, D2, D3
-	return (unsigned long long)256 * n_strips * (qmax + sw - 1) + (unsigned long long)pb * 20 * (qmax + sw * n_strips + 1);
+	const int sw = cpl * lanes, pb = 64 / lanes, n_strips = (n_strips16 * 16 + sw - 1) / sw;
+	// direction bytes (one per cell, 64 x cpl per step), then per diagonal and alignment: two boundary dwords (ping-pong) + D, D2, D3
+	return (unsigned long long)(64 * cpl) * n_strips * (qmax + sw - 1) + (unsigned long long)pb * 20 * (qmax + sw * n_strips + 1);
 }
 
 // true when the band [(r-w+1)>>1, (r+w)>>1] never clips the DP matrix: then st0/en0 follow the matrix edges only, every

@@ -492,13 +492,14 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 // the price list in profiles/r01j_valu_op_rates.txt (add/sub/logic/right shift ~2 cycles, max/min/cmp/three-operand/DPP ~4) --
 // which is why the differences are kept x 8 with the candidate's priority in the low bits (below): ~80 vector instructions per
 // step and column, ~1.3 wavefront instructions per cell instead of ~7 for a wavefront per alignment.
-template <int LANES>
+template <int LANES, int CPL>
 #ifndef PSVR_TEAM_WAVES
 #define PSVR_TEAM_WAVES 4          /* wavefronts per SIMD the register allocation aims at (4 = 128 VGPRs) */
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
-	constexpr int SW = 4 * LANES, PB = 64 / LANES;                   // strip width, alignments per wavefront
+	static_assert(CPL == 4 || CPL == 8, "columns per lane: the query window holds 8 nibbles, direction bytes go out as dwords");
+	constexpr int SW = CPL * LANES, PB = 64 / LANES;                 // strip width, alignments per wavefront
 	constexpr int kNone = (int)0x80000000;                           // "no cell yet" in the per-diagonal maximum
 	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
 	// substitution scores of every (target, query) code pair, scaled and tagged like the other candidates (see below), written by
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	const int n_strips = (n_strips16 * 16 + SW - 1) / SW;
 	const int qmax = wave_max_i32(qlen > 0 ? qlen : 0);
 	const int R = qmax + SW - 1, NR = qmax + SW * n_strips + 1;
-	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES);
+	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES, CPL);
 	unsigned long long base = 0;
 	if (T.ws_need[cls]) base = T.ws_base[cls] + (unsigned long long)((int)blockIdx.x - T.first_block[cls]) * T.ws_need[cls];   // need <= ws_need: the class's longest query bounds this wavefront's
 	else {
@@ -534,14 +535,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	if (base + need > B.ws_cap && B.err) *B.err = 20;
 	if (P.skip || bad_shape || base + need > B.ws_cap) { if (ql == 0) write_ez(out, ez, 0); return; }
 	uint8_t *w0 = B.ws + base;
-	const size_t offE = (size_t)256 * n_strips * R;
+	const size_t offE = (size_t)(64 * CPL) * n_strips * R;
 	// Every scratch address is a wave-uniform base (scalar registers) plus a constant 32-bit lane offset, so a step spends no
 	// vector instruction on addresses: direction dwords of strip s, step k at [(s * R + k) * 64 + lane]; strip-boundary values
 	// (8 bytes) and the per-diagonal records D, D2, D3 (4 bytes) of diagonal r at [r * PB + team].
 	// (a boundary record is one dword: v, x, x2 are multiples of 8 plus a constant tag and fit int8 once divided, see the step)
 	uint8_t *const uE0 = w0 + offE, *const uE1 = w0 + offE + (size_t)4 * PB * NR;
 	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
-	const unsigned l4 = 4u * (unsigned)lane, t4 = 4u * (unsigned)team;
+	const unsigned lc = (unsigned)CPL * (unsigned)lane, t4 = 4u * (unsigned)team;
 	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
 	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
@@ -575,11 +576,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		const int c0 = SW * s;
 		const int ncols = tlen - c0 < SW ? tlen - c0 : SW;
 		const int jl = tlen - 1 - c0;                                   // the last target column, if it is in this strip (else >= SW)
-		const int jb = 4 * ql;                                          // this lane's first column of the strip
-		int U[4], V[4], X[4], Y[4], X2[4], Y2[4], H[4], TC[4];
-		bool inr[4];                                                  // column inside the target
+		const int jb = CPL * ql;                                        // this lane's first column of the strip
+		int U[CPL], V[CPL], X[CPL], Y[CPL], X2[CPL], Y2[CPL], H[CPL], TC[CPL];
+		bool inr[CPL];                                                // column inside the target
 #pragma unroll
-		for (int jj = 0; jj < 4; ++jj) {
+		for (int jj = 0; jj < CPL; ++jj) {
 			U[jj] = 8 * ur_of(c0 + jb + jj);                            // u/y/y2 of the first cell of a column (:153-156)
 			V[jj] = 8 * neg_qe, X[jj] = x_init, Y[jj] = y_init, X2[jj] = x2_init, Y2[jj] = y2_init;
 			H[jj] = h_above(c0 + jb + jj);
@@ -649,12 +650,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
 		if (i0 >= 0 && j0 >= 0) {
 			const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
-			const uint8_t *pb = (const uint8_t *)((uint32_t *)w0 + team * LANES);   // the team's 4 * LANES direction bytes of a step are contiguous
+			const uint8_t *pb = w0 + team * SW;                      // the team's SW direction bytes of a step are contiguous
 			uint32_t *stage = (uint32_t *)(w0 + offE) + team;         // <= qlen + tlen ops; the strip-boundary arrays are dead now
 			n_cigar = traceback(i0, j0, qlen, tlen, w,
 				[&](int r, int k) {                                     // k counts from the 16-rounded band start of row r, as in the reference
 					const int t = k + (max(0, r - qlen + 1) & ~15), s = t / SW;
-					const unsigned b = pb[(size_t)(s * R + (r - SW * s)) * 256 + (t - SW * s)], n = ~b;
+					const unsigned b = pb[(size_t)(s * R + (r - SW * s)) * (64 * CPL) + (t - SW * s)], n = ~b;
 					// back to the reference's byte: direction in bits 0-2, "gap extended" for a, b, a2, b2 in bits 3-6
 					return (int)((4u - ((b >> 4) & 7u)) | ((n >> 3) & 1u) << 3 | ((n >> 2) & 1u) << 4 | ((n >> 1) & 1u) << 5 | (n & 1u) << 6);
 				},
@@ -666,8 +667,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	}
 	write_ez(out, ez, n_cigar);
 }
-template __global__ void extd2_team_kernel<4>(DpBatch, DpParams, TeamPlan);
-template __global__ void extd2_team_kernel<2>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>(DpBatch, DpParams, TeamPlan);
 
 // ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image

@@ -63,8 +63,7 @@ struct TeamLaunch {
 	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
 	{
 		if (!T.n_classes) return;
-		if (dp_team_lanes(1) == 2) hipLaunchKernelGGL(extd2_team_kernel<2>, dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
-		else hipLaunchKernelGGL(extd2_team_kernel<4>, dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
 	}
 };
 // the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
