@@ -675,15 +675,20 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 }
 // the pairs of the third list (reselect_pair in aln_device.h): one thread each, over a list whose length only the device knows;
 // a pair whose candidate lists stand joins the pairing-only list, another the list of full re-runs
-__global__ __launch_bounds__(64) void k_reselect(Ctx c, const int32_t *list, const unsigned long long *n_list, unsigned long long cap3, ChainCand *save, int32_t *out,
-                                                 unsigned long long *cnt, int32_t *outp, unsigned long long *cntp)
+__global__ __launch_bounds__(64) void k_reselect(Ctx c, const int32_t *list, const unsigned long long *n_list, unsigned long long cap3, ChainCand *save, int32_t *out4,
+                                                 unsigned long long *cnt4, int32_t *outp, unsigned long long *cntp)
 {
 	const unsigned long long n = *n_list < cap3 ? *n_list : cap3;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
 		const long long p = list[i];
 		if (reselect_pair(c, p, save + i * 12) == 1) outp[atomicAdd(cntp, 1ull)] = (int32_t)p;
-		else out[atomicAdd(cnt, 1ull)] = (int32_t)p;
+		else out4[atomicAdd(cnt4, 1ull)] = (int32_t)p;                       // new lists: the pair goes on from the walk
 	}
+}
+__global__ void k_copy_i32(int32_t *dst, long long at, const int32_t *src, long long n)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < n) dst[at + i] = src[i];
 }
 // one wavefront per adopted pair (adopt_variant in aln_device.h)
 __global__ __launch_bounds__(kBlock) void k_adopt(Ctx c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff)
@@ -1189,6 +1194,7 @@ struct GpuBE {
 		if (S > 0) hipLaunchKernelGGL(k_run_init, dim3(grid_for(S)), dim3(kBlock), 0, stream, poff, hoff, rcnt, hcnt, ctot, hprev, sens, mask, src, S, P, g, h0, h1);
 	}
 	void append_iota(int32_t *w, long long at, long long start, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, start, n); }
+	void append_list(int32_t *w, long long at, const int32_t *src, long long n) { if (n) hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, src, n); }
 	// one index upload, one kernel, one synchronisation; the indices stay on the device for scatter_listed_i32
 	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc)
 	{
@@ -1257,11 +1263,11 @@ struct GpuBE {
 		hipLaunchKernelGGL(k_scatter_u8, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, v);
 	}
 	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp,
-	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3)
+	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3, int32_t *out4, unsigned long long *cnt4)
 	{
 		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs, kBlock * kDirtyItems)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp, has_n, out3, cnt3, (unsigned long long)cap3);
 		// the tie-only pairs, resolved on the spot (their number stays on the device: a fixed small grid walks the list)
-		hipLaunchKernelGGL(k_reselect, dim3(64), dim3(64), 0, stream, c, (const int32_t *)out3, (const unsigned long long *)cnt3, (unsigned long long)cap3, save, out, cnt, outp, cntp);
+		hipLaunchKernelGGL(k_reselect, dim3(64), dim3(64), 0, stream, c, (const int32_t *)out3, (const unsigned long long *)cnt3, (unsigned long long)cap3, save, out4, cnt4, outp, cntp);
 		note(hipGetLastError());
 	}
 

@@ -78,7 +78,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 };
 
 struct RunStats {
-	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0, dp_seq_bytes = 0;
+	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0, dp_seq_bytes = 0, from_walk = 0;
 	unsigned long long counters[16] = {0};
 };
 
@@ -106,7 +106,7 @@ template <class BE> struct EngineCore {
 	long long cap_S = 0, cap_bases = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
 	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
 	uint8_t *d_hasn = nullptr;                       // per pair: a read of it draws for N bases (its draws are not just chain-selection ties)
-	int32_t *d_resel = nullptr; ChainCand *d_resel_save = nullptr;   // pairs whose chain selection runs again on its own (reselect_pair); the list they are compared with
+	int32_t *d_resel = nullptr, *d_resel4 = nullptr; ChainCand *d_resel_save = nullptr;   // pairs whose chain selection runs again on its own (reselect_pair); the list they are compared with
 	std::vector<int32_t> h_n_idx;                    // pairs with N draws (built by upload())
 	static const long long kReselCap = 1 << 16;      // tie-only pairs a round can resolve on the spot; beyond that they run in full
 	int32_t *d_cmask = nullptr;                      // totals with the host-resolved pairs masked out
@@ -292,7 +292,7 @@ template <class BE> struct EngineCore {
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
-		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel_save = alloc<ChainCand>(12 * (P < kReselCap ? P : kReselCap));
+		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel_save = alloc<ChainCand>(12 * (P < kReselCap ? P : kReselCap)), d_resel4 = alloc<int32_t>(P < kReselCap ? P : kReselCap);
 		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
@@ -411,9 +411,10 @@ template <class BE> struct EngineCore {
 
 	// the stages of one round over a list of slots: mate 0, then mate 1 (continues mate 0's draws), then the
 	// candidate / DP / pairing stages
-	int run_slots(const int32_t *work, long long nwork, long long &dp_done, long long &cw_done)
+	// `nwalk`: entries behind the first nwork of `work` that go on from the walk (their chain selection has been repeated already, k_reselect)
+	int run_slots(const int32_t *work, long long nwork, long long &dp_done, long long &cw_done, long long nwalk = 0)
 	{
-		if (nwork <= 0) return PSVR_OK;
+		if (nwork + nwalk <= 0) return PSVR_OK;
 		for (int mate = 0; mate < 2; ++mate) {
 			be.st_prep(c, work, nwork, mate);
 			be.st_str(c, work, nwork, mate);
@@ -421,7 +422,7 @@ template <class BE> struct EngineCore {
 			be.st_chain(c, work, nwork, mate);
 			be.st_select(c, work, nwork, mate);
 		}
-		be.st_walk(c, work, nwork);
+		be.st_walk(c, work, nwork + nwalk);
 		unsigned long long tops[kTopStride + 1];                             // from the dp counter to the cw counter
 		int32_t fl[8];
 		be.d2h2(tops, d_atops + 3 * kTopStride, sizeof tops, fl, d_flags, 32);
@@ -442,7 +443,7 @@ template <class BE> struct EngineCore {
 		if (cw_end > cw_done) be.st_assemble(c, cw_done, cw_end);
 		stats.dp_problems += dp_end - dp_done, stats.cands += cw_end - cw_done;
 		dp_done = dp_end, cw_done = cw_end;
-		be.st_finalize_pair(c, work, nwork);       // both reads' tails, then the pairing, by the same worker: the records stay close
+		be.st_finalize_pair(c, work, nwork + nwalk);       // both reads' tails, then the pairing, by the same worker: the records stay close
 		return PSVR_OK;
 	}
 
@@ -504,7 +505,7 @@ template <class BE> struct EngineCore {
 	int iterate(int trace, bool want_stats, int depth, unsigned long long *stats_ptr, bool resume)
 	{
 		int rc = PSVR_OK;
-		long long nfull = resume ? 0 : P + V, npair_only = 0, nshadow = 0;
+		long long nfull = resume ? 0 : P + V, npair_only = 0, nshadow = 0, nwalk = 0;
 		const int32_t *work = nullptr;                    // nullptr = identity: round 1 runs every real pair and every variant slot
 		std::vector<int32_t> sh_src; std::vector<long long> sh_off;
 		bool skip_eval = resume;
@@ -517,7 +518,8 @@ template <class BE> struct EngineCore {
 			// them beside the stage chain
 			const bool beside = npair_only > 0 && be.side_begin();
 			if (beside) { be.st_pair(c, d_workp, npair_only); be.side_end(); }
-			rc = run_slots(work, nfull + nshadow, dp_done, cw_done);
+			stats.from_walk += nwalk;
+			rc = run_slots(work, nfull + nshadow, dp_done, cw_done, nwalk);
 			if (beside) be.side_wait();
 			if (rc <= -1000) {
 				const int full = -rc - 1000;
@@ -529,7 +531,7 @@ template <class BE> struct EngineCore {
 			if (npair_only && !beside) be.st_pair(c, d_workp, npair_only);
 			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
 			be.dzero(d_tops + 8, 16);
-			be.st_totals(c, work, nfull + nshadow, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);
+			be.st_totals(c, work, nfull + nshadow + nwalk, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);
 			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, true);
 			unsigned long long nnew_chg[2] = {0, 0};           // newly count-sensitive pairs; did any evaluated slot draw a different number than last time?
 			const bool want_vcnt = vcnt.empty() && V && work == nullptr;   // the variant slots' draw counts ride on the same synchronisation
@@ -632,9 +634,9 @@ template <class BE> struct EngineCore {
 				adopt_pair.clear(), adopt_slot.clear();
 			}
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
-			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 8);
-			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, d_resel_save, P < kReselCap ? P : kReselCap);
-			unsigned long long nd17[17];
+			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 16);
+			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, d_resel_save, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
+			unsigned long long nd17[26];                    // [0] full re-runs, [16] pairing only, [24] tie-only pairs seen, [25] of those: on from the walk
 			int32_t flags[8];
 			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 32);
 			const unsigned long long nd[2] = {nd17[0], nd17[16]};
@@ -648,8 +650,8 @@ template <class BE> struct EngineCore {
 				return run(trace, want_stats, depth);
 			}
 			if (flags[6]) { char b[128]; snprintf(b, sizeof b, "device stage error %d (the reference would abort here)", flags[6]); err = b; rc = PSVR_ERR_UNSUPPORTED; break; }
-			nfull = (long long)nd[0], npair_only = (long long)nd[1], nshadow = 0;
-			if (nfull == 0 && npair_only == 0) break;
+			nfull = (long long)nd[0], npair_only = (long long)nd[1], nshadow = 0, nwalk = (long long)nd17[25];
+			if (nfull == 0 && npair_only == 0 && nwalk == 0) break;
 			if (stats.rounds > 200) { err = "rand()-order resolution did not converge in 200 rounds"; rc = PSVR_ERR_UNSUPPORTED; break; }
 			work = d_work;
 			// offset windows for the tie-sensitive pairs that move
@@ -675,6 +677,7 @@ template <class BE> struct EngineCore {
 				be.copy_hoff_to_shadows(c, P + V, nshadow);
 				be.append_iota(d_work, nfull, P + V, nshadow);      // work list: dirty real pairs, then the shadow slots
 			}
+			if (nwalk) be.append_list(d_work, nfull + nshadow, d_resel4, nwalk);   // ... then the pairs that go on from the walk
 		}
 		c.stats = stats_ptr;
 		if (rc == PSVR_OK && want_stats) be.d2h(stats.counters, stats_ptr, 16 * 8);

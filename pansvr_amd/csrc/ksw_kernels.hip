@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 // step and column, ~1.3 wavefront instructions per cell instead of ~7 for a wavefront per alignment.
 template <int LANES, int CPL>
 #ifndef PSVR_TEAM_WAVES
-#define PSVR_TEAM_WAVES 4          /* wavefronts per SIMD the register allocation aims at (4 = 128 VGPRs) */
+#define PSVR_TEAM_WAVES 3          /* wavefronts per SIMD the register allocation aims at: 2 lanes x 8 columns needs 166 VGPRs (3 per SIMD); held to 128 it spills and
+                                      runs like 4 x 4 did -- 3.99 / 4.00 / 2.44 ms for 4 x 4, 2 x 8 at four, 2 x 8 at three wavefronts on one box, profiles/r03b */
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
 {

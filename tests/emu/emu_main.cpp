@@ -87,7 +87,7 @@ struct CpuBE {
 		for (long long i = 0; i < n; ++i) { out[off + i * stride] = acc; acc += cnt[off + i * stride]; }
 	}
 	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp,
-	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3)
+	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3, int32_t *out4, unsigned long long *cnt4)
 	{
 		for (long long p = 0; p < c.n_pairs; ++p) {
 			int d = mark_dirty(c, p, noff, nhoff, has_n);
@@ -99,9 +99,10 @@ struct CpuBE {
 		for (unsigned long long i = 0; i < *cnt3; ++i) {
 			const long long p = out3[i];
 			if (reselect_pair(c, p, save + i * 12) == 1) outp[(*cntp)++] = (int32_t)p;
-			else out[(*cnt)++] = (int32_t)p;
+			else out4[(*cnt4)++] = (int32_t)p;
 		}
 	}
+	void append_list(int32_t *w, long long at, const int32_t *src, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = src[i]; }
 	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff) { for (long long i = 0; i < n; ++i) adopt_variant(c, pairs[i], slots[i], noff, 0, 1); }
 	bool side_begin() { return false; }       // one queue
 	void side_end() {}
