@@ -48,6 +48,8 @@ struct Opt {
 	std::vector<int> devices = {0};
 	long long batch_pairs = 2000000;       // N_NEEDED, rr.cpp:24
 	long long batch_bases = 100000000;     // MAX_read_size, rr.cpp:109 (333 334 pairs of 150 bp: the limit that actually binds)
+	long long sub_pairs = 65536;           // a batch travels through the four stages in pieces of this many pairs (0 = whole batches): three
+	                                       // reference-sized batches do not fill a four-stage pipeline, forty pieces do
 	bool sig_all = false, sig_discard = false;   // BAM input: fc_signal's -D / -U
 	int bam_level = -1;                          // zlib level of the BGZF blocks (-1 = zlib's default, what htslib's "wb" uses)
 };
@@ -82,6 +84,7 @@ static int usage()
 	        "        --device            INT  the same for one device\n"
 	        "        --batch             INT  read pairs per batch [2000000]\n"
 	        "        --batch-bases       INT  bases per batch (the reference stops a batch at 100 MB of bases) [100000000]\n"
+	        "        --sub-batch         INT  pairs per pipeline piece of a batch, 0 = whole batches (results do not depend on it) [65536]\n"
 	        "        --compress-level    INT  zlib level of the BAM output's BGZF blocks, 0-9 (1 is ~3x faster than the default) [-1 = default, like htslib]\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
 	        "        --trace                  add per-strand seed/chain hashes to --records\n\n");
@@ -177,7 +180,7 @@ int main(int argc, char **argv)
 	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
 	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
 	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
-	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006},
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006}, {"sub-batch", 1, 0, 1007},
 	                             {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {"sort-by-name", 0, 0, 'N'}, {0, 0, 0, 0}};
 	int c;
 	bool sig_by_name = false;
@@ -204,6 +207,7 @@ int main(int argc, char **argv)
 		case 1003: o.batch_pairs = atoll(optarg); break;
 		case 1004: if (!parse_devices(optarg, &o.devices)) { fprintf(stderr, "bad --devices list '%s'\n", optarg); return 1; } break;
 		case 1005: o.batch_bases = atoll(optarg); break;
+		case 1007: o.sub_pairs = atoll(optarg); break;
 		case 1006: o.bam_level = atoi(optarg); if (o.bam_level < -1 || o.bam_level > 9) { fprintf(stderr, "--compress-level wants -1 .. 9\n"); return 1; } break;
 		case 'D': o.sig_all = true; break;
 		case 'U': o.sig_discard = true; break;
@@ -303,6 +307,7 @@ int main(int argc, char **argv)
 		std::vector<std::vector<uint8_t>> mb, ob;   // formatted records of both files, per chunk of pairs
 		int state = 0;              // 0 free, 1 loaded, 2 aligned, 3 formatted
 		bool last = false;          // end-of-input marker travelling through the stages
+		long long batch_pairs_done = 0;   // > 0 on the last piece of a reference-sized batch: that batch's pairs (the progress line)
 	};
 	const int kSlots = 5;
 	Job jobs[kSlots];
@@ -313,23 +318,30 @@ int main(int argc, char **argv)
 	auto set_state = [&](Job &J, int st) { { std::lock_guard<std::mutex> lk(mu); J.state = st; } cv.notify_all(); };
 	int block = 0;
 	double t_read = 0, t_engine = 0, t_format = 0, t_write = 0, t_exchange = 0;
-	long long n_batches = 0, total_pairs = 0, rebase_iters = 0, d2h_bytes = 0;
+	long long n_batches = 0, n_ref_batches = 0, total_pairs = 0, rebase_iters = 0, d2h_bytes = 0;   // pieces run by the engine; reference-sized batches
 	size_t hbm_first = 0, hbm_last = 0;
 	EmitStats emit_stats;
 	std::thread reader([&]() {
 		long long loaded = 0, pair_base = 0;
+		// the reference's batch: N_NEEDED pairs or MAX_read_size bases, whichever comes first (rr.cpp:24,109,126); it is read in pieces
+		// that end where it ends (a piece stops at what is left of both limits), so the batches are the reference's
+		long long in_batch_pairs = 0, in_batch_bases = 0;
 		for (int slot = 0;; slot = (slot + 1) % kSlots) {
 			Job &J = jobs[slot];
 			wait_state(J, 0);
-			long long want = o.batch_pairs;
+			long long want = o.batch_pairs - in_batch_pairs;
+			if (o.sub_pairs > 0 && o.sub_pairs < want) want = o.sub_pairs;
 			if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
 			double tw = walltime();
-			const bool ok = want > 0 && fq.read(J.fb, want, o.batch_bases, o.thread_n);
+			const bool ok = want > 0 && fq.read(J.fb, want, o.batch_bases - in_batch_bases, o.thread_n);
 			t_read += walltime() - tw;
-			if (!ok) { J.last = true; set_state(J, 1); return; }
+			if (!ok) { J.last = true; J.batch_pairs_done = in_batch_pairs; set_state(J, 1); return; }
 			if (loaded == 0) fq.stat_params(&par);          // STAT_ of the very first read (rr.cpp:134-148), before the first batch is aligned
 			loaded += J.fb.n_pairs();
 			J.pair_base = pair_base, pair_base += J.fb.n_pairs();
+			in_batch_pairs += J.fb.n_pairs(), in_batch_bases += J.fb.base_off[J.fb.R];
+			J.batch_pairs_done = 0;
+			if (in_batch_pairs >= o.batch_pairs || in_batch_bases >= o.batch_bases) J.batch_pairs_done = in_batch_pairs, in_batch_pairs = in_batch_bases = 0;
 			set_state(J, 1);
 		}
 	});
@@ -341,10 +353,14 @@ int main(int argc, char **argv)
 		for (int slot = 0;; slot = (slot + 1) % kSlots) {
 			Job &J = jobs[slot];
 			wait_state(J, 2);
-			if (J.last) { set_state(J, 3); return; }
+			if (J.last) {
+				if (J.batch_pairs_done > 0) fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)J.batch_pairs_done, block++), ++n_ref_batches;   // the input ended inside a batch
+				set_state(J, 3);
+				return;
+			}
 			const long long P = J.fb.n_pairs();
 			double tw = walltime();
-			fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)P, block++);     // output_results, rr.cpp:166
+			if (J.batch_pairs_done > 0) fprintf(stderr, "Processing %d reads, at block ID %d\n", (int)J.batch_pairs_done, block++), ++n_ref_batches;     // output_results, rr.cpp:166
 			em.min_filter_score = par.min_filter_score;
 			if (frec) {
 				for (const Block &bk : J.blk)
@@ -414,12 +430,16 @@ int main(int argc, char **argv)
 		std::vector<int> rcs((size_t)D, 0);
 		std::vector<std::string> errs((size_t)D);
 		auto fail_check = [&]() { for (int d = 0; d < D; ++d) if (rcs[(size_t)d]) { fprintf(stderr, "[panSVR-amd] engine error %d on device %d: %s\n", rcs[(size_t)d], o.devices[(size_t)d], errs[(size_t)d].c_str()); abort(); } };
+		static const bool cli_timing = getenv("PSVR_CLI_TIMING") != nullptr;
 		each_device([&](int d) {
 			Block &bk = J.blk[(size_t)d];
 			const long long n = bk.hi - bk.lo;
+			const double t0 = walltime();
 			int rc = psvr_engine_set_stream_pos(eng[(size_t)d], pos);        // block 0 starts there; the others are moved below
 			if (!rc) rc = psvr_engine_upload(eng[(size_t)d], n, J.fb.bases, J.fb.base_off + 2 * bk.lo, J.fb.ori + 2 * bk.lo);
+			const double t1 = walltime();
 			if (!rc) rc = psvr_engine_run(eng[(size_t)d], o.trace ? 1 : 0, nullptr);
+			if (cli_timing && d == 0) fprintf(stderr, "[panSVR-amd] batch %lld: engine ready %.1f ms after the batch, upload %.1f ms, run %.1f ms\n", n_batches, (t0 - tw) * 1e3, (t1 - t0) * 1e3, (walltime() - t1) * 1e3);
 			if (rc) rcs[(size_t)d] = rc, errs[(size_t)d] = psvr_last_error();
 		});
 		fail_check();
@@ -501,9 +521,9 @@ int main(int argc, char **argv)
 	if (emit_stats.dropped) fprintf(stderr, "[panSVR-amd] %lld records were refused by the record rules of sam_parse1 and not written (see the ERROR lines above)\n", (long long)emit_stats.dropped);
 	fprintf(stderr, "[panSVR-amd] wall: read+parse %.3f s, engine (upload+run+download) %.3f s, format %.3f s, write%s %.3f s\n", t_read, t_engine, t_format, o.sam ? "" : "+compress", t_write);
 	fprintf(stderr,
-	        "[panSVR-amd] e2e_json {\"pairs\":%lld,\"batches\":%lld,\"devices\":%d,\"threads\":%d,\"wall_s\":%.4f,\"index_s\":%.4f,\"index_first_s\":%.4f,\"index_clone_s\":%.4f,\"read_parse_s\":%.4f,"
+	        "[panSVR-amd] e2e_json {\"pairs\":%lld,\"batches\":%lld,\"pieces\":%lld,\"devices\":%d,\"threads\":%d,\"wall_s\":%.4f,\"index_s\":%.4f,\"index_first_s\":%.4f,\"index_clone_s\":%.4f,\"read_parse_s\":%.4f,"
 	        "\"engine_s\":%.4f,\"exchange_s\":%.4f,\"rebase_iterations\":%lld,\"format_s\":%.4f,\"write_s\":%.4f,\"d2h_bytes\":%lld,\"hbm_used_first\":%zu,\"hbm_used_last\":%zu,\"dropped\":%lld}\n",
-	        total_pairs, n_batches, D, o.thread_n, wall, t_index, t_idx_first, t_idx_clone, t_read, t_engine, t_exchange, rebase_iters, t_format, t_write, d2h_bytes, hbm_first, hbm_last,
+	        total_pairs, n_ref_batches, n_batches, D, o.thread_n, wall, t_index, t_idx_first, t_idx_clone, t_read, t_engine, t_exchange, rebase_iters, t_format, t_write, d2h_bytes, hbm_first, hbm_last,
 	        (long long)emit_stats.dropped);
 	return 0;
 }
