@@ -55,6 +55,7 @@ def main():
                     help="engines per GPU: the rank's block is cut into that many contiguous sub-blocks, each run by its own engine on its own HIP queue.  Measured on "
                          "configs[1]: 1 engine 12.5 ms/step, 2 engines 16.5, 4 engines 27.6 -- the stages fill the chip by themselves, a second queue only adds the rebase rounds")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU-baseline leg (0 = all cores, capped at the reference's 48)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous, rank -> device selection and one barrier only (no GPU is touched): the launch contract, testable on CPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,9 +68,20 @@ def main():
     rehearse = os.environ.get("PSVR_BENCH_REHEARSE") == "1"      # all ranks share GPU 0 and exchange over gloo (single-GPU rehearsal of the N > 1 path)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if rehearse or not torch.cuda.is_available() else "nccl")
+        if not args.dry_run:
+            dist.init_process_group("gloo" if rehearse or not torch.cuda.is_available() else "nccl")
         if rehearse:
             local_rank = 0
+    if args.dry_run:
+        # what the driver's launch line must lead to: rank r of the node drives HIP device LOCAL_RANK, chosen before anything touches a GPU
+        if world > 1 and not dist.is_initialized():
+            dist.init_process_group("gloo")
+        if world > 1:
+            dist.barrier()
+        print(json.dumps({"dry_run": True, "rank": rank, "world": world, "local_rank": local_rank, "device": local_rank, "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if torch.cuda.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     # the engine library, the CLI (its `index` sub-command builds the bench index) and the checkers: built here if the tree is a
@@ -114,24 +126,53 @@ def main():
 
     torch.cuda.set_device(local_rank)
     xdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else None
-    t_up = time.time()
-    index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
-    t_index_upload = time.time() - t_up
     index_bytes = int(sum(v.nbytes for k, v in ix_arrays.items() if hasattr(v, "nbytes") and k != "hash_sparse"))
-    del ix_arrays
-    index_bcast = None
-    if world > 1 and xdev:
-        # SURVEY 8(e) asks for both: every rank uploads its own copy over PCIe (above) vs one RCCL broadcast of the same bytes over xGMI
+    index_bcast, index_how = None, "every rank uploads its own copy from host memory"
+    index = None
+    t_up = time.time()
+    if world > 1:
+        # rank 0 uploads the index once, the others receive the eight arrays through a broadcast (RCCL over xGMI; in the
+        # one-GPU rehearsal gloo moves host copies instead) and build their index from device memory (psvr_index_create_from_device).
+        # All ranks agree first that every rank is ready for it; any failure before the collective falls back to per-rank uploads.
+        keys = ("ref_seq", "seq", "seqf", "pos", "posp", "hash", "kmer", "off")
+        ok = 1
         try:
-            buf = torch.empty(index_bytes, dtype=torch.uint8, device="cuda")
-            dist.barrier(); torch.cuda.synchronize()
-            tb = time.time()
-            dist.broadcast(buf, src=0)
+            tens = {}
+            for k in keys:
+                a = ix_arrays[k]
+                host = torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32))
+                if rank == 0:
+                    tens[k] = host.to("cuda") if xdev else host
+                else:
+                    tens[k] = torch.empty(host.shape, dtype=host.dtype, device="cuda" if xdev else "cpu")
             torch.cuda.synchronize()
+        except Exception as ex:
+            ok, tens = 0, {}
+            print("[bench] rank %d: index broadcast not prepared: %r" % (rank, ex), file=sys.stderr)
+        t_index_upload = time.time() - t_up                      # rank 0: the one host upload; others: allocation only
+        flag = torch.tensor([ok], device=xdev or "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            dist.barrier()
+            if xdev:
+                torch.cuda.synchronize()
+            tb = time.time()
+            for k in keys:
+                dist.broadcast(tens[k], src=0)
+            if xdev:
+                torch.cuda.synchronize()
             index_bcast = round((time.time() - tb) * 1e3, 2)
-            del buf
-        except Exception as ex:      # the measurement is optional
-            index_bcast = "failed: %r" % (ex,)
+            if not xdev:
+                tens = {k: v.to("cuda") for k, v in tens.items()}
+                torch.cuda.synchronize()
+            index = aln.Index.from_device_tensors(tens, ix_arrays["chr"], ["chr1", "chr2"], device=local_rank)
+            index_how = "rank 0 uploads, %s broadcast of the eight arrays, every rank builds its index device to device" % ("RCCL" if xdev else "gloo (host copies: one-GPU rehearsal)")
+            del tens
+    if index is None:
+        t_up = time.time()
+        index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
+        t_index_upload = time.time() - t_up
+    del ix_arrays
     from pansvr_amd import dist as pdist
     K = max(1, args.engines)
     cuts = [args.pairs * j // K for j in range(K + 1)]
@@ -416,7 +457,7 @@ def main():
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step,
                                                  "parallelism": "shard%d x %d engine(s) per GPU (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, K, "none" if world == 1 else "all-gather of 6 int64 per rank over %s, %d per step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
                                                  "engines_per_gpu": K, "in_process_rebases": group_rebases,
-                                                 "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast,
+                                                 "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast, "index_distribution": index_how,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,
                 "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "dp_seq_bytes", "stale_open", "candidates", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},

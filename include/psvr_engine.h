@@ -144,6 +144,10 @@ typedef struct psvr_index_view {           /* host pointers, element counts (not
 } psvr_index_view_t;
 
 int psvr_index_create(const psvr_index_view_t *view, int device, psvr_index_t **out);
+/* The same with the eight arrays of `view` already in the memory of `device` (device pointers; chr_text / header_names stay host
+ * pointers): one process per GPU receives them through a collective -- rank 0 uploads, an RCCL broadcast over xGMI brings them to
+ * the other ranks (SURVEY 8(e) "broadcast index"; bench.py --gpus N) -- and builds its index from them, device to device. */
+int psvr_index_create_from_device(const psvr_index_view_t *view, int device, psvr_index_t **out);
 /* reads the nine files from `index_dir` and the @SQ lines of `header_sam` */
 int psvr_index_load(const char *index_dir, const char *header_sam, int device, psvr_index_t **out);
 /* Multi-GPU: a second copy of an index that is already resident on another device, moved device to device (xGMI peer

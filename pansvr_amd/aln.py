@@ -61,6 +61,27 @@ class Index:
         self.device_bytes = int(L.psvr_index_device_bytes(self.h))
         self._keep = None  # host copies are no longer needed: the index lives in HBM
 
+    @classmethod
+    def from_device_tensors(cls, tensors, chr_text, header_names, device=0):
+        """tensors: dict of torch tensors ON `device` (ref_seq, seq, seqf, pos, posp, hash, off: int64 views of the uint64 arrays; kmer:
+        int32) -- e.g. what an RCCL broadcast delivered.  The index is built from them device to device."""
+        L = lib()
+        L.psvr_index_device_bytes.restype = C.c_int64
+        self = cls.__new__(cls)
+        v = IndexView()
+        for f in ("ref_seq", "seq", "seqf", "pos", "posp", "hash", "kmer", "off"):
+            t = tensors[f]
+            setattr(v, f, t.data_ptr())
+            setattr(v, "n_" + f, t.numel())
+        v.chr_text = chr_text.encode()
+        names = (C.c_char_p * len(header_names))(*[n.encode() for n in header_names])
+        v.header_names, v.n_header = names, len(header_names)
+        self.h = C.c_void_p()
+        check(L.psvr_index_create_from_device(C.byref(v), device, C.byref(self.h)))
+        self.device_bytes = int(L.psvr_index_device_bytes(self.h))
+        self._keep = None
+        return self
+
     def close(self):
         if self.h:
             lib().psvr_index_destroy(self.h)

@@ -877,6 +877,7 @@ __global__ void k_scatter_u8(uint8_t *a, const int32_t *idx, long long n, uint8_
 struct DpPlanDev {
 	const DpDesc *desc; long long n;
 	int32_t *qlen, *tlen; long long *q_off, *t_off, *p_off;
+	int32_t *qpad, *tpad;          // the lengths rounded up to 16: every sequence starts on a 16-byte boundary of its buffer (k_dp_fetch stores 16 bases at a time)
 	int32_t *plen;                 // padded direction-byte bytes for general-kernel problems (0 otherwise), as int32 units of 256 B
 	int32_t *bucket;               // bucket id per problem
 	unsigned long long *hist;      // [512] counts, [512] cursors, then [16] the longest query per team-kernel class + [1] the scratch top
@@ -899,10 +900,13 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES) lq[threadIdx.x] = 0;
 	__syncthreads();
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i == 0) d.qlen[d.n] = d.tlen[d.n] = d.plen[d.n] = 0;      // the scans run over n + 1 entries
+	unsigned int seq_bytes = 0;                                  // query + target bytes of this thread's problem (summed per block into hist[1041])
+	if (i == 0) d.qlen[d.n] = d.tlen[d.n] = d.plen[d.n] = d.qpad[d.n] = d.tpad[d.n] = 0;      // the scans run over n + 1 entries
 	if (i < d.n) {
 		const DpDesc &x = d.desc[i];
 		d.qlen[i] = x.qlen, d.tlen[i] = x.tlen;
+		d.qpad[i] = (x.qlen + 15) & ~15, d.tpad[i] = (x.tlen + 15) & ~15;
+		seq_bytes = (unsigned int)(x.qlen + x.tlen);
 		int need;
 		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need, tiny_ok != 0, team_ok != 0);
 		int cls = 0;
@@ -916,6 +920,8 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 	__syncthreads();
 	for (int t = threadIdx.x; t < 512; t += 256) if (lh[t]) atomicAdd(d.hist + t, (unsigned long long)lh[t]);
 	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES && lq[threadIdx.x]) atomicMax(d.hist + 1024 + threadIdx.x, (unsigned long long)lq[threadIdx.x]);
+	for (int o = 32; o; o >>= 1) seq_bytes += __shfl_xor(seq_bytes, o);
+	if ((threadIdx.x & 63) == 0 && seq_bytes) atomicAdd(d.hist + 1041, (unsigned long long)seq_bytes);
 }
 __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
 {
@@ -935,16 +941,53 @@ __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long l
 		d.ez[i].cigar_off = d.q_off[i] + d.t_off[i] + 2 * i;
 	}
 }
-// K5 ref_fetch: unpack the 2-bit reference window / slice the read for every queued DP problem
-// 16 lanes per problem (most are a few bases long: the end-to-end gap fills), four problems per wavefront
+// K5 ref_fetch: unpack the 2-bit reference window / slice the read for every queued DP problem (get_refseq + the reversal of left
+// extensions, rr.cpp:920-928).  16 lanes per problem, four problems per wavefront (most are a few bases long: the end-to-end gap fills);
+// a lane turns 16 bases -- one 32-bit window of the packed source -- into 16 bytes and stores them in one piece (the sequences start on
+// 16-byte boundaries of their buffers): a base at a time was a load, a dozen instructions and a byte store per base.
+__device__ __forceinline__ uint32_t expand4(uint32_t x)             // 8 bits = four bases, first in the top bits -> four bytes, first in the lowest
+{
+	return ((x >> 6) & 3u) | ((x << 4) & 0x300u) | ((x << 14) & 0x30000u) | ((x << 24) & 0x3000000u);
+}
+__device__ __forceinline__ uint4 expand16(uint32_t w)               // 32 bits = 16 bases, first in the top bits
+{
+	return make_uint4(expand4(w >> 24), expand4((w >> 16) & 0xffu), expand4((w >> 8) & 0xffu), expand4(w & 0xffu));
+}
+__device__ __forceinline__ uint32_t rev_bases16(uint32_t w)         // the 16 2-bit groups of w in reverse order
+{
+	const uint32_t t = __builtin_bitreverse32(w);
+	return ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
+}
 __global__ __launch_bounds__(256) void k_dp_fetch(Ctx c, long long begin, long long np, const long long *q_off, const long long *t_off, uint8_t *qbuf, uint8_t *tbuf)
 {
 	const long long p = blockIdx.x * 16ll + (threadIdx.x >> 4);
 	if (p >= np) return;
 	const DpDesc &x = c.dp.base[begin + p];
 	uint8_t *q = qbuf + q_off[p], *t = tbuf + t_off[p];
-	const int n = x.qlen > x.tlen ? x.qlen : x.tlen;
-	for (int i = threadIdx.x & 15; i < n; i += 16) dp_fetch_base(c, x, i, q, t);
+	const int lane = threadIdx.x & 15;
+	const bool rev = x.type == 0;
+	const bool bytes = c.has_n4[x.read] != 0;                       // a read with a lower-case 'n' (code 4): its bases come from the per-base bytes
+	const uint64_t *rw = c.rb + ((long long)x.read * 2 + x.strand) * c.wmax;
+	const int nq = x.qlen >> 4, nt = x.tlen >> 4;                    // whole 16-base pieces
+	for (int k = lane; k < nq + nt; k += 16) {
+		const bool is_t = k >= nq;
+		const int i0 = 16 * (is_t ? k - nq : k), len = is_t ? x.tlen : x.qlen;
+		if (!is_t && bytes) { for (int i = i0; i < i0 + 16; ++i) dp_fetch_base(c, x, i, q, t); continue; }
+		const uint64_t *src = is_t ? c.idx.ref_seq : rw;
+		const uint64_t st = is_t ? (uint64_t)x.ref_st : (uint64_t)x.q_st;
+		const uint32_t w = (uint32_t)(window32(src, st + (uint64_t)(rev ? len - 16 - i0 : i0)) >> 32);
+		*(uint4 *)((is_t ? t : q) + i0) = expand16(rev ? rev_bases16(w) : w);
+	}
+	// the tails (< 16 bases each), a base per lane
+	{
+		const int i = 16 * nq + lane;
+		if (i < x.qlen) {
+			const int qi = x.q_st + (rev ? x.qlen - 1 - i : i);
+			q[i] = bytes ? c.bin[((long long)x.read * 2 + x.strand) * c.lmax + qi] : (uint8_t)base_at(rw, (uint64_t)qi);
+		}
+		const int j = 16 * nt + lane;
+		if (j < x.tlen) t[j] = (uint8_t)base_at(c.idx.ref_seq, (uint64_t)x.ref_st + (rev ? x.tlen - 1 - j : j));
+	}
 }
 
 struct GpuBE {
@@ -952,7 +995,7 @@ struct GpuBE {
 	hipStream_t stream = nullptr;
 	hipError_t last = hipSuccess;
 	std::vector<std::pair<std::string, long long>> launches;   // for psvr_engine_stats
-	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, pslab, strip_ws;
+	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, plan_qpad, plan_tpad, pslab, strip_ws;
 	DpParams dpP;
 	bool dp_ready = false;
 	static constexpr long long kTeamMinProblems = 32768;       // below this a round's DP problems go to the wavefront-per-alignment kernels
@@ -1292,35 +1335,37 @@ struct GpuBE {
 		// upper bounds for the sequence buffers: every problem has qlen, tlen < 1600; size from the actual lens
 		if (!core.ensure_dp(n, 0, 0, 0)) return set_error(PSVR_ERR_NOMEM, "DP buffers");
 		PSVR_HIP(plan_bucket.ensure(n * 4)); PSVR_HIP(plan_idx.ensure(n * 4)); PSVR_HIP(plan_plen.ensure((n + 1) * 4)); PSVR_HIP(plan_poff.ensure((n + 1) * 8));
+		PSVR_HIP(plan_qpad.ensure((n + 1) * 4)); PSVR_HIP(plan_tpad.ensure((n + 1) * 4));
 		PSVR_HIP(plan_hist.ensure(1056 * 8)); PSVR_HIP(plan_bstart.ensure(512 * 8));
 		PSVR_HIP(hipMemsetAsync(plan_hist.p, 0, 1056 * 8, stream));
 		DpPlanDev pd;
 		pd.desc = c.dp.base + d.begin, pd.n = n, pd.qlen = d.qlen, pd.tlen = d.tlen, pd.q_off = d.q_off, pd.t_off = d.t_off;
 		pd.p_off = plan_poff.as<long long>(), pd.plen = plan_plen.as<int32_t>(), pd.bucket = plan_bucket.as<int32_t>();
 		pd.hist = plan_hist.as<unsigned long long>(), pd.idx = plan_idx.as<int32_t>(), pd.ez = d.ez;
+		pd.qpad = plan_qpad.as<int32_t>(), pd.tpad = plan_tpad.as<int32_t>();
 		// a round with few problems (the re-runs after the first) cannot fill the chip at 16 alignments per wavefront: its time would be one
 		// wavefront's strips x (qlen + 15) steps; a wavefront per alignment needs qlen + tlen steps
 		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200, dp_tiny_ok(dpP, true) ? 1 : 0, n >= kTeamMinProblems ? 1 : 0);
-		st_scan((const int32_t *)d.qlen, n + 1, 1, 0, 0ll, d.q_off);
-		st_scan((const int32_t *)d.tlen, n + 1, 1, 0, 0ll, d.t_off);
+		st_scan((const int32_t *)pd.qpad, n + 1, 1, 0, 0ll, d.q_off);
+		st_scan((const int32_t *)pd.tpad, n + 1, 1, 0, 0ll, d.t_off);
 		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
 		PSVR_HIP(hipGetLastError());
-		unsigned long long hist[512], qmax[16];
+		unsigned long long hist[512], qmax[18];                // qmax[17]: query + target bytes of the round's problems
 		long long tot[3];
 		{
 			// one synchronisation for all five readbacks, through the pinned staging buffer when it exists
-			char stackbuf[512 * 8 + 16 * 8 + 24];
+			char stackbuf[512 * 8 + 18 * 8 + 24];
 			char *hb = pinned() ? (char *)pin : stackbuf;
 			PSVR_HIP(hipMemcpyAsync(hb, plan_hist.p, 512 * 8, hipMemcpyDeviceToHost, stream));
-			PSVR_HIP(hipMemcpyAsync(hb + 4096, (char *)plan_hist.p + 1024 * 8, 16 * 8, hipMemcpyDeviceToHost, stream));
-			PSVR_HIP(hipMemcpyAsync(hb + 4224, d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
-			PSVR_HIP(hipMemcpyAsync(hb + 4232, d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
-			PSVR_HIP(hipMemcpyAsync(hb + 4240, pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4096, (char *)plan_hist.p + 1024 * 8, 18 * 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4240, d.q_off + n, 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4248, d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
+			PSVR_HIP(hipMemcpyAsync(hb + 4256, pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
 			PSVR_HIP(hipStreamSynchronize(stream));
-			memcpy(hist, hb, 4096), memcpy(qmax, hb + 4096, 128), memcpy(tot, hb + 4224, 24);
+			memcpy(hist, hb, 4096), memcpy(qmax, hb + 4096, 144), memcpy(tot, hb + 4240, 24);
 		}
 		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
-		core.stats.dp_seq_bytes += tot[0] + tot[1];                   // query + target bytes the DP launches of this round read
+		core.stats.dp_seq_bytes += (long long)qmax[17];              // query + target bytes the DP launches of this round read (k_dp_lens sums them)
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
 		// scratch of the strip kernel: every wavefront bump-allocates what its 64 problems need; bound per class by its longest query
@@ -1445,15 +1490,18 @@ __global__ void k_scatter_counts(const uint32_t *ids, const uint32_t *cnts, long
 
 // `sparse` (optional, when v->hash is null): the non-empty first-level buckets as (id, count) -- the dense prefix-sum table is
 // then built in HBM (scatter + device scan) instead of being uploaded: 2 GiB that never exist on the host
-static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32_t *sparse_id = nullptr, const uint32_t *sparse_cnt = nullptr, long long n_sparse = 0)
+// `src_on_device`: the eight arrays of the view are device pointers on ix->device (psvr_index_create_from_device)
+static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32_t *sparse_id = nullptr, const uint32_t *sparse_cnt = nullptr, long long n_sparse = 0,
+                        bool src_on_device = false)
 {
 	PSVR_HIP(hipSetDevice(ix->device));
+	bool from_dev = src_on_device;
 	auto up = [&](DevBuf &b, const void *src, size_t n, size_t pad) -> hipError_t {
 		hipError_t e = b.alloc(n + pad);
 		if (e != hipSuccess) return e;
 		ix->bytes += (int64_t)(n + pad);
 		if (pad) { e = hipMemset((char *)b.p + n, 0, pad); if (e != hipSuccess) return e; }
-		return n ? hipMemcpy(b.p, src, n, hipMemcpyHostToDevice) : hipSuccess;
+		return n ? hipMemcpy(b.p, src, n, from_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) : hipSuccess;
 	};
 	PSVR_HIP(up(ix->ref_seq, v->ref_seq, v->n_ref_seq * 8, 544));   // load_index_file pads ref.seq with 536 zero bytes
 	PSVR_HIP(up(ix->seq, v->seq, v->n_seq * 8, 16));
@@ -1478,6 +1526,7 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32
 	}
 	PSVR_HIP(up(ix->off, v->off, v->n_off * 8, 0));
 	PSVR_HIP(up(ix->kmer, v->kmer, v->n_kmer * 4, 16));
+	from_dev = false;                                      // the derived tables below come from the host
 	const HostIndex &h = ix->host;
 	PSVR_HIP(up(ix->chr_end, h.chr_end_n.data(), h.chr_end_n.size() * 4, 0));
 	PSVR_HIP(up(ix->chr_idx, h.chr_search_index.data(), h.chr_search_index.size() * 4, 0));
@@ -1499,12 +1548,19 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32
 	// bracket table for the unipath-of-position search (aln_device.h mem_for_hit): one entry per 1024 positions
 	{
 		const uint32_t sh = 10;
-		const uint64_t last = v->n_seqf ? v->seqf[v->n_seqf - 1] : 0;
+		std::vector<uint64_t> seqf_host;
+		const uint64_t *seqf = v->seqf;
+		if (src_on_device) {                               // (U + 1 words: the unipath starts, read back for the table)
+			seqf_host.resize((size_t)v->n_seqf);
+			PSVR_HIP(hipMemcpy(seqf_host.data(), v->seqf, (size_t)v->n_seqf * 8, hipMemcpyDeviceToHost));
+			seqf = seqf_host.data();
+		}
+		const uint64_t last = v->n_seqf ? seqf[v->n_seqf - 1] : 0;
 		std::vector<uint32_t> hint((size_t)(last >> sh) + 3);
 		uint64_t u = 0;
 		for (size_t b = 0; b < hint.size(); ++b) {
 			const uint64_t p = (uint64_t)b << sh;
-			while (u + 1 < v->n_seqf && v->seqf[u + 1] <= p) ++u;
+			while (u + 1 < v->n_seqf && seqf[u + 1] <= p) ++u;
 			hint[b] = (uint32_t)u;
 		}
 		PSVR_HIP(up(ix->uid_hint, hint.data(), hint.size() * 4, 0));
@@ -1526,6 +1582,26 @@ extern "C" int psvr_index_create(const psvr_index_view_t *v, int device, psvr_in
 	std::string err;
 	if (!ix->host.parse_chr(v->chr_text, names, &err)) { delete ix; return set_error(PSVR_ERR_IO, "%s", err.c_str()); }
 	int rc = index_upload(ix, v);
+	if (rc) { delete ix; return rc; }
+	*out = ix;
+	return PSVR_OK;
+}
+
+// Multi-GPU, one process per GPU: the arrays arrive in this device's memory through a collective (rank 0 uploads once, an RCCL broadcast
+// over xGMI brings them to the others: bench.py) and become the index without touching the host again
+extern "C" int psvr_index_create_from_device(const psvr_index_view_t *v, int device, psvr_index_t **out)
+{
+	if (!v || !out || !v->ref_seq || !v->seq || !v->seqf || !v->pos || !v->posp || !v->hash || !v->kmer || !v->off || !v->chr_text)
+		return set_error(PSVR_ERR_ARG, "psvr_index_create_from_device: null pointer in view");
+	if (v->n_hash != ((uint64_t)1 << 28) + 1) return set_error(PSVR_ERR_IO, "unipath_g.hash must hold 4^14+1 entries, got %llu", (unsigned long long)v->n_hash);
+	if (psvr_device_count() <= 0) return set_error(PSVR_ERR_DEVICE, "no HIP device visible: the engine has no CPU path");
+	psvr_index *ix = new psvr_index;
+	ix->device = device;
+	std::vector<std::string> names;
+	for (int i = 0; i < v->n_header; ++i) names.push_back(v->header_names[i]);
+	std::string err;
+	if (!ix->host.parse_chr(v->chr_text, names, &err)) { delete ix; return set_error(PSVR_ERR_IO, "%s", err.c_str()); }
+	int rc = index_upload(ix, v, nullptr, nullptr, 0, true);
 	if (rc) { delete ix; return rc; }
 	*out = ix;
 	return PSVR_OK;

@@ -84,3 +84,19 @@ def test_two_rank_sharding_reproduces_the_single_stream_records():
     assert len(got) == len(want)
     bad = [i for i, (a, b) in enumerate(zip(want, got)) if a != b]
     assert not bad, "%d pairs differ, first %d:\n%s\n%s" % (len(bad), bad[0], want[bad[0]], got[bad[0]])
+
+
+def test_bench_launch_contract_selects_the_local_rank_device():
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) must bring rank r to HIP
+    device LOCAL_RANK before anything touches a GPU: `bench.py --dry-run` goes through the rendezvous (127.0.0.1), the device
+    choice and one barrier on CPU and prints what it chose."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    import re
+    got = sorted((json.loads(m) for m in re.findall(r"\{[^{}]*\"dry_run\"[^{}]*\}", r.stdout.decode())), key=lambda d: d["rank"])
+    assert [d["rank"] for d in got] == [0, 1] and all(d["device"] == d["local_rank"] == d["rank"] and d["world"] == 2 for d in got)
