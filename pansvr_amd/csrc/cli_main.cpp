@@ -264,22 +264,18 @@ int main(int argc, char **argv)
 	psvr::SignalStep sig;
 	std::thread sig_thread;
 	int sig_rc = 0;
+	PairFeed feed;
 	if (from_bam) {
-		signal(SIGPIPE, SIG_IGN);            // if the reader stops early (-R), the signal step's writes fail quietly and it runs to its end
-		int fds[2];
-		if (pipe(fds)) { fprintf(stderr, "[panSVR-amd] pipe() failed\n"); abort(); }
+		// f2 fused: the signal step's thread hands its pairs straight to the batch being built (PairFeed, fastq_batch.h) -- no FASTQ text, no pipe
 		sig.o.sort_by_name = sig_by_name, sig.o.input = o.reads, sig.o.header_fn = o.header, sig.o.status_fn = o.header + ".status";
 		sig.o.not_use_filter = o.sig_all, sig.o.discard_full_match = o.sig_discard;
 		sig.o.match = o.match, sig.o.mismatch = o.mismatch, sig.o.gap_open = o.gap_open, sig.o.gap_ex = o.gap_ex, sig.o.gap_open2 = o.gap_open2, sig.o.gap_ex2 = o.gap_ex2;
-		FILE *w = fdopen(fds[1], "w");
-		sig.out = w;
-		sig_thread = std::thread([&sig, &sig_rc, w]() { sig_rc = sig.run(); fclose(w); });
-		char b[64];
-		snprintf(b, sizeof b, "/dev/fd/%d", fds[0]);
-		fq_path = b;
+		sig.feed = &feed;
+		sig_thread = std::thread([&sig, &sig_rc, &feed]() { sig_rc = sig.run(); feed.close(); });
 	}
 	FastqReader fq;
-	if (!fq.open(fq_path.c_str())) { fprintf(stderr, "%s\n", fq.error().c_str()); abort(); }
+	if (from_bam) fq.open_feed(&feed);
+	else if (!fq.open(fq_path.c_str())) { fprintf(stderr, "%s\n", fq.error().c_str()); abort(); }
 	OutFile fo, fo_ori;
 	if (!fo.open(o.out, !o.sam, H, o.thread_n, o.bam_level) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n, o.bam_level)) { fprintf(stderr, "fail to open output file\n"); abort(); }
 	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
@@ -504,6 +500,7 @@ int main(int argc, char **argv)
 		set_state(J, 2);
 	}
 	reader.join(), formatter.join(), writer.join();
+	feed.abort();                                        // (a reader that stopped at -R leaves the signal step to run to its end unheard)
 	if (sig_thread.joinable()) {
 		sig_thread.join();
 		if (sig_rc) { fprintf(stderr, "[panSVR-amd] the signal step failed\n"); abort(); }

@@ -18,6 +18,8 @@
 #include <unistd.h>
 #include <zlib.h>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -217,8 +219,38 @@ struct FastqBatch {
 	void qual(long long r, const char *&b, int &n) const { line(4 * r + 3, b, n); }
 };
 
+// f2, the `signal` step fused with `aln`: when <reads> is a BAM, the signal step runs in this process and hands every
+// record pair it selects straight to the batch being built -- the record's text (kept for the records that are written: name, comment,
+// quality), its bases into the upload array and its original alignment as the numbers the signal step has just computed.  No FASTQ
+// text travels through a pipe, no line index is built, no comment is parsed again.  The batch limits are load_reads' (pairs or bases,
+// rr.cpp:24,109,126).  One producer (the signal step's thread), one consumer (the pipeline's reader stage).
+struct FastqBatch;
+class PairFeed {
+	std::mutex mu_;
+	std::condition_variable cv_;
+	FastqBatch *target_ = nullptr;
+	long long max_pairs_ = 0, max_bases_ = 0, pairs_ = 0, total_bases_ = 0;
+	int in_pair_ = 0;
+	bool full_ = false, eof_ = false, aborted_ = false;
+	std::vector<char> bases_;
+	std::vector<int64_t> off_;
+	std::vector<psvr_ori_t> ori_;
+	std::vector<uint16_t> name_end_;
+
+public:
+	std::string first_comment;
+	bool have_first = false;
+	// producer: one record (the pair is complete with its second one)
+	void put(const char *name, const std::string &comment, const std::string &seq, const std::string &qual, const psvr_ori_t &ori);
+	void close() { { std::lock_guard<std::mutex> lk(mu_); eof_ = true; } cv_.notify_all(); }
+	void abort() { { std::lock_guard<std::mutex> lk(mu_); aborted_ = true; } cv_.notify_all(); }     // the consumer stopped early (-R): the producer runs to its end unheard
+	// consumer: fills B up to the limits; false at the end of the input
+	bool fill(FastqBatch &B, long long max_pairs, long long max_bases);
+};
+
 class FastqReader {
 	TextSource src_;
+	PairFeed *feed_ = nullptr;
 	size_t est_pair_bytes_ = 1024;                   // bytes of text per pair, refined from the previous batch
 	std::vector<int32_t> slen_;                      // scratch: sequence length per candidate read of the batch being cut
 	std::string first_comment_;
@@ -246,12 +278,18 @@ class FastqReader {
 
 public:
 	bool open(const char *path) { return src_.open(path); }
+	void open_feed(PairFeed *f) { feed_ = f; }
 	const std::string &error() const { return src_.error(); }
 
 	// up to max_pairs pairs or max_bases bases (load_reads stops at 2 M pairs / 100 MB of bases, rr.cpp:24,109,126); false at the
 	// end of the input.  `B` keeps its buffers across calls.
 	bool read(FastqBatch &B, long long max_pairs, long long max_bases, int threads)
 	{
+		if (feed_) {
+			if (!feed_->fill(B, max_pairs, max_bases)) return false;
+			if (!have_first_ && feed_->have_first) first_comment_ = feed_->first_comment, have_first_ = true;
+			return true;
+		}
 		B.R = 0;
 		B.ls.clear();
 		B.ls.push_back(0);
@@ -345,5 +383,69 @@ public:
 		p->min_filter_score = mfs > 50 ? mfs : 50;
 	}
 };
+
+inline void PairFeed::put(const char *name, const std::string &comment, const std::string &seq, const std::string &qual, const psvr_ori_t &ori)
+{
+	std::unique_lock<std::mutex> lk(mu_);
+	cv_.wait(lk, [&] { return aborted_ || (target_ && !full_); });
+	if (aborted_) return;
+	FastqBatch &B = *target_;
+	if (!have_first) first_comment = comment, have_first = true;
+	// the record as the FASTQ file would hold it: @name comment \n seq \n + \n qual \n  (bam2fastqWrite_additional_str_gz, getSignalRead.cpp:15-34)
+	std::vector<char> &t = B.own;
+	const size_t nl = strlen(name);
+	t.push_back('@');
+	t.insert(t.end(), name, name + nl);
+	t.push_back(' ');
+	t.insert(t.end(), comment.begin(), comment.end());
+	t.push_back('\n');
+	B.ls.push_back(t.size());
+	t.insert(t.end(), seq.begin(), seq.end());
+	t.push_back('\n');
+	B.ls.push_back(t.size());
+	t.push_back('+'), t.push_back('\n');
+	B.ls.push_back(t.size());
+	t.insert(t.end(), qual.begin(), qual.end());
+	t.push_back('\n');
+	B.ls.push_back(t.size());
+	name_end_.push_back((uint16_t)(nl + 1 > 65535 ? 65535 : nl + 1));
+	bases_.insert(bases_.end(), seq.begin(), seq.end());
+	off_.push_back((int64_t)bases_.size());
+	ori_.push_back(ori);
+	total_bases_ += (long long)seq.size();
+	if (++in_pair_ == 2) {
+		in_pair_ = 0;
+		++pairs_;
+		if (pairs_ >= max_pairs_ || total_bases_ >= max_bases_) { full_ = true; lk.unlock(); cv_.notify_all(); }
+	}
+}
+
+inline bool PairFeed::fill(FastqBatch &B, long long max_pairs, long long max_bases)
+{
+	std::unique_lock<std::mutex> lk(mu_);
+	B.R = 0;
+	B.own.clear(), B.ls.clear(), B.ls.push_back(0);
+	bases_.clear(), off_.clear(), off_.push_back(0), ori_.clear(), name_end_.clear();
+	pairs_ = 0, total_bases_ = 0, full_ = false;
+	max_pairs_ = max_pairs, max_bases_ = max_bases;
+	target_ = &B;
+	cv_.notify_all();
+	cv_.wait(lk, [&] { return full_ || eof_; });
+	target_ = nullptr;
+	const long long R = 2 * pairs_;                           // (a trailing record without its mate cannot arrive: the signal step writes pairs)
+	if (R == 0) return false;
+	B.R = R;
+	B.text = B.own.data();
+	B.ls.resize((size_t)(4 * R + 1));
+	B.name_end.assign(name_end_.begin(), name_end_.begin() + R);
+	B.base_off = (int64_t *)B.off_buf.reserve((size_t)(R + 1) * 8);
+	B.ori = (psvr_ori_t *)B.ori_buf.reserve((size_t)R * sizeof(psvr_ori_t));
+	memcpy(B.base_off, off_.data(), (size_t)(R + 1) * 8);
+	memcpy(B.ori, ori_.data(), (size_t)R * sizeof(psvr_ori_t));
+	B.bases = (char *)B.bases_buf.reserve((size_t)B.base_off[R] + 16);
+	memcpy(B.bases, bases_.data(), (size_t)B.base_off[R]);
+	B.bases[B.base_off[R]] = 0;
+	return true;
+}
 
 } // namespace psvr

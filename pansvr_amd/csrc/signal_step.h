@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 #include "bam_reader.h"
+#include "fastq_batch.h"
 
 namespace psvr {
 
@@ -96,6 +97,7 @@ struct SignalStep {
 	bool stat_written = false;
 	int sample_max = 0;
 	FILE *out = stdout;
+	PairFeed *feed = nullptr;          // fused with `aln`: records go to the batch being built instead of FASTQ text on `out`
 
 	static bool primary(const BamRecord &r) { return !(r.flag & 0x100) && !(r.flag & 0x800); }
 
@@ -126,7 +128,7 @@ struct SignalStep {
 		return n;
 	}
 	// bam2fastqWrite_additional_str_gz, :15-34
-	void write_fastq(const BamRecord &b, const std::string &comment) const
+	void write_fastq(const BamRecord &b, const std::string &comment, const psvr_ori_t &ori) const
 	{
 		std::string seq, qual((size_t)b.l_qseq, '\0');
 		const uint8_t *s4 = b.seq(), *q = b.qual();
@@ -152,7 +154,8 @@ struct SignalStep {
 			}
 			for (int i = 0; i < half + 1 && len > 0; ++i) { const int ri = len - 1 - i; std::swap(qual[(size_t)i], qual[(size_t)ri]); }
 		}
-		fprintf(out, "@%s %s\n%s\n+\n%s\n", b.qname(), comment.c_str(), seq.c_str(), qual.c_str());
+		if (feed) feed->put(b.qname(), comment, seq, qual, ori);
+		else fprintf(out, "@%s %s\n%s\n+\n%s\n", b.qname(), comment.c_str(), seq.c_str(), qual.c_str());
 	}
 
 	// all_signal_records_read_pair, :100-256
@@ -244,8 +247,15 @@ struct SignalStep {
 			int32_t nm = 0;
 			if (x.num_tag("NM", &nm)) { snprintf(buf, sizeof buf, "NM:i:%d_", nm); reason[i] += buf; }
 		}
-		write_fastq(*b[0], reason[0]);
-		write_fastq(*b[1], reason[1]);
+		// the original alignment as `aln` reads it out of the comment (parse_ori_mapping_rst, rr.hpp:392-429: tokens 0-4 and the flag token)
+		psvr_ori_t ori[2];
+		for (int i = 0; i < 2; ++i) {
+			memset(&ori[i], 0, sizeof ori[i]);
+			ori[i].chr_id = tid[i], ori[i].ref_bg = (uint32_t)b[i]->pos, ori[i].read_bg = (uint32_t)soft_l[i], ori[i].align_score = (uint32_t)score[i], ori[i].mapq = (uint8_t)mapq[i];
+			ori[i].direction = flags[i][0] == 'F', ori[i].unmapped = flags[i][1] == 'Y';
+		}
+		write_fastq(*b[0], reason[0], ori[0]);
+		write_fastq(*b[1], reason[1], ori[1]);
 	}
 
 	// sampling_analysis_stat with bam_sort_by_name (getSignalRead.hpp:126-181): the first 100 000 primary records

@@ -19,6 +19,8 @@
 #include "../../pansvr_amd/csrc/host_io.h"
 #include "../../pansvr_amd/csrc/fastq_batch.h"
 #include "../../pansvr_amd/csrc/sam_emit.h"
+#include "../../pansvr_amd/csrc/signal_step.h"
+#include <thread>
 #include "../../oracle/ksw_oracle.h"
 
 using namespace psvr;
@@ -143,7 +145,7 @@ struct HostSvNames : SvNames {
 int main(int argc, char **argv)
 {
 	if (argc < 4) { fprintf(stderr, "usage: emu_aln <index_dir> <reads.fq> <header.sam> [--trace] [--batch N] [--sam FILE --ori-sam FILE]\n"); return 1; }
-	bool trace = false, quiet = false;
+	bool trace = false, quiet = false, sig_n = false, sig_d = false, sig_u = false;
 	long long batch = 1 << 20;
 	int threads = 1;
 	const char *sam_fn = nullptr, *ori_fn = nullptr;
@@ -151,12 +153,25 @@ int main(int argc, char **argv)
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
 		else if (!strcmp(argv[i], "--no-records")) quiet = true;
+		else if (!strcmp(argv[i], "-N")) sig_n = true;
+		else if (!strcmp(argv[i], "-D")) sig_d = true;
+		else if (!strcmp(argv[i], "-U")) sig_u = true;
 		else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoll(argv[++i]);
 		else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--sam") && i + 1 < argc) sam_fn = argv[++i];
 		else if (!strcmp(argv[i], "--ori-sam") && i + 1 < argc) ori_fn = argv[++i];
 		else if (!strcmp(argv[i], "--stream-pos") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &pos[0], &pos[1], &pos[2]);       // start of this shard in the three draw streams
 		else if (!strcmp(argv[i], "--rebase-from") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &from[0], &from[1], &from[2]);  // run there first, then rebase to --stream-pos
+	}
+	const size_t rl = strlen(argv[2]);
+	const bool from_bam = rl > 4 && !strcmp(argv[2] + rl - 4, ".bam");
+	if (from_bam) {                // the header file is WRITTEN from the BAM's header, like the CLI does
+		psvr::BamReader br;
+		if (!br.open(argv[2])) { fprintf(stderr, "%s\n", br.error().c_str()); return 2; }
+		FILE *h = fopen(argv[3], "w");
+		if (!h) return 2;
+		fwrite(br.header_text.data(), 1, br.header_text.size(), h);
+		fclose(h);
 	}
 	HostIndex hi;
 	hi.keep_sparse = true;       // PSVR_EMU_SPARSE_HASH build: no 2 GiB table on the CPU
@@ -169,7 +184,18 @@ int main(int argc, char **argv)
 	EngineCore<CpuBE> core(be);
 	FastqReader rd;
 	FastqBatch fb;
-	if (!rd.open(argv[2])) { fprintf(stderr, "%s\n", rd.error().c_str()); return 2; }
+	// <reads> = *.bam: the signal step in this process, its pairs handed to the batch reader without FASTQ text (PairFeed: what `panSVR aln x.bam` does)
+	psvr::SignalStep sig;
+	psvr::PairFeed feed;
+	std::thread sig_thread;
+	int sig_rc = 0;
+	if (from_bam) {
+		sig.o.sort_by_name = sig_n, sig.o.not_use_filter = sig_d, sig.o.discard_full_match = sig_u;
+		sig.o.input = argv[2], sig.o.header_fn = argv[3], sig.o.status_fn = std::string(argv[3]) + ".status";
+		sig.feed = &feed;
+		sig_thread = std::thread([&]() { sig_rc = sig.run(); feed.close(); });
+		rd.open_feed(&feed);
+	} else if (!rd.open(argv[2])) { fprintf(stderr, "%s\n", rd.error().c_str()); return 2; }
 	HeaderInfo H;
 	HostSvNames svn;
 	svn.h = &hi;
@@ -218,5 +244,8 @@ int main(int argc, char **argv)
 		        core.stats.pairs_run, core.stats.pair_only, core.stats.shadow_runs, core.stats.sensitive, core.stats.window_miss, core.stats.dp_problems, core.stats.cands);
 	}
 	if (fsam) fclose(fsam), fclose(fori);
+	feed.abort();
+	if (sig_thread.joinable()) sig_thread.join();
+	if (sig_rc) { fprintf(stderr, "the signal step failed\n"); return 4; }
 	return 0;
 }

@@ -133,32 +133,44 @@ def test_index_clone_is_an_index():
 
 def test_index_from_device_arrays_is_an_index():
     """psvr_index_create_from_device: the eight arrays already in device memory (as an RCCL broadcast leaves them on the ranks that did
-    not upload: bench.py --gpus N) become an index that aligns like the one created from the host arrays."""
-    import torch
-    import index_fixture
-    from pansvr_amd import aln
-    bases, base_off, ori, stat = _inputs(limit=400)
-    index = _index()
-    a = index_fixture.load_arrays(ac.index_dir("fx2"))
-    dev = torch.device("cuda:0")
-    t = {k: torch.from_numpy(a[k].view(np.int64) if a[k].dtype == np.uint64 else a[k].view(np.int32)).to(dev) for k in ("ref_seq", "seq", "seqf", "pos", "posp", "hash", "kmer", "off")}
-    torch.cuda.synchronize()
-    names = [l.split("SN:")[1].split("\t")[0] for l in synth.header_text().split("\n") if l.startswith("@SQ")]
-    idx2 = aln.Index.from_device_tensors(t, a["chr"], names, device=0)
-    assert idx2.device_bytes == index.device_bytes
-    del t
-    outs = []
-    for ix in (index, idx2):
-        eng = aln.Engine(ix, aln.default_params(stat))
-        eng.upload(bases, base_off, ori)
-        eng.run()
-        outs.append(eng.download())
-        eng.close()
-    lens = np.diff(base_off)
-    P = (len(base_off) - 1) // 2
-    x, y = (ac.engine_records(r, p, c, ori, lens, 0, P) for r, p, c in outs)
-    assert x == y and outs[0][1].tobytes() == outs[1][1].tobytes()
-    idx2.close(), index.close()
+    not upload: bench.py --gpus N) become an index that aligns like the one created from the host arrays.  In a process of its own:
+    torch brings its own HIP runtime and has to initialise the device before the engine library does (the order bench.py keeps)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys
+import numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import aln_common as ac, index_fixture, synth
+import test_abi_gpu as t
+from pansvr_amd import aln
+bases, base_off, ori, stat = t._inputs(limit=400)
+index = t._index()
+a = index_fixture.load_arrays(ac.index_dir("fx2"))
+dev = torch.device("cuda:0")
+tens = {k: torch.from_numpy(a[k].view(np.int64) if a[k].dtype == np.uint64 else a[k].view(np.int32)).to(dev) for k in ("ref_seq", "seq", "seqf", "pos", "posp", "hash", "kmer", "off")}
+torch.cuda.synchronize()
+names = [l.split("SN:")[1].split("\\t")[0] for l in synth.header_text().split("\\n") if l.startswith("@SQ")]
+idx2 = aln.Index.from_device_tensors(tens, a["chr"], names, device=0)
+assert idx2.device_bytes == index.device_bytes
+del tens
+outs = []
+for ix in (index, idx2):
+    eng = aln.Engine(ix, aln.default_params(stat))
+    eng.upload(bases, base_off, ori)
+    eng.run()
+    outs.append(eng.download())
+    eng.close()
+lens = np.diff(base_off)
+P = (len(base_off) - 1) // 2
+x, y = (ac.engine_records(r, p, c, ori, lens, 0, P) for r, p, c in outs)
+assert x == y and outs[0][1].tobytes() == outs[1][1].tobytes()
+print("FROM_DEVICE_OK", P)
+""" % (ac.ROOT, ac.HERE)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"FROM_DEVICE_OK 400" in r.stdout, r.stderr.decode()[-2000:]
 
 
 def test_index_built_in_hbm_from_the_anchor_fasta_aligns_like_the_reference_built_one():

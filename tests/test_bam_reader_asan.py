@@ -17,9 +17,9 @@ EXE = os.path.join(HERE, "asan", "signal_asan")
 @pytest.fixture(scope="module")
 def exe():
     src = os.path.join(HERE, "asan", "signal_asan_main.cpp")
-    deps = [src] + [os.path.join(ts.ROOT, "pansvr_amd", "csrc", f) for f in ("signal_step.h", "bam_reader.h")]
+    deps = [src] + [os.path.join(ts.ROOT, "pansvr_amd", "csrc", f) for f in ("signal_step.h", "bam_reader.h", "fastq_batch.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", EXE, src, "-lz"])
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-DPSVR_NO_ENGINE_LIB", "-o", EXE, src, "-lz", "-lpthread"])
     return EXE
 
 
