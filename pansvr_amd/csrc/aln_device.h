@@ -1310,12 +1310,14 @@ PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr)
 	if (n > 0 && cd[0].align_score < 40) n = 0;
 	for (int i = 0; i < n; ++i) {                                        // a record is loaded, changed and stored as a whole
 		psvr_cand_t x = cd[i];
-		const int sv = x.chr_id;
-		const SvDev &s = c.idx.sv[sv];
-		x.sv_id = sv;
-		x.chr_id = (int32_t)s.chr_id;
-		x.ref_bg += s.st_pos;
-		if (x.ref_bg >= 0x7fffffffu) x.ref_bg = 5;
+		if (x.sv_id < 0) {                                                // (a record that went through here before -- reselect_pair puts such
+			const int sv = x.chr_id;                                      // records into a new list -- has its genome coordinates already)
+			const SvDev &s = c.idx.sv[sv];
+			x.sv_id = sv;
+			x.chr_id = (int32_t)s.chr_id;
+			x.ref_bg += s.st_pos;
+			if (x.ref_bg >= 0x7fffffffu) x.ref_bg = 5;
+		}
 		x.mapq = 0;
 		if (i == 0) {
 			const int32_t d = (int32_t)(x.align_score - (n > 1 ? cd[1].align_score : 0));
@@ -1484,34 +1486,57 @@ PSVR_HD int mark_dirty(const Ctx &c, long long pair, const long long *noff, cons
 	return dirty;
 }
 
-// A pair whose reads hold no N: its draws in front of the pairing stage are the tie draws of sort_output.  At another offset the
-// ties are resolved by other values, which changes the ORDER in which tied chains are taken -- and hardly ever the candidate list that
-// comes out (it is sorted by score and chain index afterwards).  So the selection alone runs again at the new offset; if both reads'
-// lists are what they were, every later stage's result stands and only the pairing has to follow (returns 1), otherwise the pair
-// runs again from the start (returns 2).  `save`: room for one read's previous list.
-PSVR_HD int reselect_pair(const Ctx &c, long long pair, ChainCand *save)
+// A pair whose reads hold no N (or a variant slot, whose N draws are forced): its other draws in front of the pairing stage are the tie
+// draws of sort_output.  At another offset the ties are resolved by other values, which changes the ORDER in which tied chains are taken
+// -- and hardly ever the candidate list that comes out (it is sorted by score and chain index afterwards).  So the selection alone runs
+// again at the new offset.  Returns
+//   1  both reads' lists are what they were: every later stage's result stands, only the pairing has to follow;
+//   3  a list changed, but every chain on it was a candidate before (a chain is named by its last node and strand, and everything
+//      the later stages make of it depends on the chain alone): the read's candidate records are put together from the old ones
+//      and its tail (finalize_read) runs again here; only the pairing has to follow;
+//   2  a list holds a chain that was not evaluated before: the pair goes on from the walk.
+PSVR_HDN inline int reselect_pair(const Ctx &c, long long pair)
 {
-	bool same = true;
+	int result = 1;
 	for (int mate = 0; mate < 2; ++mate) {
 		const long long read = pair * 2 + mate, item = pair * 3 + mate;
 		if (!c.active[read]) continue;
 		const int n_old = c.n_ccand[read];
 		ChainCand *cc = c.ccand + read * 12;
-		for (int i = 0; i < n_old; ++i) save[i] = cc[i];
+		ChainCand save[12];
+		for (int i = 0; i < n_old && i < 12; ++i) save[i] = cc[i];
 		for (int o = 0; o < 2; ++o) {                                     // sort_output marks the chains it has taken
 			const Strand &st = c.strand[read * 2 + o];
 			PathN *pa = c.path + st.us_off;
 			for (uint32_t i = 0; i < st.us_n; ++i) pa[i].used = 0;
 		}
-		c.rcnt[item] = 0;                                                 // no N draws: select_read adds its tie draws
+		c.rcnt[item] = c.force ? (int32_t)c.force[4 * read] : 0;         // the N draws (forced in a variant slot, none in a pair without N); select_read adds its tie draws
 		select_read(c, read);
-		if (c.n_ccand[read] != n_old) same = false;
+		const int n_new = c.n_ccand[read];
+		bool same = n_new == n_old;
 		for (int i = 0; i < n_old && same; ++i) {
 			const ChainCand &a = save[i], &b = cc[i];
 			if (a.chain_score != b.chain_score || a.max_index != b.max_index || a.read_bg != b.read_bg || a.ref_bg != b.ref_bg || a.chr_id != b.chr_id || a.direction != b.direction) same = false;
 		}
+		if (same) continue;
+		if (result == 2) continue;                                        // (the other read's selection has to be repeated all the same)
+		// every chain of the new list among the old candidate records (walk_read wrote n_old of them at rh.cand_off; finalize_read has sorted them since)?
+		psvr_cand_t *cd = c.cand + c.rh[read].cand_off;
+		psvr_cand_t old[12];
+		for (int i = 0; i < n_old && i < 12; ++i) old[i] = cd[i];
+		bool all = n_new <= n_old;
+		int where[12];
+		for (int j = 0; j < n_new && all; ++j) {
+			where[j] = -1;
+			for (int i = 0; i < n_old; ++i) if (old[i].max_index == cc[j].max_index && old[i].direction == (uint8_t)cc[j].direction) where[j] = i;
+			if (where[j] < 0) all = false;
+		}
+		if (!all) { result = 2; continue; }
+		for (int j = 0; j < n_new; ++j) cd[j] = old[where[j]];
+		finalize_read(c, read, c.rh[read]);                               // sort, threshold, mapq again; coordinates stay (sv_id >= 0)
+		result = 3;
 	}
-	return same ? 1 : 2;
+	return result;
 }
 
 // A pair with N bases takes over the records of the variant slot that was evaluated with exactly the residues its draws yield
@@ -1521,12 +1546,21 @@ PSVR_HD int reselect_pair(const Ctx &c, long long pair, ChainCand *save)
 // does not depend on their values (a tie leaves max_score where it is), so worker 0 takes the slot's read records and runs the pairing
 // again where the pair really stands in the stream -- a third of the pairs with N bases, which used to run again from their first stage.
 // Declined (nothing touched) when the slot sampled positions with random_r: that result depends on the other streams' offsets.
-PSVR_HD void adopt_variant(const Ctx &c, long long pair, long long slot, const long long *noff, int part, int parts)
+PSVR_HDN inline void adopt_variant(const Ctx &c, long long pair, long long slot, const long long *noff, int part, int parts)
 {
 	if (c.hcnt[2 * slot] != 0 || c.hcnt[2 * slot + 1] != 0) return;
-	const bool repair = c.rcnt[3 * slot + 2] != 0;
+	const int32_t s0 = c.rcnt[3 * slot], s1 = c.rcnt[3 * slot + 1];
+	const bool ties = c.force && (s0 != (int32_t)c.force[4 * (2 * slot)] || s1 != (int32_t)c.force[4 * (2 * slot + 1)]);   // a read of the slot drew for tied chains too
+	const bool repair = ties || c.rcnt[3 * slot + 2] != 0;
 	if (repair) {
 		if (part != 0) return;
+		if (ties) {
+			// the slot's chain selection again where the pair stands (reselect_pair); adopted only if the candidates stand and the
+			// number of draws is what the host's walk counted on -- otherwise nothing is touched and the pair runs in full
+			c.poff[slot] = noff[pair];
+			const int r = reselect_pair(c, slot);
+			if (r == 2 || c.rcnt[3 * slot] != s0 || c.rcnt[3 * slot + 1] != s1) return;
+		}
 		for (int k = 0; k < 4; ++k) c.strand[4 * pair + k] = c.strand[4 * slot + k];
 		c.rcnt[3 * pair] = c.rcnt[3 * slot], c.rcnt[3 * pair + 1] = c.rcnt[3 * slot + 1];
 		c.hcnt[2 * pair] = c.hcnt[2 * pair + 1] = 0;

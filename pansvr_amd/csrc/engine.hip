@@ -675,14 +675,14 @@ __global__ __launch_bounds__(kBlock) void k_dirty(Ctx c, const long long *noff, 
 }
 // the pairs of the third list (reselect_pair in aln_device.h): one thread each, over a list whose length only the device knows;
 // a pair whose candidate lists stand joins the pairing-only list, another the list of full re-runs
-__global__ __launch_bounds__(64) void k_reselect(Ctx c, const int32_t *list, const unsigned long long *n_list, unsigned long long cap3, ChainCand *save, int32_t *out4,
+__global__ __launch_bounds__(64) void k_reselect(Ctx c, const int32_t *list, const unsigned long long *n_list, unsigned long long cap3, int32_t *out4,
                                                  unsigned long long *cnt4, int32_t *outp, unsigned long long *cntp)
 {
 	const unsigned long long n = *n_list < cap3 ? *n_list : cap3;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
 		const long long p = list[i];
-		if (reselect_pair(c, p, save + i * 12) == 1) outp[atomicAdd(cntp, 1ull)] = (int32_t)p;
-		else out4[atomicAdd(cnt4, 1ull)] = (int32_t)p;                       // new lists: the pair goes on from the walk
+		if (reselect_pair(c, p) != 2) outp[atomicAdd(cntp, 1ull)] = (int32_t)p;   // lists stand, or are made of chains evaluated before: the pairing follows
+		else out4[atomicAdd(cnt4, 1ull)] = (int32_t)p;                       // a chain nobody has walked yet: the pair goes on from the walk
 	}
 }
 __global__ void k_copy_i32(int32_t *dst, long long at, const int32_t *src, long long n)
@@ -1306,11 +1306,11 @@ struct GpuBE {
 		hipLaunchKernelGGL(k_scatter_u8, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, n, v);
 	}
 	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp,
-	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3, int32_t *out4, unsigned long long *cnt4)
+	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, long long cap3, int32_t *out4, unsigned long long *cnt4)
 	{
 		hipLaunchKernelGGL(k_dirty, dim3(grid_for(c.n_pairs, kBlock * kDirtyItems)), dim3(kBlock), 0, stream, c, noff, nhoff, out, cnt, outp, cntp, has_n, out3, cnt3, (unsigned long long)cap3);
 		// the tie-only pairs, resolved on the spot (their number stays on the device: a fixed small grid walks the list)
-		hipLaunchKernelGGL(k_reselect, dim3(64), dim3(64), 0, stream, c, (const int32_t *)out3, (const unsigned long long *)cnt3, (unsigned long long)cap3, save, out4, cnt4, outp, cntp);
+		hipLaunchKernelGGL(k_reselect, dim3(64), dim3(64), 0, stream, c, (const int32_t *)out3, (const unsigned long long *)cnt3, (unsigned long long)cap3, out4, cnt4, outp, cntp);
 		note(hipGetLastError());
 	}
 

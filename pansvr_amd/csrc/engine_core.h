@@ -106,7 +106,7 @@ template <class BE> struct EngineCore {
 	long long cap_S = 0, cap_bases = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
 	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
 	uint8_t *d_hasn = nullptr;                       // per pair: a read of it draws for N bases (its draws are not just chain-selection ties)
-	int32_t *d_resel = nullptr, *d_resel4 = nullptr; ChainCand *d_resel_save = nullptr;   // pairs whose chain selection runs again on its own (reselect_pair); the list they are compared with
+	int32_t *d_resel = nullptr, *d_resel4 = nullptr;   // pairs whose chain selection runs again on its own (reselect_pair); of those, the ones that go on from the walk
 	std::vector<int32_t> h_n_idx;                    // pairs with N draws (built by upload())
 	static const long long kReselCap = 1 << 16;      // tie-only pairs a round can resolve on the spot; beyond that they run in full
 	int32_t *d_cmask = nullptr;                      // totals with the host-resolved pairs masked out
@@ -292,7 +292,7 @@ template <class BE> struct EngineCore {
 		d_ctot = alloc<int32_t>(S), d_src = alloc<int32_t>(S), d_sens = alloc<uint8_t>(P), d_slist = alloc<int32_t>(P);
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
-		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel_save = alloc<ChainCand>(12 * (P < kReselCap ? P : kReselCap)), d_resel4 = alloc<int32_t>(P < kReselCap ? P : kReselCap);
+		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel4 = alloc<int32_t>(P < kReselCap ? P : kReselCap);
 		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
@@ -607,7 +607,10 @@ template <class BE> struct EngineCore {
 						// The two reads of that variant slot drew nothing but the forced residues: their records ARE this pair's at any offset
 						// (adopted below instead of running the pair again where its draws have moved to).  If the slot's pairing stage drew
 						// too, the adoption runs the pairing again at the pair's offset (adopt_variant): again whenever the offset moves.
-						if (vc[0] == sp.n1 && vc[1] == sp.n2 && (adopted[si] != sp.vslot + code || (vc[2] != 0 && adopted_at[si] != t))) {
+						// (a read of the slot that drew for tied chains as well -- vc > n -- is adopted if its selection, repeated at this offset,
+						// leaves the candidates and the counts as they are; the device declines otherwise and the pair runs in full)
+						const bool moves = vc[2] != 0 || vc[0] != sp.n1 || vc[1] != sp.n2;
+						if (vc[0] >= sp.n1 && vc[1] >= sp.n2 && (adopted[si] != sp.vslot + code || (moves && adopted_at[si] != t))) {
 							adopted[si] = sp.vslot + code, adopted_at[si] = t;
 							adopt_pair.push_back(s), adopt_slot.push_back(sp.vslot + code);
 						}
@@ -635,7 +638,7 @@ template <class BE> struct EngineCore {
 			}
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
 			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 16);
-			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, d_resel_save, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
+			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
 			unsigned long long nd17[26];                    // [0] full re-runs, [16] pairing only, [24] tie-only pairs seen, [25] of those: on from the walk
 			int32_t flags[8];
 			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 32);

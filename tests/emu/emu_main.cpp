@@ -89,7 +89,7 @@ struct CpuBE {
 		for (long long i = 0; i < n; ++i) { out[off + i * stride] = acc; acc += cnt[off + i * stride]; }
 	}
 	void st_dirty(const Ctx &c, const long long *noff, const long long *nhoff, int32_t *out, unsigned long long *cnt, int32_t *outp, unsigned long long *cntp,
-	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, ChainCand *save, long long cap3, int32_t *out4, unsigned long long *cnt4)
+	              const uint8_t *has_n, int32_t *out3, unsigned long long *cnt3, long long cap3, int32_t *out4, unsigned long long *cnt4)
 	{
 		for (long long p = 0; p < c.n_pairs; ++p) {
 			int d = mark_dirty(c, p, noff, nhoff, has_n);
@@ -100,7 +100,7 @@ struct CpuBE {
 		}
 		for (unsigned long long i = 0; i < *cnt3; ++i) {
 			const long long p = out3[i];
-			if (reselect_pair(c, p, save + i * 12) == 1) outp[(*cntp)++] = (int32_t)p;
+			if (reselect_pair(c, p) != 2) outp[(*cntp)++] = (int32_t)p;
 			else out4[(*cnt4)++] = (int32_t)p;
 		}
 	}
