@@ -920,8 +920,14 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 	__syncthreads();
 	for (int t = threadIdx.x; t < 512; t += 256) if (lh[t]) atomicAdd(d.hist + t, (unsigned long long)lh[t]);
 	if (threadIdx.x < PSVR_DP_NUM_LDS_CLASSES && lq[threadIdx.x]) atomicMax(d.hist + 1024 + threadIdx.x, (unsigned long long)lq[threadIdx.x]);
+	// (one atomic per workgroup, through LDS: 11 k wavefronts on one address were 0.1 ms of this kernel)
 	for (int o = 32; o; o >>= 1) seq_bytes += __shfl_xor(seq_bytes, o);
-	if ((threadIdx.x & 63) == 0 && seq_bytes) atomicAdd(d.hist + 1041, (unsigned long long)seq_bytes);
+	__syncthreads();                                              // lh is free again
+	if (threadIdx.x == 0) lh[0] = 0;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0 && seq_bytes) atomicAdd(&lh[0], seq_bytes);
+	__syncthreads();
+	if (threadIdx.x == 0 && lh[0]) atomicAdd(d.hist + 1041, (unsigned long long)lh[0]);
 }
 __global__ __launch_bounds__(kBlock) void k_dp_scatter(DpPlanDev d, const long long *bucket_start)
 {

@@ -499,7 +499,8 @@ template <int LANES, int CPL>
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
-	static_assert(CPL == 4 || CPL == 8, "columns per lane: the query window holds 8 nibbles, direction bytes go out as dwords");
+	static_assert(CPL == 4 || CPL == 8 || CPL == 16, "columns per lane: direction bytes go out as dwords, the query window holds 8 (16: two registers) nibbles");
+	using WinT = typename std::conditional<(CPL > 8), unsigned long long, unsigned>::type;   // the query window: one nibble per column of the lane
 	constexpr int SW = CPL * LANES, PB = 64 / LANES;                 // strip width, alignments per wavefront
 	constexpr int kNone = (int)0x80000000;                           // "no cell yet" in the per-diagonal maximum
 	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 			if (0 <= qlen - 2) d_cur = at4(uD, c0);
 		}
 		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? query[0 - jb] : 0u;   // query[k - jb] for k = 0 (raw byte: masking it here would wait for the load)
-		unsigned W = 0;                                               // query window: nibble jj = query[k - jb - jj]
+		WinT W = 0;                                                   // query window: nibble jj = query[k - jb - jj]
 		const int ksteps = qlen + ncols - 1;
 		// one anti-diagonal per iteration, see ksw_team_step.inc
 		const int k_mid = min(SW - 1, ksteps);
