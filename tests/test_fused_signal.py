@@ -96,3 +96,46 @@ def test_bam_input_equals_signal_then_fastq_on_the_gpu():
             got = (open(os.path.join(tmp, tag + ".sam"), "rb").read(), open(os.path.join(tmp, tag + ".ori.sam"), "rb").read())
             assert outs.setdefault(tag, got) == got                  # the pieces a batch is cut into do not show
     assert outs["A"] == outs["B"] and len(outs["A"][0]) > 500000
+
+
+GOLDEN = [("fx1", "reads150", 2000, ["-D"]), ("fx2", "reads150", 1500, ["-D"])]
+
+
+def _golden(name, rname):
+    import gzip
+    out = []
+    for ext in (".sam.gz", ".ori.sam.gz"):
+        with gzip.open(os.path.join(ac.HERE, "golden", "fused", "%s_%s%s" % (name, rname, ext)), "rb") as f:
+            out.append(f.read())
+    return out
+
+
+@pytest.mark.parametrize("name,rname,n_pairs,flags", GOLDEN)
+def test_bam_input_writes_what_the_references_two_steps_write(emu, name, rname, n_pairs, flags):
+    """tests/golden/fused/*: the reference's own `fc_signal` function (oracle/_ref/ref_signal) followed by the reference's own `fc_aln`
+    objects (oracle/_ref/ref_aln -t 1 -S) on the same BAM (tests/golden/gen_fused_golden.py).  The fused route -- BAM in, the signal
+    step in-process, pairs handed over without FASTQ text -- must write both files byte for byte; here on the emulated engine."""
+    tmp = tempfile.mkdtemp(prefix="psvr_fused_")
+    bam = os.path.join(tmp, "in.bam")
+    bam_of(name, rname, n_pairs, bam)
+    r = subprocess.run([emu, ac.index_dir(name), bam, os.path.join(tmp, "h.sam"), "--no-records", "--sam", os.path.join(tmp, "o.sam"), "--ori-sam", os.path.join(tmp, "p.sam"), "-N"] + flags,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    want = _golden(name, rname)
+    assert open(os.path.join(tmp, "o.sam"), "rb").read() == want[0]
+    assert open(os.path.join(tmp, "p.sam"), "rb").read() == want[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rname,n_pairs,flags", GOLDEN)
+def test_gpu_bam_input_writes_what_the_references_two_steps_write(name, rname, n_pairs, flags):
+    """The same on the MI355X through the drop-in command: `panSVR aln -N -D -S ... in.bam header.sam`."""
+    tmp = tempfile.mkdtemp(prefix="psvr_fused_")
+    bam = os.path.join(tmp, "in.bam")
+    bam_of(name, rname, n_pairs, bam)
+    r = subprocess.run([CLI, "aln", "-S", "-N"] + flags + ["-o", os.path.join(tmp, "o.sam"), "-p", os.path.join(tmp, "p.sam"), ac.index_dir(name), bam, os.path.join(tmp, "h.sam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    want = _golden(name, rname)
+    assert open(os.path.join(tmp, "o.sam"), "rb").read() == want[0]
+    assert open(os.path.join(tmp, "p.sam"), "rb").read() == want[1]
