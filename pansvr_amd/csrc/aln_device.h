@@ -99,10 +99,17 @@ template <class T> PSVR_HD long long arena_alloc(const Arena<T> &a, unsigned lon
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (a.nshard > 1) {
-		const unsigned long long s = blockIdx.x % a.nshard, cap_s = a.cap / a.nshard;
-		const unsigned long long o = atomic_bump(a.top + s * kArenaTopStride, n);
-		if (o + n > cap_s) { *a.overflow = 1; return -1; }
-		return (long long)(s * cap_s + o);
+		// region blockIdx % nshard first; a full region (a launch of few workgroups uses few regions: ADVICE r2) sends the request on to the
+		// next ones before the arena counts as full
+		const unsigned long long cap_s = a.cap / a.nshard;
+		for (unsigned int k = 0; k < a.nshard; ++k) {
+			const unsigned long long s = (blockIdx.x + k) % a.nshard;
+			if (k && a.top[s * kArenaTopStride] + n > cap_s) continue;          // (a look before the bump: a full region's counter is left alone)
+			const unsigned long long o = atomic_bump(a.top + s * kArenaTopStride, n);
+			if (o + n <= cap_s) return (long long)(s * cap_s + o);
+		}
+		*a.overflow = 1;
+		return -1;
 	}
 #endif
 	unsigned long long o = atomic_bump(a.top, n);

@@ -1074,10 +1074,15 @@ struct GpuBE {
 	void *up_ring = nullptr;
 	static constexpr size_t kUp = (size_t)8 << 20;
 	size_t up_pos = 0, up_since_sync = 0;
+	hipStream_t up_stream = nullptr;                         // the queue the outstanding slots' copies were put on
 	void h2d(void *d, const void *h, size_t n)
 	{
 		if (n && n <= kUp / 4 && (up_ring || hipHostMalloc(&up_ring, kUp, hipHostMallocDefault) == hipSuccess)) {
 			const size_t need = (n + 255) & ~(size_t)255;
+			// the engine's queue and a caller's stream take turns (psvr_engine_run / _rebase): copies still queued on the other one must
+			// have left their slots before the ring counts on the current stream's synchronisations
+			if (up_since_sync && up_stream != stream) { note(hipStreamSynchronize(up_stream)); up_since_sync = 0; }
+			up_stream = stream;
 			if (up_since_sync + need > kUp / 2) { note(hipStreamSynchronize(stream)); up_since_sync = 0; }
 			if (up_pos + need > kUp) up_pos = 0;
 			memcpy((char *)up_ring + up_pos, h, n);
@@ -1662,6 +1667,12 @@ extern "C" int psvr_index_load(const char *dir, const char *header_sam, int devi
 		const size_t ns = h.sparse_pairs.size() / 2;
 		std::vector<uint32_t> sid(ns), scn(ns);
 		for (size_t i = 0; i < ns; ++i) sid[i] = h.sparse_pairs[2 * i], scn[i] = h.sparse_pairs[2 * i + 1];
+		{   // the device scatters counts[id]: a foreign or damaged file must not reach it
+			unsigned long long tot = 0;
+			bool ok = true;
+			for (size_t i = 0; i < ns && ok; ++i) { ok = sid[i] < (1u << 28) && (i == 0 || sid[i] > sid[i - 1]); tot += scn[i]; }
+			if (!ok || tot != (unsigned long long)h.kmer.size()) { delete ix; return set_error(PSVR_ERR_IO, "unipath_g.hash.sparse: bucket ids must be < 4^14 and ascending, counts must add up to the %zu entries of unipath_g.kmer", h.kmer.size()); }
+		}
 		v.hash = nullptr, v.n_hash = ((uint64_t)1 << 28) + 1;
 		rc = index_upload(ix, &v, sid.data(), scn.data(), (long long)ns);
 		std::vector<uint32_t>().swap(h.sparse_pairs);

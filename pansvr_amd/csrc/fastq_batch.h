@@ -147,6 +147,14 @@ public:
 			gzbuffer(gz_, 1 << 20);
 			return true;
 		}
+		if (!regular) {
+			// stdin, a pipe, a FIFO: the reference's xzopen / gzdopen decodes a gzip stream there too and passes plain text through
+			// (zlib's transparent mode); nothing can be peeked at without consuming it, so zlib gets the descriptor
+			gz_ = gzdopen(fd_, "rb");
+			if (!gz_) { err_ = "gzdopen failed"; return false; }
+			gzbuffer(gz_, 4 << 20);
+			return true;
+		}
 		if (regular && allow_map && st.st_size > 0) {
 			void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
 			if (m != MAP_FAILED) {

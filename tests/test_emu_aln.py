@@ -63,11 +63,11 @@ def test_scratch_arena_growth_reruns_the_batch(emu, shrink):
     assert not bad, "%d/%d pairs differ; first %d" % (len(bad), len(want), bad[0])
 
 
-@pytest.mark.parametrize("variant", ["crlf", "no_final_newline", "tiny_batches", "truncated_pair", "gz", "pipe", "pipe_tiny_batches", "threads"])
+@pytest.mark.parametrize("variant", ["crlf", "no_final_newline", "tiny_batches", "truncated_pair", "gz", "pipe", "pipe_tiny_batches", "gz_pipe", "threads"])
 def test_fastq_reader_edge_cases(emu, variant):
     """fastq_batch.h's batch reader (memory-mapped or streamed text, line index built on threads, nothing copied but the bases) on
     awkward inputs: CR LF line ends, a last line without a newline, batches of 7 pairs, a trailing incomplete pair (ignored, like
-    the reference's read loop), a gzip file, a pipe (stream mode: text carried across batches), several index threads.  The
+    the reference's read loop), a gzip file, a pipe (stream mode: text carried across batches), a gzip stream on a pipe, several index threads.  The
     records must be those of the plain file."""
     w = ac.workdir("fx1")
     text = open(os.path.join(w, "reads150.fq")).read()
@@ -91,14 +91,14 @@ def test_fastq_reader_edge_cases(emu, variant):
             extra = ["--threads", "5", "--batch", "64"]
     path = os.path.join(w, "edge_%s.fq" % variant)
     stdin = None
-    if variant == "gz":
+    if variant in ("gz", "gz_pipe"):
         import gzip
         path += ".gz"
         with gzip.open(path, "wb") as f:
             f.write(data.encode())
     else:
         open(path, "w", newline="").write(data)
-    if variant.startswith("pipe"):
+    if variant.startswith("pipe") or variant == "gz_pipe":                    # (a gzip stream on a pipe is decoded like a gzip file: the reference's xzopen)
         stdin, path = open(path, "rb"), "-"
         stdin = subprocess.Popen(["cat"], stdin=stdin, stdout=subprocess.PIPE).stdout      # a real pipe, not a seekable file
     out = subprocess.run([emu, os.path.join(ac.golden_dir("fx1"), "idx"), path, os.path.join(w, "header.sam"), "--trace"] + extra,
