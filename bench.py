@@ -367,7 +367,7 @@ def main():
             # DP kernels also cells/s against the vector-issue bound.  Bound: profiles/r01j_valu_op_rates.txt prices a wavefront instruction at ~2.3
             # SIMD-cycles (add / sub / logic / right shift / mov) or ~4.2 (max / min / compare / left shift / three-operand / DPP); the cell update of
             # ksw_team_step.inc is 36 vector instructions (14 of the dearer kind) = ~110 cycles per 64 cells and SIMD, i.e. 1024 SIMDs x 2.4 GHz x 64 / 110.
-            groups = {"k_prep": ["k_prep"], "k_seed": ["k_seed"], "k_chain": ["k_chain"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
+            groups = {"k_prep": ["k_prep"], "k_seed": ["k_seed"], "k_chain": ["k_chain", "k_chain_select"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
                       "k_assemble+k_finalize_pair": ["k_assemble", "k_finalize_pair"], "extd2_*": [k for k in kern if k.startswith("extd2_")]}
             issue_bound = 1024 * 2.4e9 * 64 / 110.0
             rows = []

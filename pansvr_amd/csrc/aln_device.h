@@ -193,6 +193,7 @@ struct Ctx {
 	// the reference's per-handler scratch buffer as earlier reads left it ([mate][1600], see stale_compare); stale_open: set when a
 	// compare needed a position this read's own calls had not written
 	const uint8_t *tseq_in; int32_t *stale_open;
+	int32_t *any_h;              // set when a read draws from random_r (expand_seed's sampling)
 	int32_t trace;
 	int32_t *err;                // sticky error word (reference would xassert/abort)
 	unsigned long long *stats;   // [16] work counters
@@ -746,6 +747,7 @@ PSVR_HDN inline void chain_read(const Ctx &c, long long read)
 	chain_strand(c, read * 2, hdraw);
 	chain_strand(c, read * 2 + 1, hdraw);
 	c.hcnt[read] = hdraw;
+	if (hdraw && c.any_h) *c.any_h = 1;                     // somebody sampled positions with random_r: the batch needs that stream's offsets (engine_core.h)
 	if (c.stats) stat_add(c, ST_SEEDS, c.strand[read * 2].us_n + c.strand[read * 2 + 1].us_n);
 }
 

@@ -527,6 +527,18 @@ __global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *list, co
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i < (long long)*cnt) chain_read(c, list[i]);
 }
+// chaining and chain selection of a read by the same thread, one launch: the selection walks what the chaining has just written
+__global__ __launch_bounds__(kBlock) void k_chain_select(Ctx c, const int32_t *list, const unsigned int *cnt)
+{
+	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i < (long long)*cnt) { const long long r = list[i]; chain_read(c, r); select_read(c, r); }
+}
+// the pairing stage over a list whose length only the device knows yet (right behind k_dirty / k_reselect, before the host has read the counts)
+__global__ __launch_bounds__(kBlock) void k_pair_dev(Ctx c, const int32_t *list, const unsigned long long *cnt)
+{
+	const unsigned long long n = *cnt;
+	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) pair_reads(c, list[i]);
+}
 __global__ __launch_bounds__(kBlock) void k_select(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -1142,13 +1154,14 @@ struct GpuBE {
 	void st_chain(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		(void)w, (void)mate;
-		if (n > 0) { t0("k_chain"); hipLaunchKernelGGL(k_chain, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, (const int32_t *)(mem_list.as<int32_t>() + 4), (const unsigned int *)mem_list.p); t1(); }
+		if (n > 0) { t0("k_chain_select"); hipLaunchKernelGGL(k_chain_select, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, (const int32_t *)(mem_list.as<int32_t>() + 4), (const unsigned int *)mem_list.p); t1(); }
 		note(hipGetLastError());
 	}
-	void st_select(const Ctx &c, const int32_t *w, long long n, int mate)
+	void st_select(const Ctx &, const int32_t *, long long, int) {}      // (done by k_chain_select)
+	void st_pair_dev(const Ctx &c, const int32_t *list, const unsigned long long *cnt)
 	{
-		(void)w, (void)mate;
-		if (n > 0) { t0("k_select"); hipLaunchKernelGGL(k_select, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, (const int32_t *)(mem_list.as<int32_t>() + 4), (const unsigned int *)mem_list.p); t1(); }
+		const long long blocks = c.n_pairs / kBlock + 1;
+		hipLaunchKernelGGL(k_pair_dev, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0, stream, c, list, cnt);
 		note(hipGetLastError());
 	}
 	static int str_tsize(const Ctx &c)

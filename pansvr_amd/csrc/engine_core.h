@@ -293,7 +293,7 @@ template <class BE> struct EngineCore {
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
 		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel4 = alloc<int32_t>(P < kReselCap ? P : kReselCap);
-		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(8);
+		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(16);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
 		cap_us = (unsigned long long)R2 * 48 + 65536;
@@ -315,7 +315,7 @@ template <class BE> struct EngineCore {
 		for (void *p : owned) if (!p) { err = "device allocation failed"; return PSVR_ERR_NOMEM; }
 		free_arenas();
 		if (!alloc_arenas()) { err = "device allocation failed (arenas)"; return PSVR_ERR_NOMEM; }
-		c.err = d_flags + 6, c.stale_open = d_flags + 7;
+		c.err = d_flags + 6, c.stale_open = d_flags + 7, c.any_h = d_flags + 8;
 		be.h2d(d_bases, bases + b0, total_bases);
 		be.h2d(d_off, base_off, (R + 1) * 8);
 		be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
@@ -424,8 +424,9 @@ template <class BE> struct EngineCore {
 		}
 		be.st_walk(c, work, nwork + nwalk);
 		unsigned long long tops[kTopStride + 1];                             // from the dp counter to the cw counter
-		int32_t fl[8];
-		be.d2h2(tops, d_atops + 3 * kTopStride, sizeof tops, fl, d_flags, 32);
+		int32_t fl[16];
+		be.d2h2(tops, d_atops + 3 * kTopStride, sizeof tops, fl, d_flags, 64);
+		if (fl[8]) any_h = true;
 		long long dp_end = (long long)tops[0], cw_end = (long long)tops[kTopStride];
 		if (fl[7]) stats.stale_open = 1;
 		// An arena that filled up in the stages so far ends the round here: what follows (assembly, the reads' tails) would walk records
@@ -460,6 +461,7 @@ template <class BE> struct EngineCore {
 	std::vector<long long> adopted_at;                      // ... and the stream offset it was adopted at (a slot whose pairing draws is adopted again when the pair moves)
 	long long dp_done = 0, cw_done = 0;
 	bool have_run = false;
+	bool any_h = false;                               // a read of this batch has drawn from random_r
 
 	int run(int trace, bool want_stats, int depth = 0)
 	{
@@ -468,7 +470,7 @@ template <class BE> struct EngineCore {
 		if (P == 0) return PSVR_OK;
 		unsigned long long *stats_ptr = c.stats;
 		if (!want_stats) c.stats = nullptr;
-		be.dzero(d_tops, 16 * 8), be.dzero(d_atops, 6 * kTopStride * 8), be.dzero(d_flags, 8 * 4), be.dzero(stats_ptr, 16 * 8);
+		be.dzero(d_tops, 16 * 8), be.dzero(d_atops, 6 * kTopStride * 8), be.dzero(d_flags, 16 * 4), be.dzero(stats_ptr, 16 * 8);
 		unsigned long long mem0 = (unsigned long long)4 * S * kMemSlot;   // bump region starts behind the per-strand slots
 		be.h2d(c.mem.top, &mem0, 8);
 		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
@@ -479,7 +481,7 @@ template <class BE> struct EngineCore {
 		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
 		if (V) be.h2d(d_src + P, h_vsrc.data(), V * 4);
 		if (!h_sp_idx.empty()) be.scatter_u8(d_mask, h_sp_idx.data(), (long long)h_sp_idx.size(), 1);
-		dp_done = 0, cw_done = 0;
+		dp_done = 0, cw_done = 0, any_h = false;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
 		adopted.assign(special.size(), -1), adopted_at.assign(special.size(), -1), adopt_pair.clear(), adopt_slot.clear();
 		have_run = true;
@@ -508,7 +510,7 @@ template <class BE> struct EngineCore {
 		long long nfull = resume ? 0 : P + V, npair_only = 0, nshadow = 0, nwalk = 0;
 		const int32_t *work = nullptr;                    // nullptr = identity: round 1 runs every real pair and every variant slot
 		std::vector<int32_t> sh_src; std::vector<long long> sh_off;
-		bool skip_eval = resume;
+		bool skip_eval = resume, pair_done = false;
 		for (;;) {
 			if (!skip_eval) {
 			stats.rounds++;
@@ -516,7 +518,7 @@ template <class BE> struct EngineCore {
 			stats.pair_only += npair_only;
 			// the pairs that only repeat their pairing stage are not among the slots that run in full: a backend with a second queue does
 			// them beside the stage chain
-			const bool beside = npair_only > 0 && be.side_begin();
+			const bool beside = npair_only > 0 && !pair_done && be.side_begin();
 			if (beside) { be.st_pair(c, d_workp, npair_only); be.side_end(); }
 			stats.from_walk += nwalk;
 			rc = run_slots(work, nfull + nshadow, dp_done, cw_done, nwalk);
@@ -528,7 +530,8 @@ template <class BE> struct EngineCore {
 				return grow_and_rerun(fl, trace, want_stats, depth);
 			}
 			if (rc) break;
-			if (npair_only && !beside) be.st_pair(c, d_workp, npair_only);
+			if (npair_only && !beside && !pair_done) be.st_pair(c, d_workp, npair_only);
+			pair_done = false;
 			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
 			be.dzero(d_tops + 8, 16);
 			be.st_totals(c, work, nfull + nshadow + nwalk, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);
@@ -569,8 +572,13 @@ template <class BE> struct EngineCore {
 			// (the kernels go out first: the host builds its lists while they run)
 			be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
 			be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
-			be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);          // (do not depend on the walk below: they run while the host works)
-			be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
+			// random_r offsets: only when a read has sampled at all (expand_seed beyond POS_N_MAX positions) or the streams' start has moved --
+			// otherwise every read stands at the stream's start, where run_init put it, and six scan launches per pass are saved
+			const bool h_scans = any_h || resume;
+			if (h_scans) {
+				be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);          // (do not depend on the walk below: they run while the host works)
+				be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
+			}
 			std::vector<int32_t> &listed = w_listed;
 			listed.clear();
 			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
@@ -638,15 +646,19 @@ template <class BE> struct EngineCore {
 			}
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
 			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 16);
-			be.st_dirty(c, d_noff, d_nhoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
+			be.st_dirty(c, d_noff, h_scans ? d_nhoff : c.hoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
+			// the pairing-only repeats go out at once (the list's length is on the device; the host reads it below for the totals pass)
+			be.st_pair_dev(c, d_workp, d_tops + 48);
+			pair_done = true;
 			unsigned long long nd17[26];                    // [0] full re-runs, [16] pairing only, [24] tie-only pairs seen, [25] of those: on from the walk
-			int32_t flags[8];
-			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 32);
+			int32_t flags[16];
+			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 64);
+			if (flags[8]) any_h = true;
 			const unsigned long long nd[2] = {nd17[0], nd17[16]};
 			if (flags[7]) stats.stale_open = 1;
 			if (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5]) { c.stats = stats_ptr; return grow_and_rerun(flags, trace, want_stats, depth); }
 			if (flags[6] == 2 || flags[6] == 3) {      // a rand table ran out: extend and restart the batch
-				be.dzero(d_flags, 32);
+				be.dzero(d_flags, 64);
 				grand_dev_n = hrand_dev_n = 0;
 				if (!upload_rand(c.grand_n * 4, c.hrand_n * 4)) { err = "rand table allocation failed"; rc = PSVR_ERR_NOMEM; break; }
 				c.stats = stats_ptr;

@@ -105,6 +105,7 @@ struct CpuBE {
 		}
 	}
 	void append_list(int32_t *w, long long at, const int32_t *src, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = src[i]; }
+	void st_pair_dev(const Ctx &c, const int32_t *list, const unsigned long long *cnt) { for (unsigned long long i = 0; i < *cnt; ++i) pair_reads(c, list[i]); }
 	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff) { for (long long i = 0; i < n; ++i) adopt_variant(c, pairs[i], slots[i], noff, 0, 1); }
 	bool side_begin() { return false; }       // one queue
 	void side_end() {}
