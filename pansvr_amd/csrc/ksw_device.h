@@ -69,7 +69,8 @@ struct TeamPlan {
 	// 0: the wavefront bumps DpBatch::ws_top (16 k wavefronts on one counter line: ~12 ns each, the first generation queues up)
 	unsigned long long ws_base[PSVR_DP_NUM_LDS_CLASSES], ws_need[PSVR_DP_NUM_LDS_CLASSES];
 };
-template <int LANES, int CPL> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip
+template <int LANES, int CPL> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip: a row per lane and step
+template <int LANES, int CPL> __global__ void extd2_teamd_kernel(DpBatch B, DpParams P, TeamPlan T);  // the anti-diagonal sweep it replaced (PSVR_TEAM_DIAG=1, for comparison)
 // the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 // lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips

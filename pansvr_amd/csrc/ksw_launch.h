@@ -1,5 +1,6 @@
 // ksw_launch.h -- one place that maps a DP size class to its kernel instantiation
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include "ksw_device.h"
 
@@ -63,7 +64,9 @@ struct TeamLaunch {
 	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
 	{
 		if (!T.n_classes) return;
-		hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		static const bool diag = getenv("PSVR_TEAM_DIAG") && atoi(getenv("PSVR_TEAM_DIAG"));
+		if (diag) hipLaunchKernelGGL((extd2_teamd_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		else hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
 	}
 };
 // the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
