@@ -696,6 +696,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	const int n_strips = (n_strips16 * 16 + SW - 1) / SW;
 	const int qmax = wave_max_i32(qlen > 0 ? qlen : 0);
 	const int ksteps = uni(qmax + LANES - 1);                       // steps of a strip: lane ql does row k - ql in step k
+	const int k_last = uni(-wave_max_i32(live && qlen > 0 ? -qlen : (int)0x80000000)) - 1;   // the shortest live query's last row, in lane 0's count
 	const int R = ksteps, NR = qmax + SW * n_strips + 1;
 	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES, CPL);
 	unsigned long long base = 0;
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		for (int jj = 0; jj < CPL; ++jj) {
 			U[jj] = 8 * ur_of(cb + jj);                                 // u/y/y2 of the first cell of a column (:153-156)
 			V[jj] = 8 * neg_qe, X[jj] = x_init, Y[jj] = y_init, X2[jj] = x2_init, Y2[jj] = y2_init;
-			H[jj] = h_above(cb + jj);
+			H[jj] = 8 * h_above(cb + jj);
 			inr[jj] = jb + jj < ncols;
 			TC[jj] = inr[jj] ? (target[cb + jj] & 7) * 32 : 0;          // row of the score table (codes are 0..4)
 			M[jj] = kNone, G[jj] = frank(cb + jj);
@@ -784,14 +785,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		for (int kv = 0; kv < LANES - 1; ++kv) {
 			const int k = uni(kv);
 #define TEAM_MASKED 1
+#define TEAM_TOPROW 1
 #include "ksw_row_step.inc"
 #undef TEAM_MASKED
+#undef TEAM_TOPROW
 		}
-		for (int kv = LANES - 1; kv < ksteps; ++kv) {
+		{
+			const int k = LANES - 1;                                    // the last lane's row 0
+#define TEAM_MASKED 0
+#define TEAM_TOPROW 1
+#include "ksw_row_step.inc"
+#undef TEAM_MASKED
+#undef TEAM_TOPROW
+		}
+		for (int kv = LANES; kv < ksteps; ++kv) {
 			const int k = uni(kv);
 #define TEAM_MASKED 0
+#define TEAM_TOPROW 0
 #include "ksw_row_step.inc"
 #undef TEAM_MASKED
+#undef TEAM_TOPROW
 		}
 		// what is still on its way through the lanes: anti-diagonals c0 + ksteps and later, none of which an earlier strip wrote
 		if (LANES > 1) {
