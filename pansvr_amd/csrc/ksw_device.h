@@ -42,7 +42,7 @@ struct DpBatch { // device pointers of one batch
 	int32_t p_unit_shift;
 	int32_t lds_per_wave;      // reg kernels: dynamic LDS bytes of one wavefront's problem
 	long long n;               // problems in this launch
-	uint8_t *ws; unsigned long long *ws_top; unsigned long long ws_cap;   // team kernel: per-wavefront scratch, bump-allocated
+	uint8_t *ws; unsigned long long *ws_top; unsigned long long ws_cap;   // team kernel: per-wavefront scratch (TeamPlan::ws_base; ws_top is unused)
 	int *err;                  // set to 20 if that scratch runs out (cannot happen with the planners' bounds; never silent)
 };
 
@@ -65,12 +65,11 @@ struct TeamPlan {
 	int32_t first_block[PSVR_DP_NUM_LDS_CLASSES + 1];
 	int32_t n_strips16[PSVR_DP_NUM_LDS_CLASSES];
 	long long first_slot[PSVR_DP_NUM_LDS_CLASSES], count[PSVR_DP_NUM_LDS_CLASSES];
-	// scratch of class c's wavefront w at ws_base[c] + w * ws_need[c] when ws_need[c] != 0 (the planner knows the class's longest query);
-	// 0: the wavefront bumps DpBatch::ws_top (16 k wavefronts on one counter line: ~12 ns each, the first generation queues up)
+	// scratch of class c's wavefront w at ws_base[c] + w * ws_need[c] (sized by the class's longest query)
 	unsigned long long ws_base[PSVR_DP_NUM_LDS_CLASSES], ws_need[PSVR_DP_NUM_LDS_CLASSES];
 };
-template <int LANES, int CPL> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);   // ksw_kernels.hip: a row per lane and step
-template <int LANES, int CPL> __global__ void extd2_teamd_kernel(DpBatch B, DpParams P, TeamPlan T);  // the anti-diagonal sweep it replaced (PSVR_TEAM_DIAG=1, for comparison)
+template <int LANES, int CPL> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);          // ksw_kernels.hip: the sweep, a row per lane and step
+template <int LANES, int CPL> __global__ void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T);   // z-drop / end rules and traceback, a thread per alignment
 // the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 // lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips

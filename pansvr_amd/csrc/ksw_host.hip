@@ -67,6 +67,7 @@ struct Launch {
 	int kind;           // 1..5: extd2_reg_kernel<kind>; 0: extd2_lds_kernel
 	int lds_bytes;
 	int64_t first, count;   // slice of the index list
+	int qmax;               // team kernel: the longest query of the class
 };
 
 } // namespace psvr
@@ -150,14 +151,13 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 			if (b.empty()) continue;
 			// team kernel: alignments of similar query length share a wavefront (their strips take similar numbers of steps)
 			if (kind_order[ko] == PSVR_DP_KIND_STRIP) std::stable_sort(b.begin(), b.end(), [&](int32_t x, int32_t y) { return qlen[x] > qlen[y]; });
-			Launch L{kind_order[ko], kLdsClasses[cls], (int64_t)idx.size(), (int64_t)b.size()};
-			pl->launches.push_back(L);
-			if (L.kind == PSVR_DP_KIND_STRIP) {      // every wavefront bump-allocates its scratch; bound by the class's longest query
-				int qmax = 0;
-				for (int32_t i : b) qmax = std::max(qmax, qlen[i]);
+			Launch L{kind_order[ko], kLdsClasses[cls], (int64_t)idx.size(), (int64_t)b.size(), 0};
+			if (L.kind == PSVR_DP_KIND_STRIP) {      // a wavefront's scratch slice is sized by the class's longest query
+				for (int32_t i : b) L.qmax = std::max(L.qmax, qlen[i]);
 				const int lanes = dp_team_lanes(cls + 1);
-				pl->ws_bytes += (int64_t)(((uint64_t)b.size() * lanes + 63) / 64 * dp_team_ws_bytes(qmax, cls + 1, lanes));
+				pl->ws_bytes += (int64_t)(((uint64_t)b.size() * lanes + 63) / 64 * dp_team_ws_bytes(L.qmax > 0 ? L.qmax : 1, cls + 1, lanes));
 			}
+			pl->launches.push_back(L);
 			idx.insert(idx.end(), b.begin(), b.end());
 			char buf[160];
 			snprintf(buf, sizeof buf, "%s[lds=%d] x%lld; ", dp_kind_name(L.kind, variant), L.lds_bytes, (long long)L.count);
@@ -210,7 +210,7 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 	PSVR_HIP(hipMemsetAsync(pl->d_wstop.p, 0, 16, stream));
 	TeamLaunch team;
 	for (const Launch &L : pl->launches) {
-		if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds_bytes) + 1, L.first, L.count); continue; }
+		if (L.kind == PSVR_DP_KIND_STRIP) { team.add(dp_class_of(L.lds_bytes) + 1, L.first, L.count, L.qmax); continue; }
 		B.idx = pl->d_idx.as<int32_t>() + L.first;
 		dp_launch_kind(L.kind, pl->variant, (unsigned)L.count, L.lds_bytes, stream, B, pl->P);
 		PSVR_HIP(hipGetLastError());

@@ -475,202 +475,32 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 }
 
 // ------------------------------------------------------------------------------------------
-// lean regime, any size: a TEAM of 4 or 8 lanes per alignment, 4 target columns per lane in registers
+// lean regime, any size: a TEAM of lanes per alignment, a group of target columns per lane in registers
 // ------------------------------------------------------------------------------------------
 // A wavefront per alignment keeps ~40 of 64 lanes busy and pays ~200 instructions of per-diagonal bookkeeping.  Here a
-// wavefront carries 16 (or 8) alignments; each is swept in strips of 16 (32) target columns, every lane of the team holding
-// the state of 4 columns (u,v,x,y,x2,y2,H) in registers with static indices.  A strip is swept anti-diagonal by anti-diagonal
-// exactly like dp_lean_loop sweeps its lanes: a column reads the old v/x/x2/H of the column to its left, so a lane visits
-// its columns from right to left and takes the neighbour lane's last column through one DPP row_shr:1 per value at the
-// start of the step.  What crosses a strip boundary -- v,x,x2,H of the strip's last column on every anti-diagonal -- goes
-// through a per-alignment array E[r] in scratch memory, ping-ponged between strips and read one step ahead.  The
-// per-diagonal results the z-drop / end-score rules need (the maximum with the reference's tie order, H at the band ends)
-// are folded into D[r], D2[r], D3[r] as the strips pass and evaluated in anti-diagonal order afterwards; diagonals past a
-// z-drop are computed but never looked at.  Direction bytes: one dword per lane and step.  Scratch is laid out
-// [index][lane or team] so a wavefront touches consecutive addresses; it bump-allocates it (sized by the longest query among
-// its alignments, which the planner keeps similar by binning on the strip count).  The kernel is bound by vector issue: see
-// the price list in profiles/r01j_valu_op_rates.txt (add/sub/logic/right shift ~2 cycles, max/min/cmp/three-operand/DPP ~4) --
-// which is why the differences are kept x 8 with the candidate's priority in the low bits (below): ~80 vector instructions per
-// step and column, ~1.3 wavefront instructions per cell instead of ~7 for a wavefront per alignment.
-template <int LANES, int CPL>
+// wavefront carries 64 / LANES alignments (32); each is swept in strips of LANES x CPL (16) target columns, every lane of the
+// team holding the state of CPL (8) columns (u,v,x,y,x2,y2,H) in registers with static indices.  A step of the sweep is ONE
+// ROW of the lane's columns, left to right: a cell needs the cell to its left in the same row (just computed, or the
+// neighbour lane's last column through one DPP row_shr:1 per value: that lane is one row ahead) and the cell above (the
+// column's own registers) -- the same data flow as the reference's anti-diagonal sweep, cell for cell, in another order.  A
+// strip of a q-row query takes q + LANES - 1 steps; sweeping anti-diagonals inside the strip took q + 15 (2.44 -> 1.89 ms,
+// profiles/r03e).  What crosses a strip boundary -- v,x,x2 of the strip's last column in every row -- goes through a
+// per-alignment array E[row] in scratch memory, ping-ponged between strips and read one step ahead.  What the z-drop /
+// end-score rules need per ANTI-DIAGONAL -- the maximum with the reference's tie order, H at the band ends -- is collected
+// on the way: a diagonal passes a lane's columns from right to left, one column per row, so its running maximum rides in
+// a register that moves one column left per step (M[], with the diagonal's tail threshold in K[]), hops to the left
+// neighbour through DPP and is folded into D[r] by the team's first lane; D2[r], D3[r] (H in the top row / last column /
+// last row) are stored by the lane that owns the cell.  extd2_team_finish_kernel evaluates the rules in anti-diagonal order
+// afterwards; diagonals past a z-drop are computed but never looked at.  Direction bytes: CPL per lane and step.  Scratch
+// is laid out [index][lane or team] so a wavefront touches consecutive addresses; a wavefront's slice is sized by the
+// longest query of its class (the planners bin on the strip count and order by query length).  The kernel is bound by
+// vector issue: see the price list in profiles/r01j_valu_op_rates.txt (add/sub/logic/right shift ~2 cycles,
+// max/min/cmp/three-operand/DPP ~4) -- which is why the differences are kept x 8 with the candidate's priority in the low
+// bits (below): ~47 vector instructions per cell.
 #ifndef PSVR_TEAM_WAVES
-#define PSVR_TEAM_WAVES 3          /* wavefronts per SIMD the register allocation aims at: 2 lanes x 8 columns needs 166 VGPRs (3 per SIMD); held to 128 it spills and
-                                      runs like 4 x 4 did -- 3.99 / 4.00 / 2.44 ms for 4 x 4, 2 x 8 at four, 2 x 8 at three wavefronts on one box, profiles/r03b */
+#define PSVR_TEAM_WAVES 3          /* wavefronts per SIMD the register allocation aims at: 2 lanes x 8 columns needs 168 VGPRs (3 per SIMD); 1 x 16 at two per
+                                      SIMD runs as fast (1.84 vs 1.88 ms), 2 x 8 at two 2.29 ms, 4 x 4 at five 2.17 ms, 4 x 8 at three 2.54 ms: profiles/r03e */
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_teamd_kernel(DpBatch B, DpParams P, TeamPlan T)
-{
-	static_assert(CPL == 4 || CPL == 8 || CPL == 16, "columns per lane: direction bytes go out as dwords, the query window holds 8 (16: two registers) nibbles");
-	using WinT = typename std::conditional<(CPL > 8), unsigned long long, unsigned>::type;   // the query window: one nibble per column of the lane
-	constexpr int SW = CPL * LANES, PB = 64 / LANES;                 // strip width, alignments per wavefront
-	constexpr int kNone = (int)0x80000000;                           // "no cell yet" in the per-diagonal maximum
-	const int lane = threadIdx.x, team = lane / LANES, ql = lane % LANES;
-	// substitution scores of every (target, query) code pair, scaled and tagged like the other candidates (see below), written by
-	// all 64 lanes before any of them leaves
-	__shared__ int sc_lut[64];
-	{
-		const int tcode = lane >> 3, qcode = lane & 7;
-		sc_lut[lane] = 8 * ((tcode == P.m1 || qcode == P.m1) ? P.sc_N : (tcode == qcode ? P.sc_mch : P.sc_mis)) + 4;
-	}
-	__builtin_amdgcn_wave_barrier();
-	int cls = 0;
-	while (cls + 1 < T.n_classes && (int)blockIdx.x >= T.first_block[cls + 1]) ++cls;
-	const int n_strips16 = T.n_strips16[cls];
-	const long long slot = (long long)((int)blockIdx.x - T.first_block[cls]) * PB + team;
-	const bool live = slot < T.count[cls];
-	int pid = 0, qlen = 0, tlen = 0;
-	if (live) pid = B.idx[T.first_slot[cls] + slot], qlen = B.qlen[pid], tlen = B.tlen[pid];
-	const int n_strips = (n_strips16 * 16 + SW - 1) / SW;
-	const int qmax = wave_max_i32(qlen > 0 ? qlen : 0);
-	const int R = qmax + SW - 1, NR = qmax + SW * n_strips + 1;
-	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES, CPL);
-	unsigned long long base = 0;
-	if (T.ws_need[cls]) base = T.ws_base[cls] + (unsigned long long)((int)blockIdx.x - T.first_block[cls]) * T.ws_need[cls];   // need <= ws_need: the class's longest query bounds this wavefront's
-	else {
-		if (lane == 0) base = atomicAdd(B.ws_top, need);
-		base = (unsigned long long)uni64((long long)base);
-	}
-	psvr_extz_t *out = B.ez + pid;
-	EzAcc ez;
-	ez.reset();
-	const bool bad_shape = qlen <= 0 || tlen <= 0 || (tlen + SW - 1) / SW > n_strips;
-	if (!live) return;
-	if (base + need > B.ws_cap && B.err) *B.err = 20;
-	if (P.skip || bad_shape || base + need > B.ws_cap) { if (ql == 0) write_ez(out, ez, 0); return; }
-	uint8_t *w0 = B.ws + base;
-	const size_t offE = (size_t)(64 * CPL) * n_strips * R;
-	// Every scratch address is a wave-uniform base (scalar registers) plus a constant 32-bit lane offset, so a step spends no
-	// vector instruction on addresses: direction dwords of strip s, step k at [(s * R + k) * 64 + lane]; strip-boundary values
-	// (8 bytes) and the per-diagonal records D, D2, D3 (4 bytes) of diagonal r at [r * PB + team].
-	// (a boundary record is one dword: v, x, x2 are multiples of 8 plus a constant tag and fit int8 once divided, see the step)
-	uint8_t *const uE0 = w0 + offE, *const uE1 = w0 + offE + (size_t)4 * PB * NR;
-	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
-	const unsigned lc = (unsigned)CPL * (unsigned)lane, t4 = 4u * (unsigned)team;
-	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
-	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
-	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
-	const int n_rows = qlen + tlen - 1;
-	// All difference values are kept times 8, and the five candidates of a cell carry their priority in the low three bits
-	// (sc 4, a 3, b 2, a2 1, b2 0: the first of {sc,a,b,a2,b2} that reaches the maximum wins, :176-213), so one max3 pair
-	// yields both z and the direction; x / y / x2 / y2 live with their tag added so that a candidate is a single add.
-	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
-	const int x_init = 8 * neg_qe + 3, y_init = 8 * neg_qe + 2, x2_init = 8 * neg_qe2 + 1, y2_init = 8 * neg_qe2;
-	const int z_cap = 8 * P.sc_mch + 7;                               // (the substitution scores, 8 * sc + 4, sit in sc_lut)
-	const int q_m8 = 8 * P.q - 8, q2_m8 = 8 * P.q2 - 8;               // a - (z - q) > 0  <=>  tagged difference - 8 >= 0
-	const int cx = 8 - 8 * s8(P.q + P.e), cx2 = 8 - 8 * s8(P.q2 + P.e2);
-	const int long_thres = P.long_thres, ur_short = s8(-P.e), ur_at = s8(P.long_diff), ur_long = s8(-P.e2);
-	auto ur_of = [=](int r) { return r == 0 ? neg_qe : r < long_thres ? ur_short : r == long_thres ? ur_at : ur_long; };
-	// H is tracked by vertical steps only, H(i,t) = H(i-1,t) + v(i,t).  The reference takes a horizontal step for the last
-	// in-band cell of a diagonal (:322), which is the same number: both deltas come from one z.  For the top row that needs the
-	// value "above" it: -qe for column 0 (the reference's H[0] = v - qe at r == 0, :351), then the boundary u of every column
-	// added up, since H(0,t) = H(0,t-1) + u(0,t) and v(0,t) - u(0,t) + v(0,t-1) = ur(t).
-	auto h_above = [&](int t) {
-		int h = -P.qe_pre;
-		const int lt = P.long_thres;
-		if (t >= 1) {
-			if (lt >= 1) h += t < lt ? t * s8(-P.e) : (lt - 1) * s8(-P.e) + s8(P.long_diff) + (t - lt) * s8(-P.e2);
-			else h += t * s8(-P.e2);
-		}
-		return h;
-	};
-	const int ns = (tlen + SW - 1) / SW;
-	for (int sv = 0; sv < ns; ++sv) {
-		const int s = uni(sv);                                          // the wavefront's teams sweep their strips in step: scalar registers for what depends on s and k only
-		const int c0 = SW * s;
-		const int ncols = tlen - c0 < SW ? tlen - c0 : SW;
-		const int jl = tlen - 1 - c0;                                   // the last target column, if it is in this strip (else >= SW)
-		const int jb = CPL * ql;                                        // this lane's first column of the strip
-		int U[CPL], V[CPL], X[CPL], Y[CPL], X2[CPL], Y2[CPL], H[CPL], TC[CPL];
-		bool inr[CPL];                                                // column inside the target
-#pragma unroll
-		for (int jj = 0; jj < CPL; ++jj) {
-			U[jj] = 8 * ur_of(c0 + jb + jj);                            // u/y/y2 of the first cell of a column (:153-156)
-			V[jj] = 8 * neg_qe, X[jj] = x_init, Y[jj] = y_init, X2[jj] = x2_init, Y2[jj] = y2_init;
-			H[jj] = h_above(c0 + jb + jj);
-			inr[jj] = jb + jj < ncols;
-			TC[jj] = inr[jj] ? (target[c0 + jb + jj] & 7) * 32 : 0;     // row of the score table (codes are 0..4)
-		}
-		uint8_t *const Ein = (s & 1) ? uE0 : uE1, *const Eout = (s & 1) ? uE1 : uE0;
-		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
-		// loaded one step ahead, so the loads have a whole step to arrive
-		unsigned e_prev = 0;
-		int d_cur = kNone;
-		if (s > 0) {
-			e_prev = (unsigned)at4(Ein, c0 - 1);
-			if (0 <= qlen - 2) d_cur = at4(uD, c0);
-		}
-		unsigned q_cur = (unsigned)(0 - jb) < (unsigned)qlen ? query[0 - jb] : 0u;   // query[k - jb] for k = 0 (raw byte: masking it here would wait for the load)
-		WinT W = 0;                                                   // query window: nibble jj = query[k - jb - jj]
-		const int ksteps = qlen + ncols - 1;
-		// one anti-diagonal per iteration, see ksw_team_step.inc
-		const int k_mid = min(SW - 1, ksteps);
-		for (int kv = 0; kv < k_mid; ++kv) {
-			const int k = uni(kv);
-#define TEAM_MASKED 1
-#include "ksw_team_step.inc"
-#undef TEAM_MASKED
-		}
-		for (int kv = k_mid; kv < ksteps; ++kv) {
-			const int k = uni(kv);
-#define TEAM_MASKED 0
-#include "ksw_team_step.inc"
-#undef TEAM_MASKED
-		}
-	}
-	if (ql != 0) return;
-	__threadfence_block();                                            // the other lanes' D2/D3 stores
-	// the per-diagonal rules, in anti-diagonal order (ksw2_extd2_sse.c:316-351, ksw_apply_zdrop)
-	// (the records are fetched eight diagonals at a time: one lane per alignment walks them, and a load per iteration would cost a
-	// memory round trip each)
-	bool stop = false;
-	for (int r0 = 0; r0 < n_rows && !stop; r0 += 8) {
-		int kd[8], h2[8], h3[8];
-#pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			const int r = min(r0 + u, n_rows - 1);
-			kd[u] = at4(uD, r), h2[u] = at4(uD2, r), h3[u] = at4(uD3, r);   // D3 holds a value only where the last query row meets the diagonal
-		}
-#pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			const int r = r0 + u;
-			if (r >= n_rows || stop) continue;
-			const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r);
-			const int key = kd[u];
-			const int max_H = key >> 16;
-			const int H_en0 = h2[u];
-			const int max_t = H_en0 == max_H ? en0 : st0 + ((0x7fff - (key & 0xffff)) & 4095);
-			if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
-			if (r - st0 == qlen - 1 && h3[u] > ez.mqe) ez.mqe = h3[u], ez.mqe_t = st0;
-			if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) stop = true;
-			else if (r == n_rows - 1) ez.score = H_en0;                      // en0 == tlen - 1 on the last diagonal
-		}
-	}
-	int n_cigar = 0;
-	if (with_cigar) {
-		int i0 = -1, j0 = -1;
-		if (!ez.zdropped && !(P.flag & PSVR_EZ_EXTZ_ONLY)) i0 = tlen - 1, j0 = qlen - 1;
-		else if (!ez.zdropped && (P.flag & PSVR_EZ_EXTZ_ONLY) && ez.mqe + P.end_bonus > ez.max) ez.reach_end = 1, i0 = ez.mqe_t, j0 = qlen - 1;
-		else if (ez.max_t >= 0 && ez.max_q >= 0) i0 = ez.max_t, j0 = ez.max_q;
-		if (i0 >= 0 && j0 >= 0) {
-			const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
-			const uint8_t *pb = w0 + team * SW;                      // the team's SW direction bytes of a step are contiguous
-			uint32_t *stage = (uint32_t *)(w0 + offE) + team;         // <= qlen + tlen ops; the strip-boundary arrays are dead now
-			n_cigar = traceback(i0, j0, qlen, tlen, w,
-				[&](int r, int k) {                                     // k counts from the 16-rounded band start of row r, as in the reference
-					const int t = k + (max(0, r - qlen + 1) & ~15), s = t / SW;
-					const unsigned b = pb[(size_t)(s * R + (r - SW * s)) * (64 * CPL) + (t - SW * s)], n = ~b;
-					// back to the reference's byte: direction in bits 0-2, "gap extended" for a, b, a2, b2 in bits 3-6
-					return (int)((4u - ((b >> 4) & 7u)) | ((n >> 3) & 1u) << 3 | ((n >> 2) & 1u) << 4 | ((n >> 1) & 1u) << 5 | (n & 1u) << 6);
-				},
-				[&](int k, uint32_t word) { stage[(size_t)k * PB] = word; });
-			uint32_t *dst = B.cigar + out->cigar_off;
-			const bool rev = (P.flag & PSVR_EZ_REV_CIGAR) != 0;
-			for (int m = 0; m < n_cigar; ++m) dst[m] = stage[(size_t)(rev ? m : n_cigar - 1 - m) * PB];
-		}
-	}
-	write_ez(out, ez, n_cigar);
-}
-template __global__ void extd2_teamd_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>(DpBatch, DpParams, TeamPlan);
-
 template <int LANES, int CPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
@@ -699,19 +529,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	const int k_last = uni(-wave_max_i32(live && qlen > 0 ? -qlen : (int)0x80000000)) - 1;   // the shortest live query's last row, in lane 0's count
 	const int R = ksteps, NR = qmax + SW * n_strips + 1;
 	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES, CPL);
-	unsigned long long base = 0;
-	if (T.ws_need[cls]) base = T.ws_base[cls] + (unsigned long long)((int)blockIdx.x - T.first_block[cls]) * T.ws_need[cls];   // need <= ws_need: the class's longest query bounds this wavefront's
-	else {
-		if (lane == 0) base = atomicAdd(B.ws_top, need);
-		base = (unsigned long long)uni64((long long)base);
-	}
-	psvr_extz_t *out = B.ez + pid;
-	EzAcc ez;
-	ez.reset();
+	const unsigned long long base = T.ws_base[cls] + (unsigned long long)((int)blockIdx.x - T.first_block[cls]) * T.ws_need[cls];   // need <= ws_need: the class's longest query bounds this wavefront's
 	const bool bad_shape = qlen <= 0 || tlen <= 0 || (tlen + SW - 1) / SW > n_strips;
 	if (!live) return;
 	if (base + need > B.ws_cap && B.err) *B.err = 20;
-	if (P.skip || bad_shape || base + need > B.ws_cap) { if (ql == 0) write_ez(out, ez, 0); return; }
+	if (P.skip || bad_shape || base + need > B.ws_cap) return;      // (extd2_team_finish_kernel writes the empty record)
 	uint8_t *w0 = B.ws + base;
 	const size_t offE = (size_t)(64 * CPL) * n_strips * R;
 	// Every scratch address is a wave-uniform base (scalar registers) plus a constant 32-bit lane offset, so a step spends no
@@ -724,7 +546,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
 	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
-	const int n_rows = qlen + tlen - 1;
 	// All difference values are kept times 8, and the five candidates of a cell carry their priority in the low three bits
 	// (sc 4, a 3, b 2, a2 1, b2 0: the first of {sc,a,b,a2,b2} that reaches the maximum wins, :176-213), so one max3 pair
 	// yields both z and the direction; x / y / x2 / y2 live with their tag added so that a candidate is a single add.
@@ -776,6 +597,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
 		// loaded one step ahead, so the loads have a whole step to arrive
 		unsigned e_prev = 0;
+		unsigned dirw[CPL / 4];                                       // the direction bytes of the step before
 		int d_cur = kNone, out_prev = kNone;
 		if (s > 0) {
 			e_prev = (unsigned)at4(Ein, 0);
@@ -806,6 +628,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 #undef TEAM_MASKED
 #undef TEAM_TOPROW
 		}
+		if (with_cigar) {
+			uint32_t *const dst = (uint32_t *)(w0 + (size_t)(s * R + ksteps - 1) * (64 * CPL) + lc);
+#pragma unroll
+			for (int g = 0; g < CPL / 4; ++g) dst[g] = dirw[g];
+		}
 		// what is still on its way through the lanes: anti-diagonals c0 + ksteps and later, none of which an earlier strip wrote
 		if (LANES > 1) {
 			const int inc = __builtin_amdgcn_update_dpp(kNone, out_prev, 0x101, 0xf, 0xf, false);
@@ -818,8 +645,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 			if (jj > 0 || ql == 0) at4(uD, ksteps - ql + cb + jj) = M[jj];
 		__threadfence_block();                                          // the next strip's first lane reads what any lane stored here
 	}
-	if (ql != 0) return;
-	__threadfence_block();                                            // the other lanes' D2/D3 stores
+}
+
+// The per-diagonal rules and the traceback of the alignments extd2_team_kernel swept: one THREAD per alignment.  Both are chains of
+// dependent loads (a record per anti-diagonal, a direction byte per CIGAR step); inside the sweep kernel, one lane per team at three
+// wavefronts per SIMD, they took 0.39 of 2.21 ms on the DP micro-benchmark (profiles/r03e).  Thread t of block b serves team t % PB of the sweep's
+// block (b * 64 + t) / PB and finds that wavefront's scratch the way it did.
+template <int LANES, int CPL>
+__global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T)
+{
+	constexpr int SW = CPL * LANES, PB = 64 / LANES, kWinRows = 8;
+	__shared__ uint32_t win[kWinRows * (CPL / 4) * 64];              // the traceback's window of direction bytes: [row][dword][thread]
+	const int lane = threadIdx.x, team = lane % PB;
+	const int tb = (int)((blockIdx.x * 64u + (unsigned)lane) / (unsigned)PB);   // the sweep's block
+	const bool in_grid = tb < T.first_block[T.n_classes];
+	int cls = 0;
+	while (cls + 1 < T.n_classes && tb >= T.first_block[cls + 1]) ++cls;
+	const int n_strips16 = T.n_strips16[cls];
+	const long long slot = (long long)(tb - T.first_block[cls]) * PB + team;
+	const bool live = in_grid && slot < T.count[cls];
+	int pid = 0, qlen = 0, tlen = 0;
+	if (live) pid = B.idx[T.first_slot[cls] + slot], qlen = B.qlen[pid], tlen = B.tlen[pid];
+	const int n_strips = (n_strips16 * 16 + SW - 1) / SW;
+	int qmax = qlen > 0 ? qlen : 0;                                  // the longest query of the sweep's wavefront: over the PB threads that serve it
+#pragma unroll
+	for (int d = 1; d < PB; d <<= 1) qmax = max(qmax, __shfl_xor(qmax, d, 64));
+	const int ksteps = qmax + LANES - 1;
+	const int R = ksteps, NR = qmax + SW * n_strips + 1;
+	const unsigned long long need = dp_team_ws_bytes(qmax, n_strips16, LANES, CPL);
+	const unsigned long long base = T.ws_base[cls] + (unsigned long long)(tb - T.first_block[cls]) * T.ws_need[cls];
+	if (!live) return;
+	psvr_extz_t *out = B.ez + pid;
+	EzAcc ez;
+	ez.reset();
+	const bool bad_shape = qlen <= 0 || tlen <= 0 || (tlen + SW - 1) / SW > n_strips;
+	if (P.skip || bad_shape || base + need > B.ws_cap) { write_ez(out, ez, 0); return; }
+	uint8_t *w0 = B.ws + base;
+	const size_t offE = (size_t)(64 * CPL) * n_strips * R;
+	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
+	const unsigned t4 = 4u * (unsigned)team;
+	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
+	const int n_rows = qlen + tlen - 1;
 	// the per-diagonal rules, in anti-diagonal order (ksw2_extd2_sse.c:316-351, ksw_apply_zdrop)
 	// (the records are fetched eight diagonals at a time: one lane per alignment walks them, and a load per iteration would cost a
 	// memory round trip each)
@@ -856,11 +723,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 			const int w = P.w < 0 ? (tlen > qlen ? tlen : qlen) : P.w;
 			const uint8_t *pb = w0 + team * SW;                      // the team's SW direction bytes of a step are contiguous
 			uint32_t *stage = (uint32_t *)(w0 + offE) + team;         // <= qlen + tlen ops; the strip-boundary arrays are dead now
+			// A byte per CIGAR step, each address known only when the byte before it has arrived, is a chain of memory round trips.  The
+			// path moves up and to the left by at most one cell a step, so a window of kWinRows rows of the column group it is in (one lane's
+			// CPL bytes of kWinRows consecutive steps: independent loads, in flight together) serves about eight steps; it is kept in LDS.
+			int win_row = -1, win_grp = -1;                          // the window's bottom row and column group (t / CPL)
 			n_cigar = traceback(i0, j0, qlen, tlen, w,
 				[&](int r, int k) {                                     // k counts from the 16-rounded band start of row r, as in the reference
-					const int t = k + (max(0, r - qlen + 1) & ~15), s = t / SW;
-					const int x = t - SW * s;                              // column in the strip: lane x / CPL did row r - t in step r - t + x / CPL
-					const unsigned b = pb[(size_t)(s * R + (r - t + x / CPL)) * (64 * CPL) + x], n = ~b;
+					const int t = k + (max(0, r - qlen + 1) & ~15), row = r - t, grp = t / CPL;
+					if (grp != win_grp || row > win_row || row <= win_row - kWinRows) {
+						const int s = grp / LANES, gl = grp % LANES;          // strip, lane of the team: it did row `row` in step row + gl
+						const uint8_t *src = pb + (size_t)(s * R + row + gl) * (64 * CPL) + gl * CPL;
+						uint32_t tmp[kWinRows][CPL / 4];
+#pragma unroll
+						for (int d = 0; d < kWinRows; ++d)
+#pragma unroll
+							for (int u = 0; u < CPL / 4; ++u) tmp[d][u] = d <= row ? ((const uint32_t *)(src - (size_t)d * (64 * CPL)))[u] : 0u;
+#pragma unroll
+						for (int d = 0; d < kWinRows; ++d)
+#pragma unroll
+							for (int u = 0; u < CPL / 4; ++u) win[(d * (CPL / 4) + u) * 64 + lane] = tmp[d][u];
+						win_row = row, win_grp = grp;
+					}
+					const int x = t % CPL;
+					const unsigned b = (win[((win_row - row) * (CPL / 4) + (x >> 2)) * 64 + lane] >> (8 * (x & 3))) & 0xffu, n = ~b;
 					// back to the reference's byte: direction in bits 0-2, "gap extended" for a, b, a2, b2 in bits 3-6
 					return (int)((4u - ((b >> 4) & 7u)) | ((n >> 3) & 1u) << 3 | ((n >> 2) & 1u) << 4 | ((n >> 1) & 1u) << 5 | (n & 1u) << 6);
 				},
@@ -873,6 +758,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	write_ez(out, ez, n_cigar);
 }
 template __global__ void extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>(DpBatch, DpParams, TeamPlan);
 
 // ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image

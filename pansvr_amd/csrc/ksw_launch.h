@@ -1,6 +1,5 @@
 // ksw_launch.h -- one place that maps a DP size class to its kernel instantiation
 #pragma once
-#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include "ksw_device.h"
 
@@ -44,29 +43,30 @@ inline void dp_launch_kind(int kind, int variant, unsigned count, int lds, hipSt
 	}
 }
 
-// the team kernel: every class in one launch (largest classes first, their wavefronts run longest)
+// the team kernel: every class in one launch (largest classes first, their wavefronts run longest), then the launch that turns what
+// the sweep left in scratch into ksw_extz_t records and CIGARs
 struct TeamLaunch {
 	TeamPlan T;
 	TeamLaunch() { T.n_classes = 0; T.first_block[0] = 0; }
 	unsigned long long ws_next = 0;
-	// qmax: the longest query of the class if the caller knows it (scratch offsets are then computed, not bumped), else 0
-	void add(int n_strips16, long long first_slot, long long count, int qmax = 0)
+	// qmax: the longest query of the class (a wavefront's scratch slice is sized by it)
+	void add(int n_strips16, long long first_slot, long long count, int qmax)
 	{
 		const int c = T.n_classes++;
 		T.n_strips16[c] = n_strips16, T.first_slot[c] = first_slot, T.count[c] = count;
 		const int lanes = dp_team_lanes(n_strips16), pb = 64 / lanes;
 		const int blocks = (int)((count + pb - 1) / pb);
 		T.first_block[c + 1] = T.first_block[c] + blocks;
-		T.ws_need[c] = qmax > 0 ? dp_team_ws_bytes(qmax, n_strips16, lanes) : 0;
+		T.ws_need[c] = dp_team_ws_bytes(qmax > 0 ? qmax : 1, n_strips16, lanes);
 		T.ws_base[c] = ws_next;
 		ws_next += T.ws_need[c] * (unsigned long long)blocks;
 	}
 	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
 	{
 		if (!T.n_classes) return;
-		static const bool diag = getenv("PSVR_TEAM_DIAG") && atoi(getenv("PSVR_TEAM_DIAG"));
-		if (diag) hipLaunchKernelGGL((extd2_teamd_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
-		else hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		const unsigned blocks = (unsigned)T.first_block[T.n_classes], pb = 64u / PSVR_DP_TEAM_LANES;
+		hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3(blocks), dim3(64), 0, stream, B, P, T);
+		hipLaunchKernelGGL((extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((blocks * pb + 63u) / 64u), dim3(64), 0, stream, B, P, T);
 	}
 };
 // the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
