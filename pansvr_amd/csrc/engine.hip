@@ -1440,9 +1440,20 @@ struct GpuBE {
 		// The launches of a round work on disjoint problems, and all but the team kernel's are short of wavefronts (the thread-per-alignment
 		// kernel: a few hundred that run for ~0.1 ms each): they are dealt to side streams and run beside each other and beside the team
 		// kernel.  Not while kernels are being timed.
+		// The team kernel's sweep fills every SIMD's registers (three wavefronts of 168 VGPRs), so the others start when it is through and run
+		// beside its second launch, a thread per alignment chasing records and direction bytes through memory with the SIMDs idle (beside
+		// the sweep they took 1.1 ms for 0.3 ms of work and cost it 0.09 ms; the phase as a whole is the same 1.93 ms either way).
 		const bool fan = !timing && n_other + (team.T.n_classes ? 1 : 0) > 1 && side_streams();
 		int used = 0;
 		bool side2_forked = false;
+		B.idx = plan_idx.as<int32_t>();
+		if (team.T.n_classes) {
+			t0("extd2_team_kernel");
+			team.launch_sweep(stream, B, dpP);
+			if (!fan) team.launch_finish(stream, B, dpP);
+			t1();
+			PSVR_HIP(hipGetLastError());
+		}
 		if (fan) PSVR_HIP(hipEventRecord(ev_fork, stream));
 		for (const Launch3 &L : ls) {
 			if (L.kind == PSVR_DP_KIND_STRIP) continue;
@@ -1473,7 +1484,7 @@ struct GpuBE {
 		if (!team.T.n_classes && used > 2) used = side2_forked ? 3 : 2;   // (the side streams that were used)
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipEventRecord(ev_join[k], side[k]));
 		B.idx = plan_idx.as<int32_t>();
-		if (team.T.n_classes) { t0("extd2_team_kernel"); team.launch(stream, B, dpP); t1(); PSVR_HIP(hipGetLastError()); }
+		if (team.T.n_classes && fan) { team.launch_finish(stream, B, dpP); PSVR_HIP(hipGetLastError()); }
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipStreamWaitEvent(stream, ev_join[k], 0));
 		return PSVR_OK;
 	}

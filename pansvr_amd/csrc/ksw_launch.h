@@ -61,13 +61,18 @@ struct TeamLaunch {
 		T.ws_base[c] = ws_next;
 		ws_next += T.ws_need[c] * (unsigned long long)blocks;
 	}
-	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const
+	void launch_sweep(hipStream_t stream, const DpBatch &B, const DpParams &P) const
+	{
+		if (!T.n_classes) return;
+		hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+	}
+	void launch_finish(hipStream_t stream, const DpBatch &B, const DpParams &P) const
 	{
 		if (!T.n_classes) return;
 		const unsigned blocks = (unsigned)T.first_block[T.n_classes], pb = 64u / PSVR_DP_TEAM_LANES;
-		hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3(blocks), dim3(64), 0, stream, B, P, T);
 		hipLaunchKernelGGL((extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((blocks * pb + 63u) / 64u), dim3(64), 0, stream, B, P, T);
 	}
+	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const { launch_sweep(stream, B, P), launch_finish(stream, B, P); }
 };
 // the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
 inline int dp_class_of(int lds)
