@@ -808,11 +808,21 @@ __global__ void k_totals(Ctx c, const int32_t *work, long long n, int32_t *ctot,
 }
 
 // exclusive scan of int32 counts into int64 offsets, three small launches: per-tile sums, scan of the tile sums
-// (one workgroup), per-tile exclusive scan + tile base
+// (one workgroup), per-tile exclusive scan + tile base.  Up to three arrays of one length go through the same three launches
+// (blockIdx.y picks the array): the DP planning scans three, and a launch is ~5 us whatever it does.
 static const int kScanTile = 2048;      // elements per 256-thread workgroup
-__global__ __launch_bounds__(256) void k_scan_sums(const int32_t *cnt, long long n, int stride, int off, long long *tile_sum)
+struct ScanSet {
+	const int32_t *cnt[3];
+	long long *out[3];
+	int stride[3], off[3];
+	long long base[3];
+};
+__global__ __launch_bounds__(256) void k_scan_sums(ScanSet S, long long n, long long *tile_sum)
 {
 	__shared__ long long red[256];
+	const int y = blockIdx.y;
+	const int32_t *cnt = S.cnt[y];
+	const int stride = S.stride[y], off = S.off[y];
 	const long long base = blockIdx.x * (long long)kScanTile;
 	long long s = 0;
 	for (int k = 0; k < kScanTile / 256; ++k) {
@@ -822,14 +832,15 @@ __global__ __launch_bounds__(256) void k_scan_sums(const int32_t *cnt, long long
 	red[threadIdx.x] = s;
 	__syncthreads();
 	for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
-	if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
+	if (threadIdx.x == 0) tile_sum[(long long)y * gridDim.x + blockIdx.x] = red[0];
 }
-__global__ __launch_bounds__(1024) void k_scan_tiles(long long *tile_sum, long long ntile, long long base)
+__global__ __launch_bounds__(1024) void k_scan_tiles(long long *tile_sum_all, long long ntile, ScanSet S)
 {
 	__shared__ long long part[1024];
 	__shared__ long long carry;
 	const int tid = threadIdx.x;
-	if (tid == 0) carry = base;
+	long long *tile_sum = tile_sum_all + (long long)blockIdx.x * ntile;
+	if (tid == 0) carry = S.base[blockIdx.x];
 	__syncthreads();
 	for (long long t0 = 0; t0 < ntile; t0 += 1024) {
 		long long i = t0 + tid;
@@ -848,9 +859,13 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(long long *tile_sum, long l
 		__syncthreads();
 	}
 }
-__global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, long long n, int stride, int off, const long long *tile_base, long long *out)
+__global__ __launch_bounds__(256) void k_scan_apply(ScanSet S, long long n, const long long *tile_base)
 {
 	__shared__ long long part[256];
+	const int y = blockIdx.y;
+	const int32_t *cnt = S.cnt[y];
+	long long *out = S.out[y];
+	const int stride = S.stride[y], off = S.off[y];
 	const long long base = blockIdx.x * (long long)kScanTile;
 	const int per = kScanTile / 256;
 	long long v[per], s = 0;
@@ -867,7 +882,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t *cnt, long lon
 		part[threadIdx.x] += t;
 		__syncthreads();
 	}
-	long long run = tile_base[blockIdx.x] + part[threadIdx.x] - s;
+	long long run = tile_base[(long long)y * gridDim.x + blockIdx.x] + part[threadIdx.x] - s;
 	for (int k = 0; k < per; ++k) {
 		long long i = base + (long long)threadIdx.x * per + k;
 		if (i < n) out[off + i * stride] = run;
@@ -1307,16 +1322,37 @@ struct GpuBE {
 		note(hipGetLastError());
 	}
 	DevBuf scan_tmp;
+	void st_scan_set(const ScanSet &S, int n_sets, long long n)
+	{
+		if (n <= 0 || n_sets <= 0) return;
+		const long long ntile = (n + kScanTile - 1) / kScanTile;
+		note(scan_tmp.ensure((3 * ntile + 1) * 8));
+		long long *ts = scan_tmp.as<long long>();
+		hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)ntile, (unsigned)n_sets), dim3(256), 0, stream, S, n, ts);
+		hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)n_sets), dim3(1024), 0, stream, ts, ntile, S);
+		hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntile, (unsigned)n_sets), dim3(256), 0, stream, S, n, (const long long *)ts);
+		note(hipGetLastError());
+	}
 	void st_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
 	{
-		if (n <= 0) return;
-		const long long ntile = (n + kScanTile - 1) / kScanTile;
-		note(scan_tmp.ensure((ntile + 1) * 8));
-		long long *ts = scan_tmp.as<long long>();
-		hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)ntile), dim3(256), 0, stream, cnt, n, stride, off, ts);
-		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, ts, ntile, base);
-		hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntile), dim3(256), 0, stream, cnt, n, stride, off, (const long long *)ts, out);
-		note(hipGetLastError());
+		ScanSet S = {};
+		S.cnt[0] = cnt, S.out[0] = out, S.stride[0] = stride, S.off[0] = off, S.base[0] = base;
+		st_scan_set(S, 1, n);
+	}
+	// the same scan over two / three arrays of one length, in the same three launches
+	void st_scan2(const int32_t *c0, int stride0, int off0, long long base0, long long *o0, const int32_t *c1, int stride1, int off1, long long base1, long long *o1, long long n)
+	{
+		ScanSet S = {};
+		S.cnt[0] = c0, S.out[0] = o0, S.stride[0] = stride0, S.off[0] = off0, S.base[0] = base0;
+		S.cnt[1] = c1, S.out[1] = o1, S.stride[1] = stride1, S.off[1] = off1, S.base[1] = base1;
+		st_scan_set(S, 2, n);
+	}
+	void st_scan3(const int32_t *c0, long long *o0, const int32_t *c1, long long *o1, const int32_t *c2, long long *o2, long long n)
+	{
+		ScanSet S = {};
+		S.cnt[0] = c0, S.out[0] = o0, S.cnt[1] = c1, S.out[1] = o1, S.cnt[2] = c2, S.out[2] = o2;
+		for (int k = 0; k < 3; ++k) S.stride[k] = 1;
+		st_scan_set(S, 3, n);
 	}
 	void st_mask_totals(const int32_t *ctot, const uint8_t *mask, long long n, int32_t *out)
 	{
@@ -1370,9 +1406,7 @@ struct GpuBE {
 		// a round with few problems (the re-runs after the first) cannot fill the chip at 16 alignments per wavefront: its time would be one
 		// wavefront's strips x (qlen + 15) steps; a wavefront per alignment needs qlen + tlen steps
 		hipLaunchKernelGGL(k_dp_lens, dim3(grid_for(n)), dim3(kBlock), 0, stream, pd, 200, dp_tiny_ok(dpP, true) ? 1 : 0, n >= kTeamMinProblems ? 1 : 0);
-		st_scan((const int32_t *)pd.qpad, n + 1, 1, 0, 0ll, d.q_off);
-		st_scan((const int32_t *)pd.tpad, n + 1, 1, 0, 0ll, d.t_off);
-		st_scan((const int32_t *)pd.plen, n + 1, 1, 0, 0ll, pd.p_off);
+		st_scan3((const int32_t *)pd.qpad, d.q_off, (const int32_t *)pd.tpad, d.t_off, (const int32_t *)pd.plen, pd.p_off, n + 1);
 		PSVR_HIP(hipGetLastError());
 		unsigned long long hist[512], qmax[18];                // qmax[17]: query + target bytes of the round's problems
 		long long tot[3];

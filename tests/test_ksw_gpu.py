@@ -75,6 +75,36 @@ def test_gpu_tiny_problems_match_oracle():
     assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(cases), bad[:3])
 
 
+def test_gpu_team_kernel_edge_shapes_match_oracle():
+    """The team kernel (extd2_team_kernel + extd2_team_finish_kernel: strips of 16 target columns, two lanes of eight columns, a row per
+    step) at the shapes where its bookkeeping has corners: queries shorter than the lanes' stagger, a last strip of 1, 7, 8, 9 or 16
+    columns, the largest target the band of these cases lets it take (201; 207 goes to the wavefront kernels), targets of a single partial strip under long queries; with N bases, the flags it
+    implements and z-drop values that stop the rules early.  (qlen, tlen <= 16 is the thread-per-alignment kernel's, tested above.)"""
+    rng = np.random.RandomState(9091)
+    shapes = [(ql, tl) for ql in (1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64) for tl in (17, 18, 23, 24, 25, 31, 32, 33, 40, 47, 48, 49, 96, 193, 200, 201, 207)]
+    shapes += [(ql, tl) for ql in range(17, 41) for tl in (1, 2, 7, 8, 9, 15, 16)]
+    shapes += [(ql, tl) for ql in (190, 199, 200) for tl in (1, 16, 17, 32, 33, 150, 201)]
+    cases = []
+    for rep in range(3):
+        for ql, tl in shapes:
+            q = rand_seq(rng, ql)
+            t = (list(q[:min(ql, tl)]) + rand_seq(rng, tl))[:tl] if rng.randint(3) else rand_seq(rng, tl)
+            t = [int(x) for x in t]
+            for _ in range(rng.randint(4)):
+                t[rng.randint(tl)] = int(rng.randint(5))               # substitutions, some to N (4)
+            if rng.randint(8) == 0:
+                q[rng.randint(ql)] = 4
+            flag = int(rng.choice([0, 0, 0, 0x40, 0x80, 0xC0, 0x01, 0x41]))
+            cases.append(case(q, t, flag=flag, zdrop=int(rng.choice([400, 400, 30, 10, 3])), end_bonus=int(rng.choice([-1, 0, 5]))))
+    got = run_gpu(cases, "extd2")
+    bad = []
+    for i, (c, g) in enumerate(zip(cases, got)):
+        want = run_oracle(c, "extd2")
+        if g != want:
+            bad.append((i, c["flag"], c["zdrop"], len(c["query"]), len(c["target"]), diff(want, g)))
+    assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(cases), bad[:3])
+
+
 def test_gpu_random_scoring_and_bands_match_oracle():
     """Scoring parameters and band widths other than the path's (the CLI exposes -M -m -O -E -P -F -z): every kernel family gets
     exercised -- small bands clip the matrix (wavefront kernels with the SSE artefacts), large penalties leave the int8-safe
