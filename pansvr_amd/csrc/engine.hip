@@ -795,6 +795,20 @@ __global__ void k_hoff_shadows(Ctx c, long long P, long long n)
 }
 // total draws of the evaluated slots; a real pair whose total changed since its previous evaluation is count-sensitive
 // cnt[1] is set when a slot's rand() or random_r draw counts differ from its previous evaluation's
+__device__ __forceinline__ void totals_of(const Ctx &c, long long s, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, int detect)
+{
+	int32_t t = c.rcnt[3 * s] + c.rcnt[3 * s + 1] + c.rcnt[3 * s + 2];
+	const int32_t h0 = c.hcnt[2 * s], h1 = c.hcnt[2 * s + 1];
+	if (t != ctot[s] || h0 != hprev[2 * s] || h1 != hprev[2 * s + 1]) cnt[1] = 1;
+	if (detect && s < c.n_pairs && t != ctot[s] && !sens[s]) { sens[s] = 1; slist[atomicAdd(cnt, 1ull)] = (int32_t)s; }
+	ctot[s] = t, hprev[2 * s] = h0, hprev[2 * s + 1] = h1;
+}
+// the same over a list whose length only the device knows yet
+__global__ void k_totals_dev(Ctx c, const int32_t *list, const unsigned long long *n_dev, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt)
+{
+	const unsigned long long n = *n_dev;
+	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) totals_of(c, list[i], ctot, hprev, sens, slist, cnt, 1);
+}
 __global__ void k_totals(Ctx c, const int32_t *work, long long n, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, int detect)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -1136,6 +1150,21 @@ struct GpuBE {
 		}
 		d2h(h1, d1, n1), d2h(h2, d2, n2);
 	}
+	// four small readbacks with one synchronisation
+	void d2h4(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, void *h3, const void *d3, size_t n3, void *h4, const void *d4, size_t n4)
+	{
+		if (n1 + n2 + n3 + n4 <= kPinUse && pinned()) {
+			char *p = (char *)pin;
+			note(hipMemcpyAsync(p, d1, n1, hipMemcpyDeviceToHost, stream));
+			note(hipMemcpyAsync(p + n1, d2, n2, hipMemcpyDeviceToHost, stream));
+			note(hipMemcpyAsync(p + n1 + n2, d3, n3, hipMemcpyDeviceToHost, stream));
+			note(hipMemcpyAsync(p + n1 + n2 + n3, d4, n4, hipMemcpyDeviceToHost, stream));
+			note(hipStreamSynchronize(stream));
+			memcpy(h1, p, n1), memcpy(h2, p + n1, n2), memcpy(h3, p + n1 + n2, n3), memcpy(h4, p + n1 + n2 + n3, n4);
+			return;
+		}
+		d2h2(h1, d1, n1, h2, d2, n2), d2h2(h3, d3, n3, h4, d4, n4);
+	}
 	~GpuBE()
 	{
 		if (pin) (void)hipHostFree(pin);
@@ -1278,21 +1307,37 @@ struct GpuBE {
 	void append_iota(int32_t *w, long long at, long long start, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, start, n); }
 	void append_list(int32_t *w, long long at, const int32_t *src, long long n) { if (n) hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, src, n); }
 	// one index upload, one kernel, one synchronisation; the indices stay on the device for scatter_listed_i32
-	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc)
+	// oa / ob / oc = a / b / cc at the listed indices; x1, x2: two more small readbacks (or null) that ride on the same synchronisation
+	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc,
+	                   void *x1h, const void *x1d, size_t x1n, void *x2h, const void *x2d, size_t x2n)
 	{
-		if (!n) return;
+		if (!x1h) x1n = 0;
+		if (!x2h) x2n = 0;
+		if (!n) {
+			if (x1n && x2n) d2h2(x1h, x1d, x1n, x2h, x2d, x2n);
+			else if (x1n) d2h(x1h, x1d, x1n);
+			else if (x2n) d2h(x2h, x2d, x2n);
+			return;
+		}
 		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 20 + 16));
 		h2d(tmp_idx.p, idx, n * 4);
 		hipLaunchKernelGGL(k_gather_listed, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, b, cc, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
-		if ((size_t)n * 20 <= kPinUse && pinned()) {
-			note(hipMemcpyAsync(pin, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
+		if ((size_t)n * 20 + x1n + x2n <= kPinUse && pinned()) {
+			char *p = (char *)pin;
+			note(hipMemcpyAsync(p, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
+			if (x1n) note(hipMemcpyAsync(p + n * 20, x1d, x1n, hipMemcpyDeviceToHost, stream));
+			if (x2n) note(hipMemcpyAsync(p + n * 20 + x1n, x2d, x2n, hipMemcpyDeviceToHost, stream));
 			note(hipStreamSynchronize(stream));
-			memcpy(oa, pin, n * 8), memcpy(ob, (char *)pin + n * 8, n * 8), memcpy(oc, (char *)pin + n * 16, n * 4);
+			memcpy(oa, p, n * 8), memcpy(ob, p + n * 8, n * 8), memcpy(oc, p + n * 16, n * 4);
+			if (x1n) memcpy(x1h, p + n * 20, x1n);
+			if (x2n) memcpy(x2h, p + n * 20 + x1n, x2n);
 			return;
 		}
 		note(hipMemcpyAsync(oa, tmp_out.p, n * 8, hipMemcpyDeviceToHost, stream));
 		note(hipMemcpyAsync(ob, (char *)tmp_out.p + n * 8, n * 8, hipMemcpyDeviceToHost, stream));
 		note(hipMemcpyAsync(oc, (char *)tmp_out.p + n * 16, n * 4, hipMemcpyDeviceToHost, stream));
+		if (x1n) note(hipMemcpyAsync(x1h, x1d, x1n, hipMemcpyDeviceToHost, stream));
+		if (x2n) note(hipMemcpyAsync(x2h, x2d, x2n, hipMemcpyDeviceToHost, stream));
 		note(hipStreamSynchronize(stream));
 	}
 	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n)
@@ -1314,6 +1359,12 @@ struct GpuBE {
 	void st_totals(const Ctx &c, const int32_t *w, long long n, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt, bool detect)
 	{
 		if (n > 0) hipLaunchKernelGGL(k_totals, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, ctot, hprev, sens, slist, cnt, detect ? 1 : 0);
+		note(hipGetLastError());
+	}
+	void st_totals_dev(const Ctx &c, const int32_t *list, const unsigned long long *n_dev, long long n_max, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt)
+	{
+		const long long blocks = n_max / kBlock + 1;
+		hipLaunchKernelGGL(k_totals_dev, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kBlock), 0, stream, c, list, n_dev, ctot, hprev, sens, slist, cnt);
 		note(hipGetLastError());
 	}
 	void st_assemble(const Ctx &c, long long b, long long e)

@@ -511,7 +511,37 @@ template <class BE> struct EngineCore {
 		const int32_t *work = nullptr;                    // nullptr = identity: round 1 runs every real pair and every variant slot
 		std::vector<int32_t> sh_src; std::vector<long long> sh_off;
 		bool skip_eval = resume, pair_done = false;
+		bool pre_tot = false;                             // the pairing-only list's totals were taken right behind its launch (and sit in d_tops[8..9] / d_slist)
 		for (;;) {
+			std::vector<int32_t> &listed = w_listed;
+			std::vector<long long> &pre = w_pre, &cur_off = w_cur_off;
+			std::vector<int32_t> &cur_tot = w_cur_tot, &res = w_res;
+			bool gathered = false;
+			// random_r offsets: only when a read has sampled at all (expand_seed beyond POS_N_MAX positions) or the streams' start has moved --
+			// otherwise every read stands at the stream's start, where run_init put it, and six scan launches per pass are saved
+			// (any_h: run_slots below may set it -- looked at when the scans go out)
+			bool h_scans = false;
+			// every host-resolved pair: its last evaluation (offset, total) and the masked prefix in front of it
+			// (the kernels go out first: the host builds its lists while they run)
+			auto enqueue_offset_scans = [&]() {
+				h_scans = any_h || resume;
+				be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
+				be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
+				if (h_scans) {
+					be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);          // (do not depend on the host walk: they run while the host works)
+					be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
+				}
+			};
+			auto build_listed = [&]() {
+				listed.clear();
+				for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
+				if (!wins.empty()) {                              // both parts are ascending: merge instead of sorting 80 k entries again
+					const size_t mid = listed.size();
+					for (const Win &w : wins) listed.push_back(w.pair);
+					std::inplace_merge(listed.begin(), listed.begin() + mid, listed.end());
+				}
+				pre.resize(listed.size()), cur_off.resize(listed.size()), cur_tot.resize(listed.size()), res.resize(listed.size());
+			};
 			if (!skip_eval) {
 			stats.rounds++;
 			if (work == nullptr) stats.pairs_run += P, stats.shadow_runs += V; else stats.pairs_run += nfull, stats.shadow_runs += nshadow;
@@ -533,12 +563,22 @@ template <class BE> struct EngineCore {
 			if (npair_only && !beside && !pair_done) be.st_pair(c, d_workp, npair_only);
 			pair_done = false;
 			// totals of the evaluated slots; a real pair whose total differs from what the offsets assumed is sensitive
-			be.dzero(d_tops + 8, 16);
+			if (!pre_tot) be.dzero(d_tops + 8, 16);
 			be.st_totals(c, work, nfull + nshadow + nwalk, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, work != nullptr);
-			if (npair_only) be.st_totals(c, d_workp, npair_only, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, true);
+			if (npair_only && !pre_tot) be.st_totals(c, d_workp, npair_only, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8, true);
+			pre_tot = false;
 			unsigned long long nnew_chg[2] = {0, 0};           // newly count-sensitive pairs; did any evaluated slot draw a different number than last time?
 			const bool want_vcnt = vcnt.empty() && V && work == nullptr;   // the variant slots' draw counts ride on the same synchronisation
-			if (want_vcnt) { vcnt.resize(3 * V); be.d2h2(nnew_chg, d_tops + 8, 16, vcnt.data(), c.rcnt + 3 * P, 3 * V * 4); }
+			if (want_vcnt) vcnt.resize(3 * V);
+			if (work == nullptr && nshadow == 0) {
+				// first round: which pairs the host walk below looks at is known already (unless a pair turns out count-sensitive just now:
+				// then once more), so the offset scans and the gather go out behind the totals and ONE synchronisation brings everything
+				enqueue_offset_scans();
+				build_listed();
+				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(),
+				                 nnew_chg, d_tops + 8, 16, want_vcnt ? vcnt.data() : nullptr, c.rcnt + 3 * P, want_vcnt ? (size_t)3 * V * 4 : 0);
+				gathered = true;
+			} else if (want_vcnt) be.d2h2(nnew_chg, d_tops + 8, 16, vcnt.data(), c.rcnt + 3 * P, 3 * V * 4);
 			else be.d2h(nnew_chg, d_tops + 8, 16);
 			const unsigned long long nnew = nnew_chg[0];
 			// A re-run round in which every slot drew exactly as often as at its previous evaluation leaves every offset where it is: the
@@ -565,33 +605,14 @@ template <class BE> struct EngineCore {
 				std::sort(wins.begin(), wins.end(), [](const Win &a, const Win &b) { return a.pair < b.pair; });
 				be.scatter_u8(d_mask, add.data(), (long long)add.size(), 1);
 				stats.sensitive = (long long)wins.size();
+				gathered = false;                               // the mask and the lists have changed
 			}
 			}   // !skip_eval
 			skip_eval = false;
-			// every host-resolved pair: its last evaluation (offset, total) and the masked prefix in front of it
-			// (the kernels go out first: the host builds its lists while they run)
-			be.st_mask_totals(d_ctot, d_mask, P, d_cmask);
-			be.st_scan(d_cmask, P, 1, 0, 0, d_noff);
-			// random_r offsets: only when a read has sampled at all (expand_seed beyond POS_N_MAX positions) or the streams' start has moved --
-			// otherwise every read stands at the stream's start, where run_init put it, and six scan launches per pass are saved
-			const bool h_scans = any_h || resume;
-			if (h_scans) {
-				be.st_scan(c.hcnt, P, 2, 0, hrand_pos[0], d_nhoff);          // (do not depend on the walk below: they run while the host works)
-				be.st_scan(c.hcnt, P, 2, 1, hrand_pos[1], d_nhoff);
-			}
-			std::vector<int32_t> &listed = w_listed;
-			listed.clear();
-			for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
-			if (!wins.empty()) {                              // both parts are ascending: merge instead of sorting 80 k entries again
-				const size_t mid = listed.size();
-				for (const Win &w : wins) listed.push_back(w.pair);
-				std::inplace_merge(listed.begin(), listed.begin() + mid, listed.end());
-			}
-			std::vector<long long> &pre = w_pre, &cur_off = w_cur_off;
-			std::vector<int32_t> &cur_tot = w_cur_tot, &res = w_res;
-			pre.resize(listed.size()), cur_off.resize(listed.size()), cur_tot.resize(listed.size()), res.resize(listed.size());
-			if (!listed.empty()) {
-				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data());
+			if (!gathered) {
+				enqueue_offset_scans();
+				build_listed();
+				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(), nullptr, nullptr, 0, nullptr, nullptr, 0);
 			}
 			// walk O_{s+1} = O_s + D_s through the tables
 			{
@@ -650,9 +671,15 @@ template <class BE> struct EngineCore {
 			// the pairing-only repeats go out at once (the list's length is on the device; the host reads it below for the totals pass)
 			be.st_pair_dev(c, d_workp, d_tops + 48);
 			pair_done = true;
-			unsigned long long nd17[26];                    // [0] full re-runs, [16] pairing only, [24] tie-only pairs seen, [25] of those: on from the walk
+			// ... and their totals, which the next round would take first thing: when nothing else is left to run (the usual case) that round
+			// is over with the readback below instead of costing a synchronisation of its own
+			be.dzero(d_tops + 8, 16);
+			be.st_totals_dev(c, d_workp, d_tops + 48, P, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8);
+			pre_tot = true;
+			unsigned long long tops[50];                    // d_tops[8..57]: [0] newly count-sensitive, [1] any count changed, then from [24] on the lists' counters
+			const unsigned long long *nd17 = tops + 24;     // [0] full re-runs, [16] pairing only, [24] tie-only pairs seen, [25] of those: on from the walk
 			int32_t flags[16];
-			be.d2h2(nd17, d_tops + 32, sizeof nd17, flags, d_flags, 64);
+			be.d2h2(tops, d_tops + 8, sizeof tops, flags, d_flags, 64);
 			if (flags[8]) any_h = true;
 			const unsigned long long nd[2] = {nd17[0], nd17[16]};
 			if (flags[7]) stats.stale_open = 1;
@@ -667,6 +694,11 @@ template <class BE> struct EngineCore {
 			if (flags[6]) { char b[128]; snprintf(b, sizeof b, "device stage error %d (the reference would abort here)", flags[6]); err = b; rc = PSVR_ERR_UNSUPPORTED; break; }
 			nfull = (long long)nd[0], npair_only = (long long)nd[1], nshadow = 0, nwalk = (long long)nd17[25];
 			if (nfull == 0 && npair_only == 0 && nwalk == 0) break;
+			if (nfull == 0 && nwalk == 0 && tops[0] == 0 && tops[1] == 0 && wins.empty()) {
+				// the round that only repeats pairing stages: they have run, drew as often as before, nothing is sensitive -- the streams are consistent
+				stats.rounds++, stats.pair_only += npair_only;
+				break;
+			}
 			if (stats.rounds > 200) { err = "rand()-order resolution did not converge in 200 rounds"; rc = PSVR_ERR_UNSUPPORTED; break; }
 			work = d_work;
 			// offset windows for the tie-sensitive pairs that move
@@ -707,8 +739,7 @@ template <class BE> struct EngineCore {
 		// the last pair's offset + draw count of each stream (one readback: poff[P-1], then hoff / hcnt of the pair are neighbours)
 		long long lo, ho[2];
 		int32_t lc, hc[2];
-		be.d2h2(&lo, c.poff + (P - 1), 8, &lc, d_ctot + (P - 1), 4);
-		be.d2h2(ho, c.hoff + 2 * (P - 1), 16, hc, c.hcnt + 2 * (P - 1), 8);
+		be.d2h4(&lo, c.poff + (P - 1), 8, &lc, d_ctot + (P - 1), 4, ho, c.hoff + 2 * (P - 1), 16, hc, c.hcnt + 2 * (P - 1), 8);
 		out[0] = lo + lc, out[1] = ho[0] + hc[0], out[2] = ho[1] + hc[1];
 	}
 

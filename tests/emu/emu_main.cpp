@@ -33,6 +33,7 @@ struct CpuBE {
 	void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2) { memcpy(h1, d1, n1), memcpy(h2, d2, n2); }
+	void d2h4(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, void *h3, const void *d3, size_t n3, void *h4, const void *d4, size_t n4) { d2h2(h1, d1, n1, h2, d2, n2), d2h2(h3, d3, n3, h4, d4, n4); }
 	void fill_i64(long long *p, long long n, int stride, int off, long long v) { for (long long i = 0; i < n; ++i) p[off + i * stride] = v; }
 	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
 	void fill_iota(int32_t *p, long long n) { for (long long i = 0; i < n; ++i) p[i] = (int32_t)i; }
@@ -47,8 +48,12 @@ struct CpuBE {
 	}
 	void append_iota(int32_t *w, long long at, long long start, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = (int32_t)(start + i); }
 	std::vector<int32_t> listed_idx;
-	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc)
+	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc,
+	                   void *x1h, const void *x1d, size_t x1n, void *x2h, const void *x2d, size_t x2n)
 	{
+		if (x1h && x1n) memcpy(x1h, x1d, x1n);
+		if (x2h && x2n) memcpy(x2h, x2d, x2n);
+		if (!n) return;                          // (the indices of the gather before stay: scatter_listed_i32 is not called then)
 		listed_idx.assign(idx, idx + n);
 		for (long long i = 0; i < n; ++i) oa[i] = a[idx[i]], ob[i] = b[idx[i]], oc[i] = cc[idx[i]];
 	}
@@ -78,6 +83,10 @@ struct CpuBE {
 			if (detect && s < c.n_pairs && t != ctot[s] && !sens[s]) sens[s] = 1, slist[(*cnt)++] = (int32_t)s;
 			ctot[s] = t, hprev[2 * s] = h0, hprev[2 * s + 1] = h1;
 		}
+	}
+	void st_totals_dev(const Ctx &c, const int32_t *list, const unsigned long long *n_dev, long long, int32_t *ctot, int32_t *hprev, uint8_t *sens, int32_t *slist, unsigned long long *cnt)
+	{
+		st_totals(c, list, (long long)*n_dev, ctot, hprev, sens, slist, cnt, true);
 	}
 	void st_assemble(const Ctx &c, long long b, long long e) { for (long long i = b; i < e; ++i) assemble_candidate(c, i); }
 	void st_finalize(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) finalize_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
