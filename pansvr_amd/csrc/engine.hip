@@ -2082,9 +2082,9 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
 	const RunStats &s = e->core.stats;
 	snprintf(buf, n,
-	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"dp_seq_bytes\":%lld,\"candidates\":%lld,"
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"dp_seq_bytes\":%lld,\"candidates\":%lld,\"walk_pairs\":%lld,\"walk_us\":%lld,"
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
-	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.dp_seq_bytes, s.cands, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.dp_seq_bytes, s.cands, s.walk_pairs, s.walk_us, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();

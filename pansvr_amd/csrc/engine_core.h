@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include "aln_device.h"
 
@@ -79,6 +80,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 
 struct RunStats {
 	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0, dp_seq_bytes = 0, from_walk = 0;
+	long long walk_pairs = 0, walk_us = 0;     // the host walk over the N / tie-sensitive pairs: entries, microseconds (all rounds of the batch)
 	unsigned long long counters[16] = {0};
 };
 
@@ -616,6 +618,7 @@ template <class BE> struct EngineCore {
 			}
 			// walk O_{s+1} = O_s + D_s through the tables
 			{
+				const auto walk_t0 = std::chrono::steady_clock::now();
 				long long acc = 0;
 				size_t si = 0, wi = 0;
 				for (size_t i = 0; i < listed.size(); ++i) {
@@ -656,6 +659,8 @@ template <class BE> struct EngineCore {
 					res[i] = D, acc += D;
 					cur_off[i] = t;                                  // where the pair must be evaluated next
 				}
+				stats.walk_pairs += (long long)listed.size();
+				stats.walk_us += (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - walk_t0).count();
 			}
 			if (!listed.empty()) be.scatter_listed_i32(d_ctot, res.data(), (long long)listed.size());   // same indices as gather_listed
 			// new offsets from the totals; which pairs drew from a stale offset?
