@@ -460,7 +460,7 @@ def main():
                                                  "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast, "index_distribution": index_how,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,
-                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "dp_seq_bytes", "stale_open", "candidates", "walk_pairs", "walk_us", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
+                "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "dp_seq_bytes", "stale_open", "candidates", "walk_pairs", "walk_us", "n_special", "special_const", "special_nomove", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         print(json.dumps(line), flush=True)
     if eng is not None:

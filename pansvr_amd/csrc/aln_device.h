@@ -1593,6 +1593,56 @@ PSVR_HDN inline void adopt_variant(const Ctx &c, long long pair, long long slot,
 	}
 }
 
+// ---- pairs with N draws whose variant slots make them predictable (engine_core.h) ----
+// A pair with 1..3 N bases was also run once per residue assignment (its "variant slots").  If every variant draws the same number from
+// the stream, the pair's total does not depend on where in the stream it stands: it needs no place in the host's walk, and which variant's
+// records are the pair's follows from the residues at its final offset -- looked up and adopted on the device.
+struct SpecialPair { int32_t pair; uint8_t n1, n2; int32_t vslot, nvar; };
+PSVR_HD int special_is_const(const Ctx &c, const SpecialPair &sp)
+{
+	const int32_t *v0 = c.rcnt + 3 * (long long)sp.vslot;
+	for (int v = 0; v < sp.nvar; ++v) {
+		const long long slot = (long long)sp.vslot + v;
+		const int32_t *vc = c.rcnt + 3 * slot;
+		if (vc[0] != v0[0] || vc[0] + vc[1] + vc[2] != v0[0] + v0[1] + v0[2]) return 0;
+		if (c.hcnt[2 * slot] != 0 || c.hcnt[2 * slot + 1] != 0) return 0;       // (adopt_variant declines those)
+	}
+	return 1;
+}
+// the variant slot the residues at stream offset t select (the host walk's `code`, engine_core.h); -1: outside the device's window of the stream
+PSVR_HD long long special_slot_at(const Ctx &c, const SpecialPair &sp, long long t)
+{
+	int code = 0, sh = 0;
+	for (int j = 0; j < sp.n1; ++j) {
+		const long long k = t + j - c.grand_base;
+		if (k < 0 || k >= c.grand_n) return -1;
+		code |= (c.grand[k] & 3) << sh, sh += 2;
+	}
+	const int32_t c1 = c.rcnt[3 * ((long long)sp.vslot + code)];          // mate 0 does not depend on mate 1's residues
+	for (int j = 0; j < sp.n2; ++j) {
+		const long long k = t + c1 + j - c.grand_base;
+		if (k < 0 || k >= c.grand_n) return -1;
+		code |= (c.grand[k] & 3) << sh, sh += 2;
+	}
+	return (long long)sp.vslot + code;
+}
+// a predictable pair at its (new) offset: adopt the variant its residues select, unless it carries that one already (the host walk's rule for
+// the pairs it resolves itself).  All `parts` callers of a pair decide alike; part 0 records the adoption.  Returns 1 if it adopted.
+PSVR_HDN inline int adopt_auto(const Ctx &c, const SpecialPair &sp, const long long *noff, int32_t *adopted, long long *adopted_at, int part, int parts)
+{
+	const long long t = noff[sp.pair];
+	const long long slot = special_slot_at(c, sp, t);
+	if (slot < 0) { *c.err = 2; return 0; }
+	const int32_t *vc = c.rcnt + 3 * slot;
+	const bool moves = vc[2] != 0 || vc[0] != sp.n1 || vc[1] != sp.n2;
+	const int32_t had = *adopted;
+	const long long had_at = *adopted_at;
+	if (!(vc[0] >= sp.n1 && vc[1] >= sp.n2 && (had != (int32_t)slot || (moves && had_at != t)))) return 0;
+	adopt_variant(c, sp.pair, slot, noff, part, parts);
+	if (part == 0) *adopted = (int32_t)slot, *adopted_at = t;
+	return 1;
+}
+
 // materialise the byte sequences of one queued DP problem (get_refseq + the reversal of left extensions,
 // rr.cpp:920-928)
 PSVR_HD void dp_fetch_base(const Ctx &c, const DpDesc &d, int i, uint8_t *q, uint8_t *t)

@@ -708,6 +708,24 @@ __global__ __launch_bounds__(kBlock) void k_adopt(Ctx c, const int32_t *pairs, c
 	const long long i = blockIdx.x * (long long)(kBlock / 64) + (threadIdx.x >> 6);
 	if (i < n) adopt_variant(c, pairs[i], slots[i], noff, threadIdx.x & 63, 64);
 }
+// which special pairs draw alike under every residue assignment (class 1: unmasked, resolved on the device from here on)
+__global__ void k_special_class(Ctx c, const SpecialPair *sp, long long n, uint8_t *mask, uint8_t *cls)
+{
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int k = special_is_const(c, sp[i]);
+	cls[i] = (uint8_t)k;
+	if (k) mask[sp[i].pair] = 0;
+}
+// one wavefront per special pair of class 1 that is still predictable (not count-sensitive): adopt_auto in aln_device.h
+__global__ __launch_bounds__(kBlock) void k_adopt_auto(Ctx c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff,
+                                                       int32_t *adopted, long long *adopted_at, unsigned long long *count)
+{
+	const long long i = blockIdx.x * (long long)(kBlock / 64) + (threadIdx.x >> 6);
+	if (i >= n || !cls[i] || mask[sp[i].pair]) return;
+	const int did = adopt_auto(c, sp[i], noff, adopted + i, adopted_at + i, threadIdx.x & 63, 64);
+	if (count && did && (threadIdx.x & 63) == 0) atomicAdd(count, 1ull);   // (statistics only: 17 k wavefronts on one counter are 0.2 ms, tools/atomic_rate_bench.hip)
+}
 // ---- result hand-over -------------------------------------------------------------------------
 // the fixed-size ABI records (psvr_engine_download): one thread per read
 __global__ __launch_bounds__(kBlock) void k_materialize(Ctx c, long long R, psvr_read_result_t *out)
@@ -1104,6 +1122,7 @@ struct GpuBE {
 	void *dalloc(size_t n) { void *p = nullptr; hipError_t e = hipMalloc(&p, n ? n : 16); note(e); return e == hipSuccess ? p : nullptr; }
 	void dfree(void *p) { if (p) (void)hipFree(p); }
 	void dzero(void *p, size_t n) { note(hipMemsetAsync(p, 0, n, stream)); }
+	void dfill(void *p, int byte, size_t n) { note(hipMemsetAsync(p, byte, n, stream)); }
 	// small transfers (counters, lists of a few thousand pairs) go through a pinned staging buffer: a copy to or from pageable
 	// memory costs several times the latency
 	void *pin = nullptr;
@@ -1307,37 +1326,37 @@ struct GpuBE {
 	void append_iota(int32_t *w, long long at, long long start, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, start, n); }
 	void append_list(int32_t *w, long long at, const int32_t *src, long long n) { if (n) hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, src, n); }
 	// one index upload, one kernel, one synchronisation; the indices stay on the device for scatter_listed_i32
-	// oa / ob / oc = a / b / cc at the listed indices; x1, x2: two more small readbacks (or null) that ride on the same synchronisation
+	// oa / ob / oc = a / b / cc at the listed indices; x1..x3: up to three more small readbacks (or null) that ride on the same synchronisation
 	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc,
-	                   void *x1h, const void *x1d, size_t x1n, void *x2h, const void *x2d, size_t x2n)
+	                   void *x1h, const void *x1d, size_t x1n, void *x2h, const void *x2d, size_t x2n, void *x3h, const void *x3d, size_t x3n)
 	{
-		if (!x1h) x1n = 0;
-		if (!x2h) x2n = 0;
-		if (!n) {
-			if (x1n && x2n) d2h2(x1h, x1d, x1n, x2h, x2d, x2n);
-			else if (x1n) d2h(x1h, x1d, x1n);
-			else if (x2n) d2h(x2h, x2d, x2n);
-			return;
+		void *xh[3] = {x1h, x2h, x3h};
+		const void *xd[3] = {x1d, x2d, x3d};
+		size_t xn[3] = {x1h ? x1n : 0, x2h ? x2n : 0, x3h ? x3n : 0};
+		const size_t xtot = xn[0] + xn[1] + xn[2];
+		if (n) {
+			note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 20 + 16));
+			h2d(tmp_idx.p, idx, n * 4);
+			hipLaunchKernelGGL(k_gather_listed, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, b, cc, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
 		}
-		note(tmp_idx.ensure(n * 4)), note(tmp_out.ensure(n * 20 + 16));
-		h2d(tmp_idx.p, idx, n * 4);
-		hipLaunchKernelGGL(k_gather_listed, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, b, cc, (const int32_t *)tmp_idx.p, n, (long long *)tmp_out.p);
-		if ((size_t)n * 20 + x1n + x2n <= kPinUse && pinned()) {
+		if (!n && !xtot) return;
+		if ((size_t)n * 20 + xtot <= kPinUse && pinned()) {
 			char *p = (char *)pin;
-			note(hipMemcpyAsync(p, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
-			if (x1n) note(hipMemcpyAsync(p + n * 20, x1d, x1n, hipMemcpyDeviceToHost, stream));
-			if (x2n) note(hipMemcpyAsync(p + n * 20 + x1n, x2d, x2n, hipMemcpyDeviceToHost, stream));
+			if (n) note(hipMemcpyAsync(p, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
+			size_t at = (size_t)n * 20;
+			for (int k = 0; k < 3; ++k) if (xn[k]) { note(hipMemcpyAsync(p + at, xd[k], xn[k], hipMemcpyDeviceToHost, stream)); at += xn[k]; }
 			note(hipStreamSynchronize(stream));
-			memcpy(oa, p, n * 8), memcpy(ob, p + n * 8, n * 8), memcpy(oc, p + n * 16, n * 4);
-			if (x1n) memcpy(x1h, p + n * 20, x1n);
-			if (x2n) memcpy(x2h, p + n * 20 + x1n, x2n);
+			if (n) memcpy(oa, p, n * 8), memcpy(ob, p + n * 8, n * 8), memcpy(oc, p + n * 16, n * 4);
+			at = (size_t)n * 20;
+			for (int k = 0; k < 3; ++k) if (xn[k]) { memcpy(xh[k], p + at, xn[k]); at += xn[k]; }
 			return;
 		}
-		note(hipMemcpyAsync(oa, tmp_out.p, n * 8, hipMemcpyDeviceToHost, stream));
-		note(hipMemcpyAsync(ob, (char *)tmp_out.p + n * 8, n * 8, hipMemcpyDeviceToHost, stream));
-		note(hipMemcpyAsync(oc, (char *)tmp_out.p + n * 16, n * 4, hipMemcpyDeviceToHost, stream));
-		if (x1n) note(hipMemcpyAsync(x1h, x1d, x1n, hipMemcpyDeviceToHost, stream));
-		if (x2n) note(hipMemcpyAsync(x2h, x2d, x2n, hipMemcpyDeviceToHost, stream));
+		if (n) {
+			note(hipMemcpyAsync(oa, tmp_out.p, n * 8, hipMemcpyDeviceToHost, stream));
+			note(hipMemcpyAsync(ob, (char *)tmp_out.p + n * 8, n * 8, hipMemcpyDeviceToHost, stream));
+			note(hipMemcpyAsync(oc, (char *)tmp_out.p + n * 16, n * 4, hipMemcpyDeviceToHost, stream));
+		}
+		for (int k = 0; k < 3; ++k) if (xn[k]) note(hipMemcpyAsync(xh[k], xd[k], xn[k], hipMemcpyDeviceToHost, stream));
 		note(hipStreamSynchronize(stream));
 	}
 	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n)
@@ -1346,6 +1365,16 @@ struct GpuBE {
 		note(tmp_val.ensure(n * 4));
 		h2d(tmp_val.p, val, n * 4);
 		hipLaunchKernelGGL(k_scatter_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n);
+	}
+	void st_special_class(const Ctx &c, const SpecialPair *sp, long long n, uint8_t *mask, uint8_t *cls)
+	{
+		if (n > 0) hipLaunchKernelGGL(k_special_class, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, sp, n, mask, cls);
+		note(hipGetLastError());
+	}
+	void st_adopt_auto(const Ctx &c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff, int32_t *adopted, long long *adopted_at, unsigned long long *count)
+	{
+		if (n > 0) hipLaunchKernelGGL(k_adopt_auto, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, stream, c, sp, n, cls, mask, noff, adopted, adopted_at, count);
+		note(hipGetLastError());
 	}
 	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff)
 	{
@@ -2082,9 +2111,9 @@ extern "C" int psvr_engine_stats(const psvr_engine_t *e, char *buf, size_t n)
 	if (!e || !buf || !n) return set_error(PSVR_ERR_ARG, "psvr_engine_stats: bad argument");
 	const RunStats &s = e->core.stats;
 	snprintf(buf, n,
-	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"dp_seq_bytes\":%lld,\"candidates\":%lld,\"walk_pairs\":%lld,\"walk_us\":%lld,"
+	         "{\"pairs\":%lld,\"rounds\":%lld,\"pair_runs\":%lld,\"pair_only_runs\":%lld,\"shadow_runs\":%lld,\"sensitive_pairs\":%lld,\"window_misses\":%lld,\"adopted_pairs\":%lld,\"stale_open\":%lld,\"dp_problems\":%lld,\"dp_seq_bytes\":%lld,\"candidates\":%lld,\"walk_pairs\":%lld,\"walk_us\":%lld,\"n_special\":%lld,\"special_const\":%lld,\"special_nomove\":%lld,"
 	         "\"probes\":%llu,\"hits\":%llu,\"seeds\":%llu,\"dp_cells\":%llu,\"simple\":%llu,\"reads_aligned\":%llu}",
-	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.dp_seq_bytes, s.cands, s.walk_pairs, s.walk_us, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
+	         e->core.P, s.rounds, s.pairs_run, s.pair_only, s.shadow_runs, s.sensitive, s.window_miss, s.adopted, s.stale_open, s.dp_problems, s.dp_seq_bytes, s.cands, s.walk_pairs, s.walk_us, s.n_special, s.special_const, s.special_nomove, s.counters[ST_PROBES], s.counters[ST_HITS], s.counters[ST_SEEDS],
 	         s.counters[ST_CELLS], s.counters[ST_SIMPLE], s.counters[ST_READS]);
 	std::string t = buf;
 	t.pop_back();

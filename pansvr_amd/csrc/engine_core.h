@@ -80,7 +80,7 @@ struct DpIO {                 // what the DP stage needs beyond Ctx
 
 struct RunStats {
 	long long rounds = 0, pairs_run = 0, pair_only = 0, shadow_runs = 0, sensitive = 0, window_miss = 0, dp_problems = 0, cands = 0, adopted = 0, stale_open = 0, dp_seq_bytes = 0, from_walk = 0;
-	long long walk_pairs = 0, walk_us = 0;     // the host walk over the N / tie-sensitive pairs: entries, microseconds (all rounds of the batch)
+	long long walk_pairs = 0, walk_us = 0, n_special = 0, special_const = 0, special_nomove = 0;     // the host walk over the N / tie-sensitive pairs: entries, microseconds (all rounds of the batch)
 	unsigned long long counters[16] = {0};
 };
 
@@ -107,12 +107,19 @@ template <class BE> struct EngineCore {
 	char *d_bases = nullptr; long long *d_off = nullptr; psvr_ori_t *d_ori = nullptr;   // the uploaded batch
 	long long cap_S = 0, cap_bases = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
 	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
+	// the special pairs on the device: the list, which of them draw the same number under every residue assignment (resolved there, not in the
+	// host walk), the variant slot each of those carries and the offset it was adopted at
+	SpecialPair *d_special = nullptr;
+	uint8_t *d_sp_class = nullptr;
+	int32_t *d_sp_adopted = nullptr;
+	long long *d_sp_adopted_at = nullptr;
+	std::vector<uint8_t> h_sp_class;
 	uint8_t *d_hasn = nullptr;                       // per pair: a read of it draws for N bases (its draws are not just chain-selection ties)
 	int32_t *d_resel = nullptr, *d_resel4 = nullptr;   // pairs whose chain selection runs again on its own (reselect_pair); of those, the ones that go on from the walk
 	std::vector<int32_t> h_n_idx;                    // pairs with N draws (built by upload())
 	static const long long kReselCap = 1 << 16;      // tie-only pairs a round can resolve on the spot; beyond that they run in full
 	int32_t *d_cmask = nullptr;                      // totals with the host-resolved pairs masked out
-	struct Special { int32_t pair; uint8_t n1, n2; int32_t vslot, nvar; };
+	typedef SpecialPair Special;                     // (aln_device.h: the device looks at them too)
 	std::vector<Special> special;                    // pairs with 1..3 N draws, ascending
 	long long V = 0;                                 // variant slots [P, P+V)
 	long long S = 0;                                 // slots = P real pairs + V variants + window-shadow capacity
@@ -295,6 +302,10 @@ template <class BE> struct EngineCore {
 		d_hprev = alloc<int32_t>(2 * S);
 		d_force = alloc<uint8_t>(8 * S), d_mask = alloc<uint8_t>(P), d_cmask = alloc<int32_t>(P);
 		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel4 = alloc<int32_t>(P < kReselCap ? P : kReselCap);
+		{
+			const long long nsp = S / 4 + 1;                 // (a special pair has >= 4 variant slots: whatever batch fits these buffers later has no more)
+			d_special = alloc<Special>(nsp), d_sp_class = alloc<uint8_t>(nsp), d_sp_adopted = alloc<int32_t>(nsp), d_sp_adopted_at = alloc<long long>(nsp);
+		}
 		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(16);
 		const long long R2 = RS;
 		cap_mem = (unsigned long long)2 * R2 * kMemSlot + (unsigned long long)R2 * 16 + 4096;
@@ -351,6 +362,7 @@ template <class BE> struct EngineCore {
 			be.dzero(d_force, (size_t)8 * S);
 			if (V) be.h2d(d_force + (size_t)8 * P, force.data(), force.size());
 			be.dzero(d_hasn, (size_t)P);
+			if (!special.empty()) be.h2d(d_special, special.data(), special.size() * sizeof(Special));   // (constant for the batch, like d_force)
 			if (!h_n_idx.empty()) be.scatter_u8(d_hasn, h_n_idx.data(), (long long)h_n_idx.size(), 1);
 		}
 	}
@@ -483,6 +495,11 @@ template <class BE> struct EngineCore {
 		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
 		if (V) be.h2d(d_src + P, h_vsrc.data(), V * 4);
 		if (!h_sp_idx.empty()) be.scatter_u8(d_mask, h_sp_idx.data(), (long long)h_sp_idx.size(), 1);
+		if (!special.empty()) {
+			const long long nsp = (long long)special.size();
+			be.dzero(d_sp_class, nsp), be.dfill(d_sp_adopted, 0xff, nsp * 4), be.dfill(d_sp_adopted_at, 0xff, nsp * 8);   // class 0, nothing adopted (-1)
+		}
+		h_sp_class.assign(special.size(), 0);
 		dp_done = 0, cw_done = 0, any_h = false;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
 		adopted.assign(special.size(), -1), adopted_at.assign(special.size(), -1), adopt_pair.clear(), adopt_slot.clear();
@@ -536,7 +553,7 @@ template <class BE> struct EngineCore {
 			};
 			auto build_listed = [&]() {
 				listed.clear();
-				for (size_t i = 0; i < special.size(); ++i) if (is_special[i]) listed.push_back(special[i].pair);
+				for (size_t i = 0; i < special.size(); ++i) if (is_special[i] == 1) listed.push_back(special[i].pair);   // (2: resolved on the device)
 				if (!wins.empty()) {                              // both parts are ascending: merge instead of sorting 80 k entries again
 					const size_t mid = listed.size();
 					for (const Win &w : wins) listed.push_back(w.pair);
@@ -575,10 +592,15 @@ template <class BE> struct EngineCore {
 			if (work == nullptr && nshadow == 0) {
 				// first round: which pairs the host walk below looks at is known already (unless a pair turns out count-sensitive just now:
 				// then once more), so the offset scans and the gather go out behind the totals and ONE synchronisation brings everything
+				// (the special pairs every variant of which draws alike leave the host's hands here: unmasked, class 1)
+				const bool classify = want_vcnt && !special.empty();
+				if (classify) be.st_special_class(c, d_special, (long long)special.size(), d_mask, d_sp_class);
 				enqueue_offset_scans();
 				build_listed();
 				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(),
-				                 nnew_chg, d_tops + 8, 16, want_vcnt ? vcnt.data() : nullptr, c.rcnt + 3 * P, want_vcnt ? (size_t)3 * V * 4 : 0);
+				                 nnew_chg, d_tops + 8, 16, want_vcnt ? vcnt.data() : nullptr, c.rcnt + 3 * P, want_vcnt ? (size_t)3 * V * 4 : 0,
+				                 classify ? h_sp_class.data() : nullptr, d_sp_class, classify ? special.size() : 0);
+				if (classify) for (size_t i = 0; i < special.size(); ++i) if (h_sp_class[i] && is_special[i] == 1) is_special[i] = 2;
 				gathered = true;
 			} else if (want_vcnt) be.d2h2(nnew_chg, d_tops + 8, 16, vcnt.data(), c.rcnt + 3 * P, 3 * V * 4);
 			else be.d2h(nnew_chg, d_tops + 8, 16);
@@ -614,10 +636,23 @@ template <class BE> struct EngineCore {
 			if (!gathered) {
 				enqueue_offset_scans();
 				build_listed();
-				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(), nullptr, nullptr, 0, nullptr, nullptr, 0);
+				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0);
 			}
 			// walk O_{s+1} = O_s + D_s through the tables
 			{
+				if (want_stats && !vcnt.empty() && stats.n_special == 0) {
+					// (diagnostic) how many of the N pairs draw the same number whatever residues they get / draw nothing but those residues
+					for (const Special &sp : special) {
+						bool cst = true, nomove = true;
+						const int32_t *v0 = &vcnt[3 * (sp.vslot - P)];
+						for (int v = 0; v < sp.nvar; ++v) {
+							const int32_t *vc = &vcnt[3 * (sp.vslot - P + v)];
+							if (vc[0] != v0[0] || vc[0] + vc[1] + vc[2] != v0[0] + v0[1] + v0[2]) cst = false;
+							if (vc[2] != 0 || vc[0] != sp.n1 || vc[1] != sp.n2) nomove = false;
+						}
+						stats.n_special++, stats.special_const += cst, stats.special_nomove += nomove;
+					}
+				}
 				const auto walk_t0 = std::chrono::steady_clock::now();
 				long long acc = 0;
 				size_t si = 0, wi = 0;
@@ -627,7 +662,12 @@ template <class BE> struct EngineCore {
 					int32_t D = cur_tot[i];
 					while (si < special.size() && special[si].pair < s) ++si;
 					while (wi < wins.size() && wins[wi].pair < s) ++wi;
-					if (si < special.size() && special[si].pair == s && is_special[si] && !vcnt.empty()) {
+					if (si < special.size() && special[si].pair == s && is_special[si] == 2) {
+						// classified while this list was on its way: its total stands whatever its offset (and is part of `pre` for the pairs behind it)
+						res[i] = D;
+						continue;
+					}
+					if (si < special.size() && special[si].pair == s && is_special[si] == 1 && !vcnt.empty()) {
 						const Special &sp = special[si];
 						grand.ensure(t + 64);
 						int code = 0, sh2 = 0;
@@ -671,7 +711,8 @@ template <class BE> struct EngineCore {
 				adopt_pair.clear(), adopt_slot.clear();
 			}
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
-			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 16);
+			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 5 * 8);
+			if (!special.empty()) be.st_adopt_auto(c, d_special, (long long)special.size(), d_sp_class, d_mask, d_noff, d_sp_adopted, d_sp_adopted_at, want_stats ? d_tops + 60 : nullptr);
 			be.st_dirty(c, d_noff, h_scans ? d_nhoff : c.hoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
 			// the pairing-only repeats go out at once (the list's length is on the device; the host reads it below for the totals pass)
 			be.st_pair_dev(c, d_workp, d_tops + 48);
@@ -681,11 +722,12 @@ template <class BE> struct EngineCore {
 			be.dzero(d_tops + 8, 16);
 			be.st_totals_dev(c, d_workp, d_tops + 48, P, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8);
 			pre_tot = true;
-			unsigned long long tops[50];                    // d_tops[8..57]: [0] newly count-sensitive, [1] any count changed, then from [24] on the lists' counters
+			unsigned long long tops[53];                    // d_tops[8..60]: [0] newly count-sensitive, [1] any count changed, from [24] on the lists' counters, [52] adoptions made on the device
 			const unsigned long long *nd17 = tops + 24;     // [0] full re-runs, [16] pairing only, [24] tie-only pairs seen, [25] of those: on from the walk
 			int32_t flags[16];
 			be.d2h2(tops, d_tops + 8, sizeof tops, flags, d_flags, 64);
 			if (flags[8]) any_h = true;
+			stats.adopted += (long long)tops[52];
 			const unsigned long long nd[2] = {nd17[0], nd17[16]};
 			if (flags[7]) stats.stale_open = 1;
 			if (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5]) { c.stats = stats_ptr; return grow_and_rerun(flags, trace, want_stats, depth); }

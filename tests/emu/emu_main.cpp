@@ -30,6 +30,7 @@ struct CpuBE {
 	void *dalloc(size_t n) { return calloc(n ? n : 1, 1); }
 	void dfree(void *p) { free(p); }
 	void dzero(void *p, size_t n) { memset(p, 0, n); }
+	void dfill(void *p, int byte, size_t n) { memset(p, byte, n); }
 	void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2) { memcpy(h1, d1, n1), memcpy(h2, d2, n2); }
@@ -49,13 +50,22 @@ struct CpuBE {
 	void append_iota(int32_t *w, long long at, long long start, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = (int32_t)(start + i); }
 	std::vector<int32_t> listed_idx;
 	void gather_listed(const long long *a, const long long *b, const int32_t *cc, const int32_t *idx, long long n, long long *oa, long long *ob, int32_t *oc,
-	                   void *x1h, const void *x1d, size_t x1n, void *x2h, const void *x2d, size_t x2n)
+	                   void *x1h, const void *x1d, size_t x1n, void *x2h, const void *x2d, size_t x2n, void *x3h, const void *x3d, size_t x3n)
 	{
 		if (x1h && x1n) memcpy(x1h, x1d, x1n);
 		if (x2h && x2n) memcpy(x2h, x2d, x2n);
+		if (x3h && x3n) memcpy(x3h, x3d, x3n);
 		if (!n) return;                          // (the indices of the gather before stay: scatter_listed_i32 is not called then)
 		listed_idx.assign(idx, idx + n);
 		for (long long i = 0; i < n; ++i) oa[i] = a[idx[i]], ob[i] = b[idx[i]], oc[i] = cc[idx[i]];
+	}
+	void st_special_class(const Ctx &c, const SpecialPair *sp, long long n, uint8_t *mask, uint8_t *cls)
+	{
+		for (long long i = 0; i < n; ++i) { cls[i] = (uint8_t)special_is_const(c, sp[i]); if (cls[i]) mask[sp[i].pair] = 0; }
+	}
+	void st_adopt_auto(const Ctx &c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff, int32_t *adopted, long long *adopted_at, unsigned long long *count)
+	{
+		for (long long i = 0; i < n; ++i) if (cls[i] && !mask[sp[i].pair]) { const int did = adopt_auto(c, sp[i], noff, adopted + i, adopted_at + i, 0, 1); if (count) *count += (unsigned long long)did; }
 	}
 	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n) { for (long long i = 0; i < n; ++i) a[listed_idx[i]] = val[i]; }
 	void scatter_u8(uint8_t *a, const int32_t *idx, long long n, uint8_t v) { for (long long i = 0; i < n; ++i) a[idx[i]] = v; }
