@@ -1634,10 +1634,11 @@ PSVR_HDN inline int adopt_auto(const Ctx &c, const SpecialPair &sp, const long l
 	const long long slot = special_slot_at(c, sp, t);
 	if (slot < 0) { *c.err = 2; return 0; }
 	const int32_t *vc = c.rcnt + 3 * slot;
-	const bool moves = vc[2] != 0 || vc[0] != sp.n1 || vc[1] != sp.n2;
 	const int32_t had = *adopted;
 	const long long had_at = *adopted_at;
-	if (!(vc[0] >= sp.n1 && vc[1] >= sp.n2 && (had != (int32_t)slot || (moves && had_at != t)))) return 0;
+	// (the same slot at another offset is adopted again even if nothing of it depends on the offset: the adoption is also what tells
+	// mark_dirty that the pair stands where it belongs -- left alone it would run in full)
+	if (!(vc[0] >= sp.n1 && vc[1] >= sp.n2 && (had != (int32_t)slot || had_at != t))) return 0;
 	adopt_variant(c, sp.pair, slot, noff, part, parts);
 	if (part == 0) *adopted = (int32_t)slot, *adopted_at = t;
 	return 1;

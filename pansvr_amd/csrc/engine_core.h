@@ -681,8 +681,9 @@ template <class BE> struct EngineCore {
 						// too, the adoption runs the pairing again at the pair's offset (adopt_variant): again whenever the offset moves.
 						// (a read of the slot that drew for tied chains as well -- vc > n -- is adopted if its selection, repeated at this offset,
 						// leaves the candidates and the counts as they are; the device declines otherwise and the pair runs in full)
-						const bool moves = vc[2] != 0 || vc[0] != sp.n1 || vc[1] != sp.n2;
-						if (vc[0] >= sp.n1 && vc[1] >= sp.n2 && (adopted[si] != sp.vslot + code || (moves && adopted_at[si] != t))) {
+						// (the same slot at another offset is adopted again even if nothing of it depends on the offset: the adoption is also what
+						// tells mark_dirty that the pair stands where it belongs -- left alone it ran in full, 3.7 k pairs per rebase of the bench batch)
+						if (vc[0] >= sp.n1 && vc[1] >= sp.n2 && (adopted[si] != sp.vslot + code || adopted_at[si] != t)) {
 							adopted[si] = sp.vslot + code, adopted_at[si] = t;
 							adopt_pair.push_back(s), adopt_slot.push_back(sp.vslot + code);
 						}
