@@ -432,6 +432,7 @@ def main():
             # Counted from the run: dp_cells / dp_problems gives the mean shape; direction bytes are scratch and not counted.
             cfg5 = {"workload": "configs[4]: %d synthetic 250 bp PE pairs vs 2000 anchors with 2 kbp edges (%.1f Mbp), indels up to 40" % (args.pairs, len(anc5["codes"]) / 1e6),
                     "reads_per_s": round(2 * args.pairs / t5, 1), "ms_per_step": round(t5 * 1e3, 3), "dominant_kernel": dom5,
+                    "rounds": s5.get("rounds"), "pair_runs": s5.get("pair_runs"), "pair_only_runs": s5.get("pair_only_runs"),
                     "dp_problems": s5["dp_problems"], "dp_cells": s5["dp_cells"], "dp_kernels_ms": wide,
                     "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(k5.items(), key=lambda kv: -kv[1]["ms"])}}
             dp_ms = sum(wide.values())
