@@ -1543,7 +1543,7 @@ struct GpuBE {
 		B.qseq = d.qbuf, B.q_off = (const int64_t *)d.q_off, B.qlen = d.qlen;
 		B.tseq = d.tbuf, B.t_off = (const int64_t *)d.t_off, B.tlen = d.tlen;
 		B.ez = d.ez, B.cigar = d.cig, B.pslab = (uint8_t *)pslab.p, B.p_off = (const int64_t *)plan_poff.p, B.p_unit_shift = 8;   // slab offsets in 256-byte units
-		B.ws = (uint8_t *)strip_ws.p, B.ws_top = plan_hist.as<unsigned long long>() + 1040, B.ws_cap = ws_bytes;   // the top counter was zeroed with the histograms
+		B.ws = (uint8_t *)strip_ws.p, B.ws_cap = ws_bytes;
 		B.err = c.err;
 		TeamLaunch team;
 		size_t n_other = 0;

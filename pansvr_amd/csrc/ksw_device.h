@@ -4,9 +4,10 @@
 // ksw2_extz2_sse.c:23-305) and ksw_backtrack_D / ksw_apply_zdrop (src/kswlib/ksw2.h:119-151,245-261).
 //
 // Design (MI355X-first, not a port of the SSE code).  Four kernels share the recurrences; the planners route a problem by shape:
-//   * extd2_team_kernel<4>  -- the `aln` path's kernel: band never clips the matrix, values fit int8 (dp_band_never_binds &&
-//     nowrap_ok).  4 lanes per alignment, 16 alignments per wavefront, the matrix swept in strips of 16 target columns with
-//     the state of 4 columns per lane in registers; see the kernel for the strip boundary / per-diagonal bookkeeping.
+//   * extd2_team_kernel<LANES, CPL> + extd2_team_finish_kernel -- the `aln` path's kernel: band never clips the matrix, values fit
+//     int8 (dp_band_never_binds && nowrap_ok).  2 lanes per alignment, 32 alignments per wavefront, the matrix swept in strips of
+//     16 target columns with the state of 8 columns per lane in registers, a ROW of them per step; see the kernel for the strip
+//     boundary / per-diagonal bookkeeping.  The z-drop / end rules and the traceback are the second launch, a thread per alignment.
 //   * extd2_tiny_kernel     -- same regime, qlen, tlen <= 16: one thread per alignment, state in LDS.
 //   * extd2_reg_kernel<K,PG> -- one 64-lane wavefront per alignment, lane L of chunk c owns target column t = 64c + L, the
 //     per-column state (u,v,x,y,x2,y2,s,H) in VGPRs, (r-1,t-1) neighbours by DPP wave_shr:1 with the inter-chunk carry
@@ -42,7 +43,7 @@ struct DpBatch { // device pointers of one batch
 	int32_t p_unit_shift;
 	int32_t lds_per_wave;      // reg kernels: dynamic LDS bytes of one wavefront's problem
 	long long n;               // problems in this launch
-	uint8_t *ws; unsigned long long *ws_top; unsigned long long ws_cap;   // team kernel: per-wavefront scratch (TeamPlan::ws_base; ws_top is unused)
+	uint8_t *ws; unsigned long long ws_cap;   // team kernel: per-wavefront scratch, a slice per wavefront (TeamPlan::ws_base)
 	int *err;                  // set to 20 if that scratch runs out (cannot happen with the planners' bounds; never silent)
 };
 
@@ -74,10 +75,9 @@ template <int LANES, int CPL> __global__ void extd2_team_finish_kernel(DpBatch B
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 // lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips
 // A team = PSVR_DP_TEAM_LANES lanes, each with PSVR_DP_TEAM_CPL target columns of a strip in registers (strip width = their product).
-// 4 x 4 was the first shape; 2 x 8 keeps the 16-column strips (same share of ramp slots) but spends a step's fixed cost -- neighbour
-// exchange, boundary records, per-diagonal maximum, query window: ~100 of a step's ~245 vector instructions -- on eight cells instead
-// of four, and puts 32 alignments in a wavefront (the one-lane-per-alignment passes behind the sweep use twice the lanes).
-// (2 x 4, 8-column strips: fewer ramp slots but twice the strips, 5.7 vs 4.9 ms when it was tried.)
+// 4 x 4 was the first shape; 2 x 8 keeps the 16-column strips but spends a step's fixed cost -- neighbour exchange, boundary records,
+// per-diagonal maximum -- on eight cells instead of four, and puts 32 alignments in a wavefront.  Other shapes of the row sweep on the
+// bench batch (profiles/r03e_team_kernel_row_sweep.txt): 1 x 16 at two wavefronts per SIMD as fast, 4 x 4 and 4 x 8 slower.
 #ifndef PSVR_DP_TEAM_LANES
 #define PSVR_DP_TEAM_LANES 2
 #endif

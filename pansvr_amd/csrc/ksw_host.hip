@@ -168,7 +168,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	PSVR_HIP(pl->d_poff.alloc(n * 8));
 	PSVR_HIP(pl->d_qlen.alloc(n * 4));
 	PSVR_HIP(pl->d_tlen.alloc(n * 4));
-	PSVR_HIP(pl->d_wstop.alloc(16));      // scratch top (8 B) + error flag (4 B)
+	PSVR_HIP(pl->d_wstop.alloc(16));      // the error flag (4 B, at offset 8)
 	if (n) {
 		PSVR_HIP(hipMemcpy(pl->d_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
 		PSVR_HIP(hipMemcpy(pl->d_poff.p, poff.data(), n * 8, hipMemcpyHostToDevice));
@@ -205,7 +205,7 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 	B.tseq = d_tseq, B.t_off = d_t_off, B.tlen = pl->d_tlen.as<int32_t>();
 	B.ez = d_ez, B.cigar = d_cigar;
 	B.pslab = (uint8_t *)d_work, B.p_off = pl->d_poff.as<int64_t>(), B.p_unit_shift = 0;
-	B.ws = (uint8_t *)d_work + ((pl->pslab_bytes + 255) & ~(int64_t)255), B.ws_top = pl->d_wstop.as<unsigned long long>(), B.ws_cap = (unsigned long long)pl->ws_bytes;
+	B.ws = (uint8_t *)d_work + ((pl->pslab_bytes + 255) & ~(int64_t)255), B.ws_cap = (unsigned long long)pl->ws_bytes;
 	B.err = (int *)(pl->d_wstop.as<unsigned long long>() + 1);
 	PSVR_HIP(hipMemsetAsync(pl->d_wstop.p, 0, 16, stream));
 	TeamLaunch team;
