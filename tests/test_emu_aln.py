@@ -106,3 +106,29 @@ def test_fastq_reader_edge_cases(emu, variant):
     got = [normalise(l) for l in out.split("\n") if l.strip()]
     want = [normalise(l) for l in ac.golden_lines("fx1", "reads150")[:n_keep]]
     assert got == want
+
+
+@pytest.mark.parametrize("name,rname", [c for c in CASES if c in (("fx1", "reads150"), ("fx3", "lower"), ("fx2", "reads150"), ("fx5", "hicopy"))])
+def test_rebase_equals_a_run_from_the_new_position(emu, name, rname):
+    """A shard that ran from one place in the rand() / random_r streams and is moved to another (psvr_engine_rebase: what a rank of the
+    multi-GPU path does when the ranks before it have reported their draws) must hold exactly the records -- and end exactly where -- a
+    run from the new place does.  Several distances, so that pairs with N bases meet residues that select the variant slot they carry
+    already as well as other ones (the adoption rules of engine_core.h), and tie draws fall on other values."""
+    w = ac.workdir(name)
+    base = [emu, ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--trace"]
+
+    def run(extra):
+        r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        end = [l for l in r.stderr.decode().split("\n") if "stream_end" in l][-1]
+        return [normalise(l) for l in r.stdout.decode().split("\n") if l.strip()], end
+
+    places = ((3, 0, 0), (2 + 1000, 0, 0), (2 + 12345, 7, 5), (2 + 400000, 0, 3))
+    if name == "fx5":                                  # (a run of the high-copy set takes a minute on the CPU: the one place that moves all three streams)
+        places = places[2:3]
+    for g, h0, h1 in places:
+        pos = "%d,%d,%d" % (g, h0, h1)
+        want, want_end = run(["--stream-pos", pos])
+        got, got_end = run(["--stream-pos", pos, "--rebase-from", "2,0,0"])
+        assert got_end == want_end, (pos, got_end, want_end)
+        bad = [i for i, (a, b) in enumerate(zip(want, got)) if a != b]
+        assert len(got) == len(want) and not bad, "%s: %d pairs differ after the rebase, first %d:\nrun:    %s\nrebase: %s" % (pos, len(bad), bad[0], want[bad[0]], got[bad[0]])
