@@ -94,3 +94,38 @@ def test_three_rank_sharding_on_the_engine_equals_one_engine():
             detail = "cigar words differ only" if not bad else "first of %d reads: %d (pair %d) one=%r shard=%r" % (len(bad), bad[0], lo + bad[0] // 2, ra[bad[0]], rb[bad[0]])
             raise AssertionError("read records of rank %d differ: %s" % (r, detail))
     eng.close(), index.close()
+
+
+def test_rebase_equals_a_run_from_the_new_position():
+    """One engine, no exchange: a batch that ran from [2, 0, 0] and is moved (psvr_engine_rebase) must hold what a run from the new
+    position holds, and end where it ends -- at several distances, so that the N pairs (3 % of the reads here) meet residues that select
+    the variant slot they carry already as well as other ones, and with no pair evaluated in full again by the rebase
+    (`pair_runs`: the adoption / re-selection / pairing-only paths of engine_core.h carry it)."""
+    from pansvr_amd import aln
+    ix, bases, base_off, ori = _setup()
+    index = aln.Index(ix, ["chr1", "chr2"], device=0)
+    eng = aln.Engine(index, aln.default_params((150, 200, 400, 600)))
+    eng.upload(bases, base_off, ori)
+
+    def records():
+        reads, pairs, cig = eng.download()
+        r = reads.copy()
+        for fld in ("seed_hash", "chain_hash", "n_seed"):
+            r[fld] = 0
+        return canon(r, cig), pairs.tobytes(), eng.stream_end()
+
+    for pos in ([3, 0, 0], [2 + 1000, 0, 0], [2 + 123457, 5, 3], [2 + 40000, 0, 0]):
+        eng.set_stream_pos(pos)
+        eng.run()
+        want = records()
+        eng.set_stream_pos([2, 0, 0])
+        eng.run()
+        runs = eng.stats()["pair_runs"]
+        eng.rebase(pos)
+        got = records()
+        assert got[2] == want[2], (pos, got[2], want[2])
+        assert got[1] == want[1], "pairing records differ after the rebase to %r" % (pos,)
+        assert got[0] == want[0], "read records differ after the rebase to %r" % (pos,)
+        if pos[1] == 0 and pos[2] == 0:                      # (a moved random_r stream sends the reads that sampled positions through in full)
+            assert eng.stats()["pair_runs"] == runs, (pos, eng.stats()["pair_runs"], runs)
+    eng.close(), index.close()
