@@ -89,7 +89,8 @@ __host__ __device__ inline int dp_team_lanes(int n_strips16) { return PSVR_DP_TE
 __host__ __device__ inline unsigned long long dp_team_ws_bytes(int qmax, int n_strips16, int lanes, int cpl = PSVR_DP_TEAM_CPL)
 {
 	const int sw = cpl * lanes, pb = 64 / lanes, n_strips = (n_strips16 * 16 + sw - 1) / sw;
-	// direction bytes (one per cell, 64 x cpl per step), then per diagonal and alignment: two boundary dwords (ping-pong) + D, D2, D3
+	// direction bytes (one per cell, 64 x cpl per step), then per row / diagonal and alignment: two boundary dwords (ping-pong), the key D and the
+	// dword with the two band-end values (16 bytes; sized for 20: a fifth dword per diagonal is head-room, not used)
 	return (unsigned long long)(64 * cpl) * n_strips * (qmax + sw - 1) + (unsigned long long)pb * 20 * (qmax + sw * n_strips + 1);
 }
 

@@ -541,9 +541,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 	// (8 bytes) and the per-diagonal records D, D2, D3 (4 bytes) of diagonal r at [r * PB + team].
 	// (a boundary record is one dword: v, x, x2 are multiples of 8 plus a constant tag and fit int8 once divided, see the step)
 	uint8_t *const uE0 = w0 + offE, *const uE1 = w0 + offE + (size_t)4 * PB * NR;
-	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
+	// per anti-diagonal r: the maximum's key D[r] (a dword the first lane reads, folds and writes back) and, in one dword of a second array,
+	// H at the band's end (low half) and in the last row (high half) as int16, each stored once by the lane that owns the cell
+	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD23 = uD + (size_t)4 * PB * NR;
 	const unsigned lc = (unsigned)CPL * (unsigned)lane, t4 = 4u * (unsigned)team;
 	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
+	auto atD2 = [=](int r) -> short & { return *(short *)(uD23 + (size_t)r * (4 * PB) + t4); };
+	auto atD3 = [=](int r) -> short & { return *(short *)(uD23 + (size_t)r * (4 * PB) + t4 + 2); };
 	const uint8_t *query = B.qseq + B.q_off[pid], *target = B.tseq + B.t_off[pid];
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	// All difference values are kept times 8, and the five candidates of a cell carry their priority in the low three bits
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpPara
 	if (P.skip || bad_shape || base + need > B.ws_cap) { write_ez(out, ez, 0); return; }
 	uint8_t *w0 = B.ws + base;
 	const size_t offE = (size_t)(64 * CPL) * n_strips * R;
-	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD2 = uD + (size_t)4 * PB * NR, *const uD3 = uD2 + (size_t)4 * PB * NR;
+	uint8_t *const uD = w0 + offE + (size_t)8 * PB * NR, *const uD23 = uD + (size_t)4 * PB * NR;   // key; H at the band's end | in the last row << 16
 	const unsigned t4 = 4u * (unsigned)team;
 	auto at4 = [=](uint8_t *ub, int r) -> int & { return *(int *)(ub + (size_t)r * (4 * PB) + t4); };
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
@@ -696,7 +700,8 @@ __global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpPara
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
 			const int r = min(r0 + u, n_rows - 1);
-			kd[u] = at4(uD, r), h2[u] = at4(uD2, r), h3[u] = at4(uD3, r);   // D3 holds a value only where the last query row meets the diagonal
+			const int w23 = at4(uD23, r);
+			kd[u] = at4(uD, r), h2[u] = (int)(short)(w23 & 0xffff), h3[u] = w23 >> 16;   // the high half holds a value only where the last query row meets the diagonal
 		}
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
