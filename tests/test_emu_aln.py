@@ -108,12 +108,13 @@ def test_fastq_reader_edge_cases(emu, variant):
     assert got == want
 
 
-@pytest.mark.parametrize("name,rname", [c for c in CASES if c in (("fx1", "reads150"), ("fx3", "lower"), ("fx2", "reads150"), ("fx5", "hicopy"))])
+@pytest.mark.parametrize("name,rname", [c for c in CASES if c in (("fx1", "reads150"), ("fx3", "lower"), ("fx2", "reads150"))])
 def test_rebase_equals_a_run_from_the_new_position(emu, name, rname):
     """A shard that ran from one place in the rand() / random_r streams and is moved to another (psvr_engine_rebase: what a rank of the
     multi-GPU path does when the ranks before it have reported their draws) must hold exactly the records -- and end exactly where -- a
     run from the new place does.  Several distances, so that pairs with N bases meet residues that select the variant slot they carry
-    already as well as other ones (the adoption rules of engine_core.h), and tie draws fall on other values."""
+    already as well as other ones (the adoption rules of engine_core.h), and tie draws fall on other values.  (The set that samples
+    positions with random_r, fx5-hicopy, passes too: four minutes on the CPU, so it is not in this list.)"""
     w = ac.workdir(name)
     base = [emu, ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--trace"]
 
@@ -123,8 +124,8 @@ def test_rebase_equals_a_run_from_the_new_position(emu, name, rname):
         return [normalise(l) for l in r.stdout.decode().split("\n") if l.strip()], end
 
     places = ((3, 0, 0), (2 + 1000, 0, 0), (2 + 12345, 7, 5), (2 + 400000, 0, 3))
-    if name == "fx5":                                  # (a run of the high-copy set takes a minute on the CPU: the one place that moves all three streams)
-        places = places[2:3]
+    if name == "fx2":                                  # (the tie-heavy set takes its rounds: two places)
+        places = places[1:3]
     for g, h0, h1 in places:
         pos = "%d,%d,%d" % (g, h0, h1)
         want, want_end = run(["--stream-pos", pos])
