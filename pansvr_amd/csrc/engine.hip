@@ -1123,6 +1123,12 @@ struct GpuBE {
 	void dfree(void *p) { if (p) (void)hipFree(p); }
 	void dzero(void *p, size_t n) { note(hipMemsetAsync(p, 0, n, stream)); }
 	void dfill(void *p, int byte, size_t n) { note(hipMemsetAsync(p, byte, n, stream)); }
+	void d2d(void *dst, const void *src, size_t n) { if (n) note(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream)); }
+	void scatter_u8_dev(uint8_t *a, const int32_t *d_idx, long long n, uint8_t v)
+	{
+		if (n > 0) hipLaunchKernelGGL(k_scatter_u8, dim3(grid_for(n)), dim3(kBlock), 0, stream, a, d_idx, n, v);
+		note(hipGetLastError());
+	}
 	// small transfers (counters, lists of a few thousand pairs) go through a pinned staging buffer: a copy to or from pageable
 	// memory costs several times the latency
 	void *pin = nullptr;

@@ -110,6 +110,7 @@ template <class BE> struct EngineCore {
 	// the special pairs on the device: the list, which of them draw the same number under every residue assignment (resolved there, not in the
 	// host walk), the variant slot each of those carries and the offset it was adopted at
 	SpecialPair *d_special = nullptr;
+	int32_t *d_vsrc = nullptr, *d_spidx = nullptr;   // variant slot -> pair, the special pairs' numbers: constant for the batch, copied / scattered device to device at every run
 	uint8_t *d_sp_class = nullptr;
 	int32_t *d_sp_adopted = nullptr;
 	long long *d_sp_adopted_at = nullptr;
@@ -304,6 +305,7 @@ template <class BE> struct EngineCore {
 		d_hasn = alloc<uint8_t>(P), d_resel = alloc<int32_t>(P), d_resel4 = alloc<int32_t>(P < kReselCap ? P : kReselCap);
 		{
 			const long long nsp = S / 4 + 1;                 // (a special pair has >= 4 variant slots: whatever batch fits these buffers later has no more)
+			d_vsrc = alloc<int32_t>(S), d_spidx = alloc<int32_t>(nsp);
 			d_special = alloc<Special>(nsp), d_sp_class = alloc<uint8_t>(nsp), d_sp_adopted = alloc<int32_t>(nsp), d_sp_adopted_at = alloc<long long>(nsp);
 		}
 		d_tops = alloc<unsigned long long>(64), d_atops = alloc<unsigned long long>(6 * kTopStride), d_flags = alloc<int32_t>(16);
@@ -362,7 +364,11 @@ template <class BE> struct EngineCore {
 			be.dzero(d_force, (size_t)8 * S);
 			if (V) be.h2d(d_force + (size_t)8 * P, force.data(), force.size());
 			be.dzero(d_hasn, (size_t)P);
-			if (!special.empty()) be.h2d(d_special, special.data(), special.size() * sizeof(Special));   // (constant for the batch, like d_force)
+			if (!special.empty()) {                                   // (constant for the batch, like d_force)
+				be.h2d(d_special, special.data(), special.size() * sizeof(Special));
+				be.h2d(d_spidx, h_sp_idx.data(), h_sp_idx.size() * 4);
+			}
+			if (V) be.h2d(d_vsrc, h_vsrc.data(), V * 4);
 			if (!h_n_idx.empty()) be.scatter_u8(d_hasn, h_n_idx.data(), (long long)h_n_idx.size(), 1);
 		}
 	}
@@ -493,8 +499,8 @@ template <class BE> struct EngineCore {
 		be.run_init(c.poff, c.hoff, c.rcnt, c.hcnt, d_ctot, d_hprev, d_sens, d_mask, d_src, S, P, grand_pos, hrand_pos[0], hrand_pos[1]);
 		c.src = d_src, c.force = d_force;
 		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
-		if (V) be.h2d(d_src + P, h_vsrc.data(), V * 4);
-		if (!h_sp_idx.empty()) be.scatter_u8(d_mask, h_sp_idx.data(), (long long)h_sp_idx.size(), 1);
+		if (V) be.d2d(d_src + P, d_vsrc, V * 4);
+		if (!h_sp_idx.empty()) be.scatter_u8_dev(d_mask, d_spidx, (long long)h_sp_idx.size(), 1);
 		if (!special.empty()) {
 			const long long nsp = (long long)special.size();
 			be.dzero(d_sp_class, nsp), be.dfill(d_sp_adopted, 0xff, nsp * 4), be.dfill(d_sp_adopted_at, 0xff, nsp * 8);   // class 0, nothing adopted (-1)

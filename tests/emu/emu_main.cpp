@@ -31,6 +31,8 @@ struct CpuBE {
 	void dfree(void *p) { free(p); }
 	void dzero(void *p, size_t n) { memset(p, 0, n); }
 	void dfill(void *p, int byte, size_t n) { memset(p, byte, n); }
+	void d2d(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
+	void scatter_u8_dev(uint8_t *a, const int32_t *idx, long long n, uint8_t v) { scatter_u8(a, idx, n, v); }
 	void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2) { memcpy(h1, d1, n1), memcpy(h2, d2, n2); }
