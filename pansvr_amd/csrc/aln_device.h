@@ -1593,6 +1593,33 @@ PSVR_HDN inline void adopt_variant(const Ctx &c, long long pair, long long slot,
 	}
 }
 
+// what a run resets before its first round (engine_core.h::run): one launch instead of a dozen fills, copies and memsets of their own
+struct RunInit {
+	long long *poff, *hoff;
+	int32_t *rcnt, *hcnt, *ctot, *hprev, *src;
+	uint8_t *sens, *mask;
+	long long S, P, V, g, h0, h1;
+	const int32_t *vsrc;                 // variant slot -> pair
+	const int32_t *spidx; long long nsp; // the special pairs (masked: the host or k_adopt_auto resolves them)
+	uint8_t *sp_class; int32_t *sp_adopted; long long *sp_adopted_at;
+	unsigned long long *tops; int n_tops; unsigned long long *atops; int n_atops; int32_t *flags; unsigned long long *stats;
+	unsigned long long *mem_top; unsigned long long mem0;
+};
+PSVR_HD void run_init_slot(const RunInit &r, long long s)
+{
+	if (s < r.S) {
+		r.poff[s] = r.g, r.hoff[2 * s] = r.h0, r.hoff[2 * s + 1] = r.h1;
+		r.rcnt[3 * s] = 0, r.rcnt[3 * s + 1] = 0, r.rcnt[3 * s + 2] = 0, r.hcnt[2 * s] = 0, r.hcnt[2 * s + 1] = 0, r.ctot[s] = 0, r.hprev[2 * s] = 0, r.hprev[2 * s + 1] = 0;
+		r.src[s] = s >= r.P && s < r.P + r.V ? r.vsrc[s - r.P] : (int32_t)s;
+		if (s < r.P) r.sens[s] = 0, r.mask[s] = 0;
+	}
+	if (s < r.nsp) r.sp_class[s] = 0, r.sp_adopted[s] = -1, r.sp_adopted_at[s] = -1;
+	if (s < r.n_tops) r.tops[s] = 0;
+	if (s < r.n_atops) r.atops[s] = 0;
+	if (s < 16) { r.flags[s] = 0; if (r.stats) r.stats[s] = 0; }
+	if (s == 0) *r.mem_top = r.mem0;
+}
+
 // ---- pairs with N draws whose variant slots make them predictable (engine_core.h) ----
 // A pair with 1..3 N bases was also run once per residue assignment (its "variant slots").  If every variant draws the same number from
 // the stream, the pair's total does not depend on where in the stream it stands: it needs no place in the host's walk, and which variant's

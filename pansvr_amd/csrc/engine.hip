@@ -772,14 +772,9 @@ __global__ __launch_bounds__(kBlock) void k_compact_copy(Ctx c, long long R, con
 		ow += m;
 	}
 }
-__global__ __launch_bounds__(kBlock) void k_run_init(long long *poff, long long *hoff, int32_t *rcnt, int32_t *hcnt, int32_t *ctot, int32_t *hprev, uint8_t *sens, uint8_t *mask,
-                                                   int32_t *src, long long S, long long P, long long g, long long h0, long long h1)
+__global__ __launch_bounds__(kBlock) void k_run_init(RunInit r)
 {
-	const long long s = blockIdx.x * (long long)kBlock + threadIdx.x;
-	if (s >= S) return;
-	poff[s] = g, hoff[2 * s] = h0, hoff[2 * s + 1] = h1;
-	rcnt[3 * s] = 0, rcnt[3 * s + 1] = 0, rcnt[3 * s + 2] = 0, hcnt[2 * s] = 0, hcnt[2 * s + 1] = 0, ctot[s] = 0, hprev[2 * s] = 0, hprev[2 * s + 1] = 0, src[s] = (int32_t)s;
-	if (s < P) sens[s] = 0, mask[s] = 0;
+	run_init_slot(r, blockIdx.x * (long long)kBlock + threadIdx.x);
 }
 __global__ void k_fill_i64(long long *p, long long n, int stride, int off, long long v)
 {
@@ -1324,10 +1319,12 @@ struct GpuBE {
 #undef PSVR_STAGE
 	DevBuf tmp_idx, tmp_val, tmp_out;
 	void fill_iota(int32_t *p, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, p, 0ll, 0ll, n); }
-	void run_init(long long *poff, long long *hoff, int32_t *rcnt, int32_t *hcnt, int32_t *ctot, int32_t *hprev, uint8_t *sens, uint8_t *mask, int32_t *src,
-	              long long S, long long P, long long g, long long h0, long long h1)
+	void run_init(const RunInit &r)
 	{
-		if (S > 0) hipLaunchKernelGGL(k_run_init, dim3(grid_for(S)), dim3(kBlock), 0, stream, poff, hoff, rcnt, hcnt, ctot, hprev, sens, mask, src, S, P, g, h0, h1);
+		long long n = r.S;
+		for (long long k : {r.nsp, (long long)r.n_tops, (long long)r.n_atops, 16ll}) if (k > n) n = k;
+		hipLaunchKernelGGL(k_run_init, dim3(grid_for(n)), dim3(kBlock), 0, stream, r);
+		note(hipGetLastError());
 	}
 	void append_iota(int32_t *w, long long at, long long start, long long n) { if (n) hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, start, n); }
 	void append_list(int32_t *w, long long at, const int32_t *src, long long n) { if (n) hipLaunchKernelGGL(k_copy_i32, dim3(grid_for(n)), dim3(kBlock), 0, stream, w, at, src, n); }

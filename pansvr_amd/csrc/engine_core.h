@@ -490,21 +490,23 @@ template <class BE> struct EngineCore {
 		if (P == 0) return PSVR_OK;
 		unsigned long long *stats_ptr = c.stats;
 		if (!want_stats) c.stats = nullptr;
-		be.dzero(d_tops, 16 * 8), be.dzero(d_atops, 6 * kTopStride * 8), be.dzero(d_flags, 16 * 4), be.dzero(stats_ptr, 16 * 8);
-		unsigned long long mem0 = (unsigned long long)4 * S * kMemSlot;   // bump region starts behind the per-strand slots
-		be.h2d(c.mem.top, &mem0, 8);
 		if (!upload_rand(total_bases / 64 + 4096, 4096)) { err = "rand table allocation failed"; c.stats = stats_ptr; return PSVR_ERR_NOMEM; }
-		// initial guess: nobody draws.  (One pass over the slots: poff = grand_pos, hoff = the two random_r positions, rcnt = hcnt = ctot = hprev =
-		// sens = mask = 0, src = identity -- a dozen fills and memsets of their own were 0.1 ms of launches per run.)
-		be.run_init(c.poff, c.hoff, c.rcnt, c.hcnt, d_ctot, d_hprev, d_sens, d_mask, d_src, S, P, grand_pos, hrand_pos[0], hrand_pos[1]);
-		c.src = d_src, c.force = d_force;
-		// variant slots (sources and forced residues were prepared by upload(); d_force is constant for the batch)
-		if (V) be.d2d(d_src + P, d_vsrc, V * 4);
-		if (!h_sp_idx.empty()) be.scatter_u8_dev(d_mask, d_spidx, (long long)h_sp_idx.size(), 1);
-		if (!special.empty()) {
-			const long long nsp = (long long)special.size();
-			be.dzero(d_sp_class, nsp), be.dfill(d_sp_adopted, 0xff, nsp * 4), be.dfill(d_sp_adopted_at, 0xff, nsp * 8);   // class 0, nothing adopted (-1)
+		// initial guess: nobody draws.  One pass over the slots: poff = grand_pos, hoff = the two random_r positions, rcnt = hcnt = ctot = hprev =
+		// sens = mask = 0, src = identity (the variant slots: their pair); the special pairs' classes and adoptions; the counters, flags and
+		// statistics; the bump region's start behind the per-strand MEM slots -- a dozen fills, copies and memsets of their own were 0.1 ms per run.
+		{
+			RunInit ri;
+			ri.poff = c.poff, ri.hoff = c.hoff, ri.rcnt = c.rcnt, ri.hcnt = c.hcnt, ri.ctot = d_ctot, ri.hprev = d_hprev, ri.src = d_src, ri.sens = d_sens, ri.mask = d_mask;
+			ri.S = S, ri.P = P, ri.V = V, ri.g = grand_pos, ri.h0 = hrand_pos[0], ri.h1 = hrand_pos[1];
+			ri.vsrc = d_vsrc, ri.spidx = d_spidx, ri.nsp = (long long)special.size();
+			ri.sp_class = d_sp_class, ri.sp_adopted = d_sp_adopted, ri.sp_adopted_at = d_sp_adopted_at;
+			ri.tops = d_tops, ri.n_tops = 16, ri.atops = d_atops, ri.n_atops = 6 * kTopStride, ri.flags = d_flags, ri.stats = stats_ptr;
+			ri.mem_top = c.mem.top, ri.mem0 = (unsigned long long)4 * S * kMemSlot;   // bump region starts behind the per-strand slots
+			be.run_init(ri);
 		}
+		c.src = d_src, c.force = d_force;
+		// (the special pairs are masked after the pass above has cleared every pair's bit)
+		if (!h_sp_idx.empty()) be.scatter_u8_dev(d_mask, d_spidx, (long long)h_sp_idx.size(), 1);
 		h_sp_class.assign(special.size(), 0);
 		dp_done = 0, cw_done = 0, any_h = false;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);

@@ -40,14 +40,11 @@ struct CpuBE {
 	void fill_i64(long long *p, long long n, int stride, int off, long long v) { for (long long i = 0; i < n; ++i) p[off + i * stride] = v; }
 	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
 	void fill_iota(int32_t *p, long long n) { for (long long i = 0; i < n; ++i) p[i] = (int32_t)i; }
-	void run_init(long long *poff, long long *hoff, int32_t *rcnt, int32_t *hcnt, int32_t *ctot, int32_t *hprev, uint8_t *sens, uint8_t *mask, int32_t *src,
-	              long long S, long long P, long long g, long long h0, long long h1)
+	void run_init(const RunInit &r)
 	{
-		for (long long s = 0; s < S; ++s) {
-			poff[s] = g, hoff[2 * s] = h0, hoff[2 * s + 1] = h1;
-			rcnt[3 * s] = rcnt[3 * s + 1] = rcnt[3 * s + 2] = 0, hcnt[2 * s] = hcnt[2 * s + 1] = 0, ctot[s] = 0, hprev[2 * s] = hprev[2 * s + 1] = 0, src[s] = (int32_t)s;
-			if (s < P) sens[s] = 0, mask[s] = 0;
-		}
+		long long n = r.S;
+		for (long long k : {r.nsp, (long long)r.n_tops, (long long)r.n_atops, 16ll}) if (k > n) n = k;
+		for (long long s = 0; s < n; ++s) run_init_slot(r, s);
 	}
 	void append_iota(int32_t *w, long long at, long long start, long long n) { for (long long i = 0; i < n; ++i) w[at + i] = (int32_t)(start + i); }
 	std::vector<int32_t> listed_idx;
