@@ -720,7 +720,7 @@ template <class BE> struct EngineCore {
 				adopt_pair.clear(), adopt_slot.clear();
 			}
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
-			be.dzero(d_tops + 32, 17 * 8), be.dzero(d_tops + 56, 5 * 8);
+			be.dzero(d_tops + 8, 53 * 8);                   // [8..9] the totals counters of k_totals_dev below, [32..] the lists' counters, [60] the adoptions: one fill
 			if (!special.empty()) be.st_adopt_auto(c, d_special, (long long)special.size(), d_sp_class, d_mask, d_noff, d_sp_adopted, d_sp_adopted_at, want_stats ? d_tops + 60 : nullptr);
 			be.st_dirty(c, d_noff, h_scans ? d_nhoff : c.hoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
 			// the pairing-only repeats go out at once (the list's length is on the device; the host reads it below for the totals pass)
@@ -728,7 +728,6 @@ template <class BE> struct EngineCore {
 			pair_done = true;
 			// ... and their totals, which the next round would take first thing: when nothing else is left to run (the usual case) that round
 			// is over with the readback below instead of costing a synchronisation of its own
-			be.dzero(d_tops + 8, 16);
 			be.st_totals_dev(c, d_workp, d_tops + 48, P, d_ctot, d_hprev, d_sens, d_slist, d_tops + 8);
 			pre_tot = true;
 			unsigned long long tops[53];                    // d_tops[8..60]: [0] newly count-sensitive, [1] any count changed, from [24] on the lists' counters, [52] adoptions made on the device
