@@ -719,10 +719,14 @@ __global__ void k_special_class(Ctx c, const SpecialPair *sp, long long n, uint8
 }
 // one wavefront per special pair of class 1 that is still predictable (not count-sensitive): adopt_auto in aln_device.h
 __global__ __launch_bounds__(kBlock) void k_adopt_auto(Ctx c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff,
-                                                       int32_t *adopted, long long *adopted_at, unsigned long long *count)
+                                                       int32_t *adopted, long long *adopted_at, unsigned long long *count, const int32_t *host_pairs, const int32_t *host_slots, long long n_host)
 {
 	const long long i = blockIdx.x * (long long)(kBlock / 64) + (threadIdx.x >> 6);
-	if (i >= n || !cls[i] || mask[sp[i].pair]) return;
+	if (i >= n) {                                                     // behind the special pairs: the adoptions the host's walk decided (pair, slot)
+		if (i - n < n_host) adopt_variant(c, host_pairs[i - n], host_slots[i - n], noff, threadIdx.x & 63, 64);
+		return;
+	}
+	if (!cls[i] || mask[sp[i].pair]) return;
 	const int did = adopt_auto(c, sp[i], noff, adopted + i, adopted_at + i, threadIdx.x & 63, 64);
 	if (count && did && (threadIdx.x & 63) == 0) atomicAdd(count, 1ull);   // (statistics only: 17 k wavefronts on one counter are 0.2 ms, tools/atomic_rate_bench.hip)
 }
@@ -1374,9 +1378,17 @@ struct GpuBE {
 		if (n > 0) hipLaunchKernelGGL(k_special_class, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, sp, n, mask, cls);
 		note(hipGetLastError());
 	}
-	void st_adopt_auto(const Ctx &c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff, int32_t *adopted, long long *adopted_at, unsigned long long *count)
+	// ... and, in the same launch, the adoptions the host's walk decided for the pairs it resolves itself
+	void st_adopt_auto(const Ctx &c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff, int32_t *adopted, long long *adopted_at, unsigned long long *count,
+	                   const int32_t *host_pairs, const int32_t *host_slots, long long n_host)
 	{
-		if (n > 0) hipLaunchKernelGGL(k_adopt_auto, dim3(grid_for(n, kBlock / 64)), dim3(kBlock), 0, stream, c, sp, n, cls, mask, noff, adopted, adopted_at, count);
+		if (n + n_host <= 0) return;
+		if (n_host) {
+			note(tmp_idx.ensure(n_host * 4)), note(tmp_val.ensure(n_host * 4));
+			h2d(tmp_idx.p, host_pairs, n_host * 4), h2d(tmp_val.p, host_slots, n_host * 4);
+		}
+		hipLaunchKernelGGL(k_adopt_auto, dim3(grid_for(n + n_host, kBlock / 64)), dim3(kBlock), 0, stream, c, sp, n, cls, mask, noff, adopted, adopted_at, count,
+		                   (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n_host);
 		note(hipGetLastError());
 	}
 	void st_adopt(const Ctx &c, const int32_t *pairs, const int32_t *slots, long long n, const long long *noff)

@@ -714,14 +714,15 @@ template <class BE> struct EngineCore {
 			if (!listed.empty()) be.scatter_listed_i32(d_ctot, res.data(), (long long)listed.size());   // same indices as gather_listed
 			// new offsets from the totals; which pairs drew from a stale offset?
 			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
-			if (!adopt_pair.empty()) {
-				be.st_adopt(c, adopt_pair.data(), adopt_slot.data(), (long long)adopt_pair.size(), d_noff);
+			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
+			be.dzero(d_tops + 8, 53 * 8);                   // [8..9] the totals counters of k_totals_dev below, [32..] the lists' counters, [60] the adoptions: one fill
+			// adoptions: the special pairs the device resolves, and in the same launch the ones this walk decided
+			if (!special.empty()) {
+				be.st_adopt_auto(c, d_special, (long long)special.size(), d_sp_class, d_mask, d_noff, d_sp_adopted, d_sp_adopted_at, want_stats ? d_tops + 60 : nullptr,
+				                 adopt_pair.data(), adopt_slot.data(), (long long)adopt_pair.size());
 				stats.adopted += (long long)adopt_pair.size();
 				adopt_pair.clear(), adopt_slot.clear();
 			}
-			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
-			be.dzero(d_tops + 8, 53 * 8);                   // [8..9] the totals counters of k_totals_dev below, [32..] the lists' counters, [60] the adoptions: one fill
-			if (!special.empty()) be.st_adopt_auto(c, d_special, (long long)special.size(), d_sp_class, d_mask, d_noff, d_sp_adopted, d_sp_adopted_at, want_stats ? d_tops + 60 : nullptr);
 			be.st_dirty(c, d_noff, h_scans ? d_nhoff : c.hoff, d_work, d_tops + 32, d_workp, d_tops + 48, d_hasn, d_resel, d_tops + 56, P < kReselCap ? P : kReselCap, d_resel4, d_tops + 57);
 			// the pairing-only repeats go out at once (the list's length is on the device; the host reads it below for the totals pass)
 			be.st_pair_dev(c, d_workp, d_tops + 48);

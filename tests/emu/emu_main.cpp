@@ -62,8 +62,10 @@ struct CpuBE {
 	{
 		for (long long i = 0; i < n; ++i) { cls[i] = (uint8_t)special_is_const(c, sp[i]); if (cls[i]) mask[sp[i].pair] = 0; }
 	}
-	void st_adopt_auto(const Ctx &c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff, int32_t *adopted, long long *adopted_at, unsigned long long *count)
+	void st_adopt_auto(const Ctx &c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff, int32_t *adopted, long long *adopted_at, unsigned long long *count,
+	                   const int32_t *host_pairs, const int32_t *host_slots, long long n_host)
 	{
+		st_adopt(c, host_pairs, host_slots, n_host, noff);
 		for (long long i = 0; i < n; ++i) if (cls[i] && !mask[sp[i].pair]) { const int did = adopt_auto(c, sp[i], noff, adopted + i, adopted_at + i, 0, 1); if (count) *count += (unsigned long long)did; }
 	}
 	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n) { for (long long i = 0; i < n; ++i) a[listed_idx[i]] = val[i]; }
