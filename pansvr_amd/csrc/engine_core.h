@@ -474,7 +474,31 @@ template <class BE> struct EngineCore {
 	std::vector<int32_t> w_listed, w_cur_tot, w_res;    // scratch of the host offset walk, kept across iterations
 	std::vector<long long> w_pre, w_cur_off;
 	std::vector<int32_t> h_vsrc, h_sp_idx;            // variant slot -> pair; pairs with variant slots (built by upload())
-	std::vector<int32_t> vcnt;                        // per variant slot: c1, c2, c3
+	// per variant slot: c1, c2, c3 -- read back once per batch (1 MB on the bench batch); a plain buffer: a vector's resize() would zero what the
+	// readback overwrites
+	struct HostTable {
+		int32_t *p = nullptr;
+		size_t n = 0, cap = 0;
+		bool empty() const { return n == 0; }
+		void clear() { n = 0; }
+		int32_t *data() { return p; }
+		const int32_t &operator[](size_t i) const { return p[i]; }
+		bool resize(size_t want)
+		{
+			if (want > cap) {
+				free(p);
+				cap = want + want / 4 + 1024;
+				p = (int32_t *)malloc(cap * sizeof(int32_t));
+				if (!p) { cap = n = 0; return false; }
+			}
+			n = want;
+			return true;
+		}
+		~HostTable() { free(p); }
+		HostTable() = default;
+		HostTable(const HostTable &) = delete;
+		HostTable &operator=(const HostTable &) = delete;
+	} vcnt;
 	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
 	std::vector<char> is_special;                     // a special pair whose prediction failed falls back to the window method
 	std::vector<int32_t> adopted, adopt_pair, adopt_slot;   // per special pair: the variant slot whose records it carries (-1 none); this walk's new adoptions
@@ -596,7 +620,7 @@ template <class BE> struct EngineCore {
 			pre_tot = false;
 			unsigned long long nnew_chg[2] = {0, 0};           // newly count-sensitive pairs; did any evaluated slot draw a different number than last time?
 			const bool want_vcnt = vcnt.empty() && V && work == nullptr;   // the variant slots' draw counts ride on the same synchronisation
-			if (want_vcnt) vcnt.resize(3 * V);
+			if (want_vcnt && !vcnt.resize((size_t)3 * V)) { err = "host allocation failed (variant table)"; rc = PSVR_ERR_NOMEM; break; }
 			if (work == nullptr && nshadow == 0) {
 				// first round: which pairs the host walk below looks at is known already (unless a pair turns out count-sensitive just now:
 				// then once more), so the offset scans and the gather go out behind the totals and ONE synchronisation brings everything
