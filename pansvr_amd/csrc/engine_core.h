@@ -739,7 +739,7 @@ template <class BE> struct EngineCore {
 			// new offsets from the totals; which pairs drew from a stale offset?
 			be.st_scan(d_ctot, P, 1, 0, grand_pos, d_noff);
 			// (the two list counters in cache lines of their own: d_tops[32], d_tops[48])
-			be.dzero(d_tops + 8, 53 * 8);                   // [8..9] the totals counters of k_totals_dev below, [32..] the lists' counters, [60] the adoptions: one fill
+			be.dzero(d_tops + 8, 56 * 8);                   // [8..9] the totals counters of k_totals_dev below, [32..] the lists' counters, [60] the adoptions: one fill (to the buffer's end: a size the runtime does not split)
 			// adoptions: the special pairs the device resolves, and in the same launch the ones this walk decided
 			if (!special.empty()) {
 				be.st_adopt_auto(c, d_special, (long long)special.size(), d_sp_class, d_mask, d_noff, d_sp_adopted, d_sp_adopted_at, want_stats ? d_tops + 60 : nullptr,
