@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 // end-score rules need per ANTI-DIAGONAL -- the maximum with the reference's tie order, H at the band ends -- is collected
 // on the way: a diagonal passes a lane's columns from right to left, one column per row, so its running maximum rides in
 // a register that moves one column left per step (M[], with the diagonal's tail threshold in K[]), hops to the left
-// neighbour through DPP and is folded into D[r] by the team's first lane; D2[r], D3[r] (H in the top row / last column /
+// neighbour through DPP and is folded into D[r] by the team's first lane; the int16 halves of D23[r] (H in the top row / last column /
 // last row) are stored by the lane that owns the cell.  extd2_team_finish_kernel evaluates the rules in anti-diagonal order
 // afterwards; diagonals past a z-drop are computed but never looked at.  Direction bytes: CPL per lane and step.  Scratch
 // is laid out [index][lane or team] so a wavefront touches consecutive addresses; a wavefront's slice is sized by the
