@@ -42,8 +42,8 @@ def align_seconds(err, key="ALIGN_SECONDS"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU (configs[1]: 1 M)")
     ap.add_argument("--anchors", type=int, default=10000)
     ap.add_argument("--cpu-pairs", type=int, default=300000, help="pairs of the CPU-baseline sample (0 = skip)")
