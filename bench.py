@@ -33,10 +33,90 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HEADER = "@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n"
+# The team DP kernel's cell update as compiled (pansvr_amd/csrc/ksw_row_step.inc; profiles/r03e_sq_counters.md: 99 323 vector instructions per
+# wavefront for 2 112 cells per lane-step mix = 47 per cell), priced with profiles/r01j_valu_op_rates.txt at ~3.0 SIMD-cycles per instruction
+DP_OWN_CYCLES = 47 * 3.0
 
 
 def align_seconds(err, key="ALIGN_SECONDS"):
     return max(float([l for l in err.split("\n") if l.startswith(key)][-1].split()[1]), 1e-9)
+
+
+def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
+    """The rate a caller of the public C ABI sustains when it overlaps the three steps of a batch the way the reference's kt_pipeline
+    overlaps load / align / write (src/clib/kthread.c:157-197): `slots` job slots, each an engine of its own on its own HIP queue,
+    driven by its own host thread -- upload(N+1) | run(N) | download_compact(N-1).  The runs themselves are a chain (batch N+1 starts in
+    the rand() / random_r streams where batch N ended), everything else overlaps.  All buffers are page-locked (psvr_host_alloc) and
+    allocated, touched and sized before the clock starts.  Returns the timing and, per batch, a checksum of the downloaded records,
+    which the caller compares with the serial path's."""
+    import threading
+    import zlib
+    pb, po, pr = pin_in
+    engs = [aln.Engine(index, params) for _ in range(slots)]
+    outs = [aln.HostBuffers() for _ in range(n_batches)]
+    state = {"turn": 0, "pos": [2, 0, 0], "err": None}
+    cv = threading.Condition()
+    res = [None] * n_batches
+    # warm-up: every slot's engine allocates its buffers, every output buffer set is allocated and touched by one transfer
+    for e in engs:
+        e.upload(pb, po, pr)
+        e.set_stream_pos([2, 0, 0])
+        e.run()
+    for k in range(n_batches):
+        engs[k % slots].download_compact(outs[k])
+
+    def worker(s):
+        try:
+            for k in range(s, n_batches, slots):
+                e = engs[s]
+                e.upload(pb, po, pr)
+                with cv:
+                    while state["turn"] != k and state["err"] is None:
+                        cv.wait()
+                    if state["err"] is not None:
+                        return
+                    pos = list(state["pos"])
+                e.set_stream_pos(pos)
+                e.run()
+                end = e.stream_end()
+                with cv:
+                    state["pos"], state["turn"] = end, k + 1
+                    cv.notify_all()
+                res[k] = e.download_compact(outs[k])
+        except Exception as ex:          # noqa: BLE001 -- surfaced below
+            with cv:
+                state["err"] = ex
+                cv.notify_all()
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(slots)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    if state["err"] is not None:
+        for e in engs:
+            e.close()
+        raise state["err"]
+    sums = [zlib.crc32(b"".join(a.tobytes() for a in r)) for r in res]
+    # the serial path through the same entry points: one engine, batch after batch
+    e = engs[0]
+    pos, serial = [2, 0, 0], []
+    hb = aln.HostBuffers()
+    ts = time.time()
+    for k in range(n_batches):
+        e.upload(pb, po, pr)
+        e.set_stream_pos(pos)
+        e.run()
+        pos = e.stream_end()
+        serial.append(zlib.crc32(b"".join(a.tobytes() for a in e.download_compact(hb))))
+    ts = time.time() - ts
+    for x in engs:
+        x.close()
+    for o in outs:
+        o.close()
+    hb.close()
+    return dt, sums, serial, ts
 
 
 def main():
@@ -50,11 +130,14 @@ def main():
     ap.add_argument("--check-pairs", type=int, default=50000, help="pairs per rank whose engine records are compared with the reference objects")
     ap.add_argument("--no-ref-cpu", action="store_true", help="time only the oracle port even if oracle/_ref/ref_aln is present")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `panSVR aln` leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the overlapped-ABI leg (pcie_inclusive.pipelined)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the configs[4] (250 bp / edge-2000) leg")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("PSVR_BENCH_ENGINES", "1")),
                     help="engines per GPU: the rank's block is cut into that many contiguous sub-blocks, each run by its own engine on its own HIP queue.  Measured on "
                          "configs[1]: 1 engine 12.5 ms/step, 2 engines 16.5, 4 engines 27.6 -- the stages fill the chip by themselves, a second queue only adds the rebase rounds")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU-baseline leg (0 = all cores, capped at the reference's 48)")
+    ap.add_argument("--one-pass", action="store_true", help="profiling runs (rocprofv3 --pmc): the warm-up and timed steps only, none of the extra engine passes (per-kernel timing, "
+                                                            "work counters, PCIe legs, e2e, cfg5): every kernel's counters then belong to exactly warmup + steps passes")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous, rank -> device selection and one barrier only (no GPU is touched): the launch contract, testable on CPU")
     args = ap.parse_args()
 
@@ -68,14 +151,13 @@ def main():
     rehearse = os.environ.get("PSVR_BENCH_REHEARSE") == "1"      # all ranks share GPU 0 and exchange over gloo (single-GPU rehearsal of the N > 1 path)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if not args.dry_run:
-            dist.init_process_group("gloo" if rehearse or not torch.cuda.is_available() else "nccl")
+        # the default group is gloo: the control plane (barriers, agreement on fallbacks) comes up wherever torch.distributed does; the RCCL
+        # plane for the bulk data is created beside it and tried before anything depends on it (pansvr_amd/dist.py::data_plane)
+        dist.init_process_group("gloo")
         if rehearse:
             local_rank = 0
     if args.dry_run:
         # what the driver's launch line must lead to: rank r of the node drives HIP device LOCAL_RANK, chosen before anything touches a GPU
-        if world > 1 and not dist.is_initialized():
-            dist.init_process_group("gloo")
         if world > 1:
             dist.barrier()
         print(json.dumps({"dry_run": True, "rank": rank, "world": world, "local_rank": local_rank, "device": local_rank, "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
@@ -125,7 +207,10 @@ def main():
     t_host = time.time() - t_setup
 
     torch.cuda.set_device(local_rank)
-    xdev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else None
+    from pansvr_amd import dist as pdist
+    # (the one-GPU rehearsal shares a device between the ranks, which RCCL refuses: PSVR_BENCH_REHEARSE_TRY_RCCL=1 tries it all the same --
+    # that is the fallback path of data_plane(), run on purpose)
+    data_pg, xdev, plane_how = pdist.data_plane(world > 1 and (not rehearse or os.environ.get("PSVR_BENCH_REHEARSE_TRY_RCCL") == "1"))
     index_bytes = int(sum(v.nbytes for k, v in ix_arrays.items() if hasattr(v, "nbytes") and k != "hash_sparse"))
     index_bcast, index_how = None, "every rank uploads its own copy from host memory"
     index = None
@@ -150,30 +235,41 @@ def main():
             ok, tens = 0, {}
             print("[bench] rank %d: index broadcast not prepared: %r" % (rank, ex), file=sys.stderr)
         t_index_upload = time.time() - t_up                      # rank 0: the one host upload; others: allocation only
-        flag = torch.tensor([ok], device=xdev or "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # (gloo control plane)
         if int(flag.item()) == 1:
             dist.barrier()
             if xdev:
                 torch.cuda.synchronize()
             tb = time.time()
-            for k in keys:
-                dist.broadcast(tens[k], src=0)
-            if xdev:
-                torch.cuda.synchronize()
-            index_bcast = round((time.time() - tb) * 1e3, 2)
-            if not xdev:
-                tens = {k: v.to("cuda") for k, v in tens.items()}
-                torch.cuda.synchronize()
-            index = aln.Index.from_device_tensors(tens, ix_arrays["chr"], ["chr1", "chr2"], device=local_rank)
-            index_how = "rank 0 uploads, %s broadcast of the eight arrays, every rank builds its index device to device" % ("RCCL" if xdev else "gloo (host copies: one-GPU rehearsal)")
+            try:
+                for k in keys:
+                    dist.broadcast(tens[k], src=0, group=data_pg)
+                if xdev:
+                    torch.cuda.synchronize()
+                index_bcast = round((time.time() - tb) * 1e3, 2)
+                if not xdev:
+                    tens = {k: v.to("cuda") for k, v in tens.items()}
+                    torch.cuda.synchronize()
+                index = aln.Index.from_device_tensors(tens, ix_arrays["chr"], ["chr1", "chr2"], device=local_rank)
+            except Exception as ex:
+                ok, index = 0, None
+                print("[bench] rank %d: index broadcast failed: %r" % (rank, ex), file=sys.stderr)
+            # every rank has its index, or every rank uploads its own (a rank left without one must not be the only one to fall back)
+            flag = torch.tensor([1 if index is not None else 0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                index_how = "rank 0 uploads, %s broadcast of the eight arrays, every rank builds its index device to device" % ("RCCL" if xdev else "gloo (host copies)")
+            else:
+                if index is not None:
+                    index.close()
+                index, index_bcast = None, None
             del tens
     if index is None:
         t_up = time.time()
         index = aln.Index(ix_arrays, ["chr1", "chr2"], device=local_rank)
         t_index_upload = time.time() - t_up
     del ix_arrays
-    from pansvr_amd import dist as pdist
     K = max(1, args.engines)
     cuts = [args.pairs * j // K for j in range(K + 1)]
     engs = []
@@ -193,32 +289,71 @@ def main():
 
     exchange_iters = []
     my_start = [2, 0, 0]
+    phase = {}                                             # seconds per phase of the N > 1 step, summed over the timed steps
+    gather = pdist.BlockGather(xdev, data_pg) if world > 1 else None
+    gathered = None
+
+    def pack(buf):
+        return engs[0].compact_pack(buf.data_ptr(), buf.numel())
 
     def step():
-        nonlocal my_start
+        nonlocal my_start, gathered
         if world == 1 and K == 1:
             engs[0].run()                                  # (a run does not advance the engine's stream position: every step starts at the same place)
             return
         if world == 1:
             group.run_at([2, 0, 0])
             return
-        my_start, _, it = pdist.resolve_stream_order([2, 0, 0], group.run_at, group.rebase_to, device=xdev)
+        my_start, _, it = pdist.resolve_stream_order([2, 0, 0], group.run_at, group.rebase_to, device=xdev, group=data_pg, times=phase)
         exchange_iters.append(it)
+        # the ordered gather (the reference's output_results): every rank's block of compact records -> rank 0, in block order
+        if K == 1:
+            tg = time.time()
+            nc, nw = engs[0].compact_sizes()
+            gathered = gather.gather(aln.Engine.compact_layout(args.pairs, nc, nw)[4], pack)
+            phase["gather"] = phase.get("gather", 0.0) + (time.time() - tg)
 
     for _ in range(args.warmup):
         step()
     barrier()
+    phase.clear()
+    del exchange_iters[:]
     t0 = time.time()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], device=xdev or "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([dt])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)            # (gloo control plane)
         dt = float(t.item())
+    # what rank 0 holds after the last step's gather must be the ranks' own blocks, in rank order: every rank sums its block as 64-bit
+    # words, rank 0 sums what it received (checker, outside the timed region)
+    gather_check = None
+    if world > 1 and K == 1:
+        def words_sum(t, n):
+            return int(t[:n - n % 8].view(torch.int64).sum().item())
+        own = pdist.all_gather_i64([words_sum(gather.mine, gather.sizes[rank]), gather.sizes[rank]], xdev, data_pg)
+        if rank == 0:
+            bad = [r for r, (buf, n, meta) in enumerate(gathered) if n != own[r][1] or words_sum(buf, n) != own[r][0] or meta[0] != args.pairs]
+            gather_check = {"blocks": world, "bytes": int(sum(n for _, n, _ in gathered)), "blocks_differing": len(bad)}
     reads_per_step = 2 * args.pairs * world
     value = reads_per_step * args.steps / dt
+
+    if args.one_pass:
+        if rank == 0:
+            print(json.dumps({"one_pass": True, "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "engine_passes": args.steps + args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3)}), flush=True)
+        for e in engs:
+            e.close()
+        index.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        shutil.rmtree(tmp, ignore_errors=True)
+        if world > 1 and local_rank == 0:
+            shutil.rmtree(idx_dir, ignore_errors=True)
+        return
 
     # ---- every rank's block against the reference objects, started where the block starts in the draw streams (checker only)
     parity_local = None
@@ -253,7 +388,7 @@ def main():
             parity_local = [n_chk, sum(1 for i in range(n_chk) if got[i] != want[i]), against]
     parity = None
     if world > 1:
-        cnt = pdist.all_gather_i64([parity_local[0] if parity_local else 0, parity_local[1] if parity_local else 0], xdev)
+        cnt = pdist.all_gather_i64([parity_local[0] if parity_local else 0, parity_local[1] if parity_local else 0], xdev, data_pg)
         if rank == 0:
             parity = {"pairs_checked": sum(c[0] for c in cnt), "pairs_differing": sum(c[1] for c in cnt), "ranks_checked": sum(1 for c in cnt if c[0]),
                       "against": parity_local[2] if parity_local else None, "per_rank": cnt}
@@ -302,11 +437,23 @@ def main():
     eng.download_compact(hb)
     tp = time.time() - tp
     pcie["page_locked"] = {"reads_per_s": round(2 * args.pairs / tp, 1), "ms": round(tp * 1e3, 2)}
-    hb.close(), pin_in.close()
+    hb.close()
+    if rank == 0 and world == 1 and not args.no_pipeline:
+        # ... and the overlapped rate: three job slots, upload(N+1) | run(N) | download_compact(N-1) through the same entry points
+        try:
+            nb = 8
+            pdt, psums, ssums, sdt = pipelined_abi(aln, index, aln.default_params((150, 200, 400, 600)), (pb, po, pr), n_batches=nb, slots=3)
+            pcie["pipelined"] = {"reads_per_s": round(2 * args.pairs * nb / pdt, 1), "ms_per_batch": round(pdt / nb * 1e3, 2), "batches": nb, "slots": 3,
+                                 "equal_to_serial": psums == ssums, "serial_ms_per_batch_incl_checksum": round(sdt / nb * 1e3, 2),
+                                 "note": "8 batches of the bench batch back to back (the draw streams continue from batch to batch), 3 engines on their own HIP queues driven by 3 host threads: "
+                                         "upload(N+1) | run(N) | download_compact(N-1); page-locked buffers allocated and touched before the clock starts; the records of every batch == the serial path's (crc32)"}
+        except Exception as ex:          # noqa: BLE001
+            pcie["pipelined"] = {"error": repr(ex)[:300]}
+    pin_in.close()
 
     roofline, cpu, e2e = None, None, None
     if rank == 0:
-        bytes_per_read, seed_bytes_per_read, own_bytes = None, None, None
+        bytes_per_read, own_bytes = None, None
         base = [idx_dir, fq, os.path.join(tmp, "header.sam")]
         if n_cpu > 0:
             # algorithmic bytes per read, counted by the oracle on a part of the CPU sample; the executables report the
@@ -316,7 +463,6 @@ def main():
             r = subprocess.run([exe] + base + ["--stats", "--limit", str(n_port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
             cs = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
             bytes_per_read = cs["bytes"]["total"] / (2.0 * n_port)
-            seed_bytes_per_read = (cs["bytes"]["probe"] + cs["bytes"]["hit"] + cs["bytes"]["read"]) / (2.0 * n_port)
             # each kernel's OWN share of the algorithmic bytes (SURVEY 8(d) terms, per read): bases in -> prep; hash probes + MEM hits -> seeding;
             # unipath positions -> chaining; reference windows -> walk + fetch; ksw_extz_t + CIGAR out -> the DP kernels; candidate records -> assembly + tails
             b = {k: v / (2.0 * n_port) for k, v in cs["bytes"].items()}
@@ -338,55 +484,81 @@ def main():
                        "sample": "first %d pairs of the same workload through the reference's own fc_aln objects (oracle/_ref/ref_aln: read_realignment / deBGA_index / graph / "
                                  "ksw2_extd2_sse / htslib sam_parse1, compiled from the reference tree): `value` = the reference's kt_for over align_read_pair (incl. output_BAM) at -t %d, "
                                  "value_1_thread the same at -t 1; port_value = oracle/aln_oracle on %d pairs" % (n_cpu, nt, n_port)}
+        # which term of the algorithmic bytes each timed kernel owns
+        groups = {"k_prep": ["k_prep"], "k_seed": ["k_seed"], "k_chain": ["k_chain", "k_chain_select"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
+                  "k_assemble+k_finalize_pair": ["k_assemble", "k_finalize_pair"], "extd2_*": [k for k in kern if k.startswith("extd2_")]}
+        group_of = {k: g for g, names in groups.items() for k in names}
         launches = max(1, kern[dom]["launches"])
         avg_ms = kern[dom]["ms"] / launches
-        share = {"k_seed": seed_bytes_per_read}.get(dom, bytes_per_read)
-        # HBM-side traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/pmc_latest.json, written by tools/pmc_to_json.py; FETCH_SIZE/WRITE_SIZE are KiB per dispatch)
-        traffic = None
+        # HBM-side traffic per kernel from the committed rocprofv3 --pmc passes of this same command on the tree named in the file
+        # (profiles/pmc_latest.json, written by tools/pmc_to_json.py; FETCH_SIZE / WRITE_SIZE are KiB per dispatch)
+        pmc, pmc_src = {}, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            want_k = dom.replace(",hbm>", ", true>").replace(",lds>", ", false>")
-            kd = pj["kernels"].get(want_k) or next((v for k, v in pj["kernels"].items() if k.split("<")[0] == want_k), None)
-            if kd and pj.get("pairs_per_gpu") == args.pairs:
-                traffic = int((kd["fetch_KiB_per_step"] + kd["write_KiB_per_step"]) * 1024)
+            if pj.get("pairs_per_gpu") == args.pairs:
+                for k, v in pj["kernels"].items():
+                    b = k.split("<")[0]
+                    pmc[b] = pmc.get(b, 0) + int((v["fetch_KiB_per_step"] + v["write_KiB_per_step"]) * 1024)
+                pmc_src = "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s`, tree %s)" % (pj.get("command", "bench.py --one-pass"), pj.get("commit", "?"))
         except Exception:
-            traffic = None
-        if share is not None:
-            # first launch of the dominant kernel covers all 2P reads of the batch; later (speculative) launches cover few
-            alg_bytes = share * 2 * args.pairs
-            achieved = alg_bytes / (kern[dom]["ms"] * 1e-3) / 1e9
-            step_ms = dt / args.steps * 1e3
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
-                        "traffic": traffic, "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (KiB*1024) per step from profiles/pmc_latest.json (rocprofv3 --pmc passes of this command, committed); gfx950 FETCH_SIZE under-reports coalesced reads by up to 2x", "alg_bytes_per_read": round(share, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
-                        "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
-                        "whole_step": {"achieved": round(bytes_per_read * 2 * args.pairs / (step_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
-                                       "note": "the whole path's algorithmic bytes over the whole step (per GPU), for scale: the step is latency / issue bound"}}
+            pmc = {}
+
+        def traffic_of(names):
+            t = [pmc[b] for b in set(n.split("<")[0] for n in names) if b in pmc]
+            return int(sum(t)) if t else None
+        if own_bytes is not None:
+            # The dominant kernel's roofline: ITS OWN algorithmic bytes (the term of SURVEY 8(d)'s sum it is responsible for) x the reads one
+            # launch covers / its average launch duration (HIP events on the launch stream, this run).  Reads per launch: a per-mate
+            # kernel (seeding, chaining) covers the P reads of one mate per launch, the others all 2P; the few reads of the re-run rounds
+            # ride in launches that are counted (they lower the average a little, never raise it).
+            g = group_of.get(dom)
+            share = own_bytes.get(g) if g else None
+            if share is not None:
+                alg_bytes = share * 2 * args.pairs                  # per step, all launches of the kernel together
+                achieved = alg_bytes / (kern[dom]["ms"] * 1e-3) / 1e9
+                step_ms = dt / args.steps * 1e3
+                whole = bytes_per_read * 2 * args.pairs / (step_ms * 1e-3) / 1e9
+                tr = traffic_of([dom])
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
+                            "traffic": tr, "traffic_over_algorithmic": round(tr / alg_bytes, 2) if tr else None,
+                            "traffic_note": "raw FETCH_SIZE+WRITE_SIZE (KiB*1024) of this kernel per step; gfx950 FETCH_SIZE under-reports coalesced reads by up to 2x", "traffic_source": pmc_src,
+                            "alg_bytes_per_read": round(share, 1), "alg_bytes_per_launch": round(alg_bytes / launches, 1), "alg_bytes_per_read_whole_path": round(bytes_per_read, 1),
+                            "kernel_ms_per_step": round(kern[dom]["ms"], 4), "kernel_launches_per_step": launches, "avg_launch_ms": round(avg_ms, 4),
+                            "whole_step": {"achieved": round(whole, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(whole / 8000.0, 6), "ms": round(step_ms, 3),
+                                           "traffic": int(sum(pmc.values())) if pmc else None,
+                                           "traffic_over_algorithmic": round(sum(pmc.values()) / (bytes_per_read * 2 * args.pairs), 2) if pmc else None,
+                                           "note": "the whole path's algorithmic bytes over the whole step (per GPU): the step is latency / issue bound"}}
         if roofline is not None and own_bytes is not None:
-            # per-kernel table, measured live (HIP events of the timed pass): own algorithmic bytes, time, GB/s and fraction of the HBM peak; for the
-            # DP kernels also cells/s against the vector-issue bound.  Bound: profiles/r01j_valu_op_rates.txt prices a wavefront instruction at ~2.3
-            # SIMD-cycles (add / sub / logic / right shift / mov) or ~4.2 (max / min / compare / left shift / three-operand / DPP); the cell update of
-            # ksw_team_step.inc is 36 vector instructions (14 of the dearer kind) = ~110 cycles per 64 cells and SIMD, i.e. 1024 SIMDs x 2.4 GHz x 64 / 110.
-            groups = {"k_prep": ["k_prep"], "k_seed": ["k_seed"], "k_chain": ["k_chain", "k_chain_select"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
-                      "k_assemble+k_finalize_pair": ["k_assemble", "k_finalize_pair"], "extd2_*": [k for k in kern if k.startswith("extd2_")]}
-            issue_bound = 1024 * 2.4e9 * 64 / 110.0
+            # per-kernel table, measured live (HIP events of the timed pass): own algorithmic bytes, time, GB/s, fraction of the HBM peak, counter
+            # traffic / algorithmic; for the DP kernels also cells/s against two vector-issue bounds (profiles/r01j_valu_op_rates.txt prices a
+            # wavefront instruction at ~2.3 SIMD-cycles (add / sub / logic / right shift / mov) or ~4.2 (max / min / compare / left shift /
+            # three-operand / DPP / v_pk_*)):
+            #   own stream: the cell update of ksw_row_step.inc as compiled (see DP_INSTR below) -- how close the sweep runs to the price of its own instructions
+            #   recurrence: the dual-affine cell as few instructions as the recurrence allows (2 x max3 for z + direction, 4 state updates of
+            #               add + max, 2 differences, 1 score lookup, 1 H add, 1 direction store share: ~16 instructions, half of the dearer kind)
+            DP_INSTR = {"own_stream_cycles_per_64_cells": DP_OWN_CYCLES, "recurrence_cycles_per_64_cells": 16 * 3.25}
+            issue_bound = 1024 * 2.4e9 * 64 / DP_INSTR["own_stream_cycles_per_64_cells"]
+            issue_bound_min = 1024 * 2.4e9 * 64 / DP_INSTR["recurrence_cycles_per_64_cells"]
             rows = []
             for g, names in groups.items():
                 ms = sum(kern[k]["ms"] for k in names if k in kern)
                 if ms <= 0:
                     continue
                 gbs = own_bytes[g] * 2 * args.pairs / (ms * 1e-3) / 1e9
-                row = {"kernels": g, "own_alg_bytes_per_read": round(own_bytes[g], 1), "ms_per_step": round(ms, 4), "achieved_GBps": round(gbs, 2), "frac_of_hbm_peak": round(gbs / 8000.0, 6)}
+                tr = traffic_of([k for k in names if k in kern])
+                row = {"kernels": g, "own_alg_bytes_per_read": round(own_bytes[g], 1), "ms_per_step": round(ms, 4), "achieved_GBps": round(gbs, 2), "frac_of_hbm_peak": round(gbs / 8000.0, 6),
+                       "traffic": tr, "traffic_over_algorithmic": round(tr / (own_bytes[g] * 2 * args.pairs), 2) if tr and own_bytes[g] > 0 else None}
                 if g == "extd2_*":
                     row["cells_per_s"] = round(st["dp_cells"] / (ms * 1e-3), 1)
                     row["valu_issue_bound_cells_per_s"] = round(issue_bound, 1)
                     row["frac_of_issue_bound"] = round(st["dp_cells"] / (ms * 1e-3) / issue_bound, 4)
+                    row["frac_of_recurrence_bound"] = round(st["dp_cells"] / (ms * 1e-3) / issue_bound_min, 4)
+                    row["issue_model"] = DP_INSTR
                     row["note"] = "sum over all DP launches of a step as if they ran one after the other (timed pass); integer DP is vector-issue bound, the byte fraction says little"
                 rows.append(row)
             rows.append({"kernels": "others (" + ", ".join(sorted(k for k in kern if not any(k in v for v in groups.values()))) + ")",
                          "ms_per_step": round(sum(v["ms"] for k, v in kern.items() if not any(k in n for n in groups.values())), 4), "own_alg_bytes_per_read": 0.0})
             roofline["kernels"] = rows
-            roofline["traffic_source"] = "profiles (committed rocprofv3 --pmc passes), not this run"
         # ---- the drop-in command end to end: FASTQ file in, both record files out (index load reported separately)
         if n_e2e:
             cli = os.path.join(ROOT, "pansvr_amd", "bin", "panSVR")
@@ -444,11 +616,22 @@ def main():
                 del cig5
                 cfg5["dp_roofline"] = {"bound": "hbm", "kernels": "all extd2_* launches of a step", "achieved": round(dp_bytes / (dp_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(dp_bytes / (dp_ms * 1e-3) / 1e9 / 8000.0, 6), "alg_bytes": int(dp_bytes), "cells_per_s": round(s5["dp_cells"] / (dp_ms * 1e-3), 1),
-                                       "frac_of_issue_bound": round(s5["dp_cells"] / (dp_ms * 1e-3) / (1024 * 2.4e9 * 64 / 110.0), 4),
-                                       "note": "bytes counted by the engine (sequences in, ksw_extz_t + CIGAR out); integer DP is vector-issue bound: cells/s against 1024 SIMDs x 2.4 GHz x 64 lanes / ~110 cycles per cell update is the figure to watch"}
+                                       "frac_of_issue_bound": round(s5["dp_cells"] / (dp_ms * 1e-3) / (1024 * 2.4e9 * 64 / DP_OWN_CYCLES), 4),
+                                       "frac_of_recurrence_bound": round(s5["dp_cells"] / (dp_ms * 1e-3) / (1024 * 2.4e9 * 64 / (16 * 3.25)), 4),
+                                       "note": "bytes counted by the engine (sequences in, ksw_extz_t + CIGAR out); integer DP is vector-issue bound: cells/s against 1024 SIMDs x 2.4 GHz x 64 lanes / the cycles of a cell update (the kernel's own instruction stream: %.0f; the recurrence's minimum: %.0f) is the figure to watch" % (DP_OWN_CYCLES, 16 * 3.25)}
             eng5.close(), index5.close()
         except Exception as ex:
             cfg5 = {"error": repr(ex)}
+    multi = None
+    if world > 1:
+        # per-step phases of the N > 1 step, the slowest rank's clock for each (rank 0 never rebases; the step itself is max over ranks between barriers)
+        keys = ("run", "rebase", "exchange", "gather")
+        allp = pdist.all_gather_i64([int(phase.get(k, 0.0) * 1e9) for k in keys], xdev, data_pg)
+        per = {k: round(max(r[i] for r in allp) / 1e9 / args.steps * 1e3, 3) for i, k in enumerate(keys)}
+        multi = {"data_plane": plane_how, "run_ms": per.get("run"), "rebase_ms": per.get("rebase", 0.0), "exchange_ms": per.get("exchange"), "gather_ms": per.get("gather"),
+                 "exchange_iters": max(exchange_iters) if exchange_iters else 0, "gather_check": gather_check,
+                 "gather": "every rank's compact records (psvr_engine_download_compact into device memory) -> rank 0, point to point, in block order = input order; inside the timed step" if K == 1 else "not timed with --engines > 1"}
+    failed = bool(parity and parity["pairs_differing"]) or bool(gather_check and gather_check["blocks_differing"])
     if rank == 0:
         line = {"metric": "signal reads realigned/sec (150 bp PE); bit-exact CIGAR vs CPU ref", "value": round(value, 1), "unit": "reads/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -456,13 +639,16 @@ def main():
                 "data": "synthetic", "config": {"workload": "configs[1]: %d synthetic 150 bp PE signal read pairs per GPU vs %d-anchor SV reference (%.1f Mbp), `panSVR aln` hot path"
                                                  % (args.pairs, args.anchors, len(anc["codes"]) / 1e6),
                                                  "pairs_per_gpu": args.pairs, "reads_per_step": reads_per_step,
-                                                 "parallelism": "shard%d x %d engine(s) per GPU (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, K, "none" if world == 1 else "all-gather of 6 int64 per rank over %s, %d per step" % (dist.get_backend(), max(exchange_iters) if exchange_iters else 0)),
+                                                 "parallelism": "shard%d x %d engine(s) per GPU (index replicated, one input cut into contiguous blocks, draw-order exchange: %s)" % (world, K, "none" if world == 1 else "all-gather of 6 int64 per rank over %s, %d per step" % ("RCCL" if xdev else "gloo", max(exchange_iters) if exchange_iters else 0)),
                                                  "engines_per_gpu": K, "in_process_rebases": group_rebases,
                                                  "index_hbm_bytes": index_device_bytes, "index_upload_s": round(t_index_upload, 2), "index_broadcast_ms": index_bcast, "index_distribution": index_how,
                                                  "host_setup_s": round(t_host, 1), "setup_s": round(t_setup, 1)},
-                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,
+                "roofline": roofline, "cpu_baseline": cpu, "parity_check": parity, "multi_gpu": multi, "e2e": e2e, "pcie_inclusive": pcie, "cfg5": cfg5,
                 "engine": {k: st[k] for k in ("rounds", "pair_runs", "pair_only_runs", "shadow_runs", "sensitive_pairs", "window_misses", "adopted_pairs", "dp_problems", "dp_seq_bytes", "stale_open", "candidates", "walk_pairs", "walk_us", "n_special", "special_const", "special_nomove", "probes", "hits", "seeds", "dp_cells", "hbm_used_bytes") if k in st},
                 "kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
+        if failed:
+            # a fast result that differs from the reference's is not a result: the line says so and the run fails
+            line["error"] = "parity check failed: %s" % json.dumps({"parity_check": parity, "gather_check": gather_check})
         print(json.dumps(line), flush=True)
     if eng is not None:
         eng.close(), index.close()
@@ -472,6 +658,8 @@ def main():
     shutil.rmtree(tmp, ignore_errors=True)
     if world > 1 and local_rank == 0:
         shutil.rmtree(idx_dir, ignore_errors=True)
+    if rank == 0 and failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -269,7 +269,10 @@ int psvr_engine_download(psvr_engine_t *eng, psvr_read_result_t *reads, psvr_pai
                          uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used);
 /* Compact form of the same results: hdr[2*n_pairs], pairs[n_pairs], then only the candidates and CIGAR words that exist,
  * densely packed in read order (cands[k].cigar_off indexes `cigar`).  Call with cands == NULL (or cigar == NULL) to learn
- * cand_used / cigar_used first; PSVR_ERR_OVERFLOW if a capacity is too small (the counts are still returned). */
+ * cand_used / cigar_used first; PSVR_ERR_OVERFLOW if a capacity is too small (the counts are still returned).
+ * The four destinations may be host memory (page-locked: psvr_host_alloc) or memory of the engine's device: the ordered
+ * gather of a one-process-per-GPU host (reference: output_results, read_realignment.cpp:165-176, which walks the batch in
+ * input order) sends a block on to its peer straight from HBM. */
 int psvr_engine_download_compact(psvr_engine_t *eng, psvr_read_hdr_t *hdr, psvr_pair_result_t *pairs,
                                  psvr_cand_t *cands, int64_t cand_cap, int64_t *cand_used,
                                  uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_used);

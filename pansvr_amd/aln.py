@@ -157,6 +157,38 @@ class Engine:
                                              C.c_int64(len(cands)), C.byref(nc), cig.ctypes.data_as(C.c_void_p), C.c_int64(len(cig)), C.byref(nw)))
         return hdr, pairs, cands[:int(nc.value)], cig[:int(nw.value)]
 
+    def compact_sizes(self):
+        """(candidates, CIGAR words) of the compact form (builds it on the device if it is not there yet)."""
+        nc, nw = C.c_int64(0), C.c_int64(0)
+        rc = lib().psvr_engine_download_compact(self.h, None, None, None, C.c_int64(0), C.byref(nc), None, C.c_int64(0), C.byref(nw))
+        if rc not in (0, 6):
+            check(rc)
+        return int(nc.value), int(nw.value)
+
+    @staticmethod
+    def compact_layout(n_pairs, nc, nw):
+        """Byte offsets of hdr | pairs | cands | cigar in a packed block (each section on a 64-byte boundary) and the block's size."""
+        def up(x):
+            return (x + 63) & ~63
+        o_hdr = 0
+        o_pairs = up(o_hdr + 2 * n_pairs * HDR_DTYPE.itemsize)
+        o_cands = up(o_pairs + n_pairs * PAIR_DTYPE.itemsize)
+        o_cig = up(o_cands + nc * CAND_DTYPE.itemsize)
+        return o_hdr, o_pairs, o_cands, o_cig, up(o_cig + nw * 4)
+
+    def compact_pack(self, base_ptr, cap):
+        """The compact form as ONE block at base_ptr (host memory, or memory of the engine's device: psvr_engine_download_compact takes
+        either) -- what the ordered gather of a one-process-per-GPU host sends to rank 0.  Returns (bytes used, [n_pairs, nc, nw])."""
+        P = self.n_pairs
+        nc, nw = self.compact_sizes()
+        o_hdr, o_pairs, o_cands, o_cig, total = self.compact_layout(P, nc, nw)
+        if total > cap:
+            raise EngineError("compact_pack: block of %d bytes does not fit %d" % (total, cap))
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().psvr_engine_download_compact(self.h, C.c_void_p(base_ptr + o_hdr), C.c_void_p(base_ptr + o_pairs), C.c_void_p(base_ptr + o_cands), C.c_int64(nc + 1), C.byref(a),
+                                                 C.c_void_p(base_ptr + o_cig), C.c_int64(nw + 1), C.byref(b)))
+        return total, [P, nc, nw]
+
     def download_into(self, bufs):
         """Like download(), into the caller's page-locked buffers (HostBuffers): the copies run at the link's rate."""
         P = self.n_pairs

@@ -1568,7 +1568,16 @@ PSVR_HDN inline void adopt_variant(const Ctx &c, long long pair, long long slot,
 			// number of draws is what the host's walk counted on -- otherwise nothing is touched and the pair runs in full
 			c.poff[slot] = noff[pair];
 			const int r = reselect_pair(c, slot);
-			if (r == 2 || c.rcnt[3 * slot] != s0 || c.rcnt[3 * slot + 1] != s1) return;
+			if (r == 2 || c.rcnt[3 * slot] != s0 || c.rcnt[3 * slot + 1] != s1) {
+				// Declined: the pair runs in full.  reselect_pair has rewritten the slot's chain selection (and, on result 3, its candidate
+				// records), so the slot is not what the host's table of variant counts (read once per batch) describes any more: its
+				// counts go back to what that table holds -- special_slot_at and the host's walk keep counting on them -- and the slot is
+				// closed for further adoptions (hcnt != 0 declines above; nothing else looks at a variant slot's hcnt after round 1),
+				// so no later attempt compares against, or adopts, the changed records
+				c.rcnt[3 * slot] = s0, c.rcnt[3 * slot + 1] = s1;
+				c.hcnt[2 * slot] = -1;
+				return;
+			}
 		}
 		for (int k = 0; k < 4; ++k) c.strand[4 * pair + k] = c.strand[4 * slot + k];
 		c.rcnt[3 * pair] = c.rcnt[3 * slot], c.rcnt[3 * pair + 1] = c.rcnt[3 * slot + 1];

@@ -1036,7 +1036,11 @@ __global__ __launch_bounds__(256) void k_dp_fetch(Ctx c, long long begin, long l
 	for (int k = lane; k < nq + nt; k += 16) {
 		const bool is_t = k >= nq;
 		const int i0 = 16 * (is_t ? k - nq : k), len = is_t ? x.tlen : x.qlen;
-		if (!is_t && bytes) { for (int i = i0; i < i0 + 16; ++i) dp_fetch_base(c, x, i, q, t); continue; }
+		if (!is_t && bytes) {                                        // query bytes only: the target's chunks belong to other lanes
+			const uint8_t *rs = c.bin + ((long long)x.read * 2 + x.strand) * c.lmax;
+			for (int i = i0; i < i0 + 16; ++i) q[i] = rs[x.q_st + (rev ? x.qlen - 1 - i : i)];
+			continue;
+		}
 		const uint64_t *src = is_t ? c.idx.ref_seq : rw;
 		const uint64_t st = is_t ? (uint64_t)x.ref_st : (uint64_t)x.q_st;
 		const uint32_t w = (uint32_t)(window32(src, st + (uint64_t)(rev ? len - 16 - i0 : i0)) >> 32);
@@ -1140,6 +1144,9 @@ struct GpuBE {
 	static constexpr size_t kUp = (size_t)8 << 20;
 	size_t up_pos = 0, up_since_sync = 0;
 	hipStream_t up_stream = nullptr;                         // the queue the outstanding slots' copies were put on
+	// `stream` has just been synchronised: every copy out of the ring that was queued on it has left its slot.  The ring then never has to
+	// touch a stream it is not currently running on -- a caller's stream (psvr_engine_run / _rebase) may be gone by the next upload
+	void synced() { if (up_since_sync && up_stream == stream) up_since_sync = 0; }
 	void h2d(void *d, const void *h, size_t n)
 	{
 		if (n && n <= kUp / 4 && (up_ring || hipHostMalloc(&up_ring, kUp, hipHostMallocDefault) == hipSuccess)) {
@@ -1155,12 +1162,12 @@ struct GpuBE {
 			up_pos += need, up_since_sync += need;
 			return;
 		}
-		note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream));
+		note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); synced();
 	}
 	void d2h(void *h, const void *d, size_t n)
 	{
-		if (n && n <= kPinUse && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); memcpy(h, pin, n); return; }
-		note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream));
+		if (n && n <= kPinUse && pinned()) { note(hipMemcpyAsync(pin, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); synced(); memcpy(h, pin, n); return; }
+		note(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream)); note(hipStreamSynchronize(stream)); synced();
 	}
 	// two small readbacks with one synchronisation
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2)
@@ -1168,7 +1175,7 @@ struct GpuBE {
 		if (n1 + n2 <= kPinUse && pinned()) {
 			note(hipMemcpyAsync(pin, d1, n1, hipMemcpyDeviceToHost, stream));
 			note(hipMemcpyAsync((char *)pin + n1, d2, n2, hipMemcpyDeviceToHost, stream));
-			note(hipStreamSynchronize(stream));
+			note(hipStreamSynchronize(stream)); synced();
 			memcpy(h1, pin, n1), memcpy(h2, (char *)pin + n1, n2);
 			return;
 		}
@@ -1183,7 +1190,7 @@ struct GpuBE {
 			note(hipMemcpyAsync(p + n1, d2, n2, hipMemcpyDeviceToHost, stream));
 			note(hipMemcpyAsync(p + n1 + n2, d3, n3, hipMemcpyDeviceToHost, stream));
 			note(hipMemcpyAsync(p + n1 + n2 + n3, d4, n4, hipMemcpyDeviceToHost, stream));
-			note(hipStreamSynchronize(stream));
+			note(hipStreamSynchronize(stream)); synced();
 			memcpy(h1, p, n1), memcpy(h2, p + n1, n2), memcpy(h3, p + n1 + n2, n3), memcpy(h4, p + n1 + n2 + n3, n4);
 			return;
 		}
@@ -1352,7 +1359,7 @@ struct GpuBE {
 			if (n) note(hipMemcpyAsync(p, tmp_out.p, n * 20, hipMemcpyDeviceToHost, stream));
 			size_t at = (size_t)n * 20;
 			for (int k = 0; k < 3; ++k) if (xn[k]) { note(hipMemcpyAsync(p + at, xd[k], xn[k], hipMemcpyDeviceToHost, stream)); at += xn[k]; }
-			note(hipStreamSynchronize(stream));
+			note(hipStreamSynchronize(stream)); synced();
 			if (n) memcpy(oa, p, n * 8), memcpy(ob, p + n * 8, n * 8), memcpy(oc, p + n * 16, n * 4);
 			at = (size_t)n * 20;
 			for (int k = 0; k < 3; ++k) if (xn[k]) { memcpy(xh[k], p + at, xn[k]); at += xn[k]; }
@@ -1364,7 +1371,7 @@ struct GpuBE {
 			note(hipMemcpyAsync(oc, (char *)tmp_out.p + n * 16, n * 4, hipMemcpyDeviceToHost, stream));
 		}
 		for (int k = 0; k < 3; ++k) if (xn[k]) note(hipMemcpyAsync(xh[k], xd[k], xn[k], hipMemcpyDeviceToHost, stream));
-		note(hipStreamSynchronize(stream));
+		note(hipStreamSynchronize(stream)); synced();
 	}
 	void scatter_listed_i32(int32_t *a, const int32_t *val, long long n)
 	{
@@ -1515,18 +1522,20 @@ struct GpuBE {
 			PSVR_HIP(hipMemcpyAsync(hb + 4248, d.t_off + n, 8, hipMemcpyDeviceToHost, stream));
 			PSVR_HIP(hipMemcpyAsync(hb + 4256, pd.p_off + n, 8, hipMemcpyDeviceToHost, stream));
 			PSVR_HIP(hipStreamSynchronize(stream));
+			synced();
 			memcpy(hist, hb, 4096), memcpy(qmax, hb + 4096, 144), memcpy(tot, hb + 4240, 24);
 		}
 		// NB: the scans ran over n+1 entries, element n of qlen/tlen/plen is scratch: its value only lands in slot n+1 (never read)
 		core.stats.dp_seq_bytes += (long long)qmax[17];              // query + target bytes the DP launches of this round read (k_dp_lens sums them)
 		if (!core.ensure_dp(n, tot[0], tot[1], tot[0] + tot[1] + 2 * n)) return set_error(PSVR_ERR_NOMEM, "DP sequence buffers");
 		PSVR_HIP(pslab.ensure((size_t)(tot[2] << 8) + 256));
-		// scratch of the strip kernel: every wavefront bump-allocates what its 64 problems need; bound per class by its longest query
+		// scratch of the team kernel: a wavefront's slice starts at an offset computed from its class (TeamLaunch::add), sized by the class's
+		// longest query -- the same clamp (>= 1) as there
 		unsigned long long ws_bytes = 0, team_cnt[PSVR_DP_NUM_LDS_CLASSES];
 		for (int cls = 0; cls < PSVR_DP_NUM_LDS_CLASSES; ++cls) {
 			team_cnt[cls] = 0;
 			for (int qb = 0; qb < 16; ++qb) team_cnt[cls] += hist[256 + cls * 16 + qb];
-			if (team_cnt[cls]) { const int lanes = dp_team_lanes(cls + 1); ws_bytes += (team_cnt[cls] * lanes + 63) / 64 * dp_team_ws_bytes((int)qmax[cls], cls + 1, lanes); }
+			if (team_cnt[cls]) { const int lanes = dp_team_lanes(cls + 1); ws_bytes += (team_cnt[cls] * lanes + 63) / 64 * dp_team_ws_bytes(qmax[cls] > 0 ? (int)qmax[cls] : 1, cls + 1, lanes); }
 		}
 		PSVR_HIP(strip_ws.ensure((size_t)ws_bytes + 256));
 		long long bstart[512], acc = 0;
@@ -2011,6 +2020,7 @@ extern "C" int psvr_engine_run(psvr_engine_t *e, int trace, void *stream)
 	int rc = e->core.run(trace & 1, (trace & 2) != 0);
 	hipError_t s = hipStreamSynchronize(e->be.stream);
 	if (s != hipSuccess) e->be.note(s);
+	e->be.synced();             // (a caller's stream is not looked at again after this call)
 	e->be.collect_timing();
 	e->committed = false;       // the rand streams advance when the next batch is uploaded (or a stream position is set)
 	return engine_status(e, rc);
@@ -2045,6 +2055,7 @@ extern "C" int psvr_engine_rebase(psvr_engine_t *e, const int64_t pos[3], void *
 	int rc = e->core.rebase(pos[0], pos[1], pos[2], e->core.c.trace, false);
 	hipError_t s = hipStreamSynchronize(e->be.stream);
 	if (s != hipSuccess) e->be.note(s);
+	e->be.synced();
 	return engine_status(e, rc);
 }
 
@@ -2103,10 +2114,12 @@ extern "C" int psvr_engine_download_compact(psvr_engine_t *e, psvr_read_hdr_t *h
 	if (cigar_used) *cigar_used = e->compact_nw;
 	if ((cands && e->compact_nc > cand_cap) || (cigar && e->compact_nw > cigar_cap))
 		return set_error(PSVR_ERR_OVERFLOW, "compact download: need %lld candidates / %lld cigar words", e->compact_nc, e->compact_nw);
-	if (hdr) PSVR_HIP(hipMemcpyAsync(hdr, e->cmp_hdr.p, (size_t)R * sizeof(psvr_read_hdr_t), hipMemcpyDeviceToHost, e->own));
-	if (pairs) PSVR_HIP(hipMemcpyAsync(pairs, c.c.pres, (size_t)c.P * sizeof(psvr_pair_result_t), hipMemcpyDeviceToHost, e->own));
-	if (cands && e->compact_nc) PSVR_HIP(hipMemcpyAsync(cands, e->cmp_cand.p, (size_t)e->compact_nc * sizeof(psvr_cand_t), hipMemcpyDeviceToHost, e->own));
-	if (cigar && e->compact_nw) PSVR_HIP(hipMemcpyAsync(cigar, e->cmp_cig.p, (size_t)e->compact_nw * 4, hipMemcpyDeviceToHost, e->own));
+	// (hipMemcpyDefault: the destinations may be host memory or memory of this device -- the ordered gather of a one-process-per-GPU host
+	// hands the blocks on over RCCL without a trip through the host)
+	if (hdr) PSVR_HIP(hipMemcpyAsync(hdr, e->cmp_hdr.p, (size_t)R * sizeof(psvr_read_hdr_t), hipMemcpyDefault, e->own));
+	if (pairs) PSVR_HIP(hipMemcpyAsync(pairs, c.c.pres, (size_t)c.P * sizeof(psvr_pair_result_t), hipMemcpyDefault, e->own));
+	if (cands && e->compact_nc) PSVR_HIP(hipMemcpyAsync(cands, e->cmp_cand.p, (size_t)e->compact_nc * sizeof(psvr_cand_t), hipMemcpyDefault, e->own));
+	if (cigar && e->compact_nw) PSVR_HIP(hipMemcpyAsync(cigar, e->cmp_cig.p, (size_t)e->compact_nw * 4, hipMemcpyDefault, e->own));
 	PSVR_HIP(hipStreamSynchronize(e->own));
 	return PSVR_OK;
 }

@@ -166,7 +166,7 @@ struct HostSvNames : SvNames {
 int main(int argc, char **argv)
 {
 	if (argc < 4) { fprintf(stderr, "usage: emu_aln <index_dir> <reads.fq> <header.sam> [--trace] [--batch N] [--sam FILE --ori-sam FILE]\n"); return 1; }
-	bool trace = false, quiet = false, sig_n = false, sig_d = false, sig_u = false;
+	bool trace = false, quiet = false, not_ori = false, sig_n = false, sig_d = false, sig_u = false;
 	long long batch = 1 << 20;
 	int threads = 1;
 	const char *sam_fn = nullptr, *ori_fn = nullptr;
@@ -174,6 +174,7 @@ int main(int argc, char **argv)
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
 		else if (!strcmp(argv[i], "--no-records")) quiet = true;
+		else if (!strcmp(argv[i], "-Q")) not_ori = true;            // --not-ori (read_realignment.cpp:485)
 		else if (!strcmp(argv[i], "-N")) sig_n = true;
 		else if (!strcmp(argv[i], "-D")) sig_d = true;
 		else if (!strcmp(argv[i], "-U")) sig_u = true;
@@ -227,7 +228,7 @@ int main(int argc, char **argv)
 		fsam = fopen(sam_fn, "w"), fori = fopen(ori_fn, "w");
 		if (!fsam || !fori) { fprintf(stderr, "cannot open the SAM outputs\n"); return 2; }
 		fputs(H.text.c_str(), fsam), fputs(H.text.c_str(), fori);
-		em.H = &H, em.sv = &svn;
+		em.H = &H, em.sv = &svn, em.not_ori = not_ori;
 	}
 	bool first = true;
 	long long pair_base = 0;

@@ -28,11 +28,16 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 SCORE_SETS = [("fx2", "reads150", s) for s in ((3, 9, 12, 2, 24, 1, 200), (1, 4, 6, 1, 20, 0, 50), (2, 30, 40, 3, 60, 2, 400))]
 
 
+# `-Q` / --not-ori (read_realignment.cpp:485: an ORIGINAL primary is not written to the main file): (data set, reads).  fx2 holds
+# unmapped and full-score originals and repeats whose original alignment outscores the new one; fx1 is the plain set.
+NOT_ORI_SETS = [("fx1", "reads150"), ("fx2", "reads150")]
+
+
 def score_tag(s):
     return "score_" + "_".join(str(x) for x in s)
 
 
-def main(names):
+def main(names, only_not_ori=False):
     for name in names:
         ds = datasets.DATASETS[name]
         work = os.environ.get("PSVR_GOLDEN_WORK", tempfile.mkdtemp(prefix="psvr_" + name))
@@ -45,7 +50,9 @@ def main(names):
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         out = os.path.join(HERE, name)
         os.makedirs(out, exist_ok=True)
-        if ds.get("index") == "sha256":
+        if only_not_ori:
+            pass
+        elif ds.get("index") == "sha256":
             # too large to commit: the compact form's SHA-256 per file; tests rebuild the index with `panSVR index` and compare
             import hashlib
             cdir = os.path.join(work, "idx_compact")
@@ -55,7 +62,7 @@ def main(names):
                     f.write("%s  %s\n" % (hashlib.sha256(open(os.path.join(cdir, fn), "rb").read()).hexdigest(), fn))
         else:
             index_fixture.compact(idx, os.path.join(out, "idx"))
-        for rname in ds["reads"]:
+        for rname in ([] if only_not_ori else ds["reads"]):
             sam, ori, rec = (os.path.join(work, rname + e) for e in (".ref.sam", ".ref.ori.sam", ".ref.jsonl"))
             subprocess.run([os.path.join(REF, "ref_aln"), "-t", "1", "-S", "-o", sam, "-p", ori, idx, os.path.join(work, rname + ".fq"), os.path.join(work, "header.sam"),
                             "--trace", "--records", rec], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
@@ -68,8 +75,18 @@ def main(names):
             put(os.path.join(out, rname + ".sam.gz"), open(sam, "rb").read())
             put(os.path.join(out, rname + ".ori.sam.gz"), open(ori, "rb").read())
             print(name, rname, len(lines), "pairs", os.path.getsize(sam), "B sam", os.path.getsize(ori), "B ori sam")
-        for sname, rname, sc in SCORE_SETS:
+        for sname, rname in NOT_ORI_SETS:
             if sname != name:
+                continue
+            sam, ori = (os.path.join(work, rname + e) for e in (".refQ.sam", ".refQ.ori.sam"))
+            subprocess.run([os.path.join(REF, "ref_aln"), "-t", "1", "-S", "-Q", "-o", sam, "-p", ori, idx, os.path.join(work, rname + ".fq"), os.path.join(work, "header.sam")],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            for src, ext in ((sam, ".notori.sam.gz"), (ori, ".notori.ori.sam.gz")):
+                with open(os.path.join(out, rname + ext), "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
+                    f.write(open(src, "rb").read())
+            print(name, rname, "-Q", os.path.getsize(sam), "B sam", os.path.getsize(ori), "B ori sam")
+        for sname, rname, sc in SCORE_SETS:
+            if sname != name or only_not_ori:
                 continue
             rec = os.path.join(work, rname + "." + score_tag(sc) + ".jsonl")
             M, m, O, E, P, F, z = sc
@@ -83,4 +100,5 @@ def main(names):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or list(datasets.DATASETS))
+    argv = [a for a in sys.argv[1:] if a != "--only-not-ori"]      # --only-not-ori: just the -Q files (the other fixtures stay as committed)
+    main(argv or list(datasets.DATASETS), only_not_ori="--only-not-ori" in sys.argv[1:])

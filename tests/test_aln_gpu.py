@@ -44,6 +44,21 @@ def test_gpu_engine_matches_reference_records(name, rname):
                                                                                              gl[first][:500] if first < len(gl) else None))
 
 
+@pytest.mark.parametrize("name,rname", [("fx1", "reads150"), ("fx2", "reads150")])
+def test_gpu_cli_not_ori_option_matches_the_reference(name, rname):
+    """`panSVR aln -S -Q` on the GPU == the reference's own `fc_aln -t 1 -S -Q` files (read_realignment.cpp:485), byte for byte."""
+    import gzip
+    w = ac.workdir(name)
+    tmp = tempfile.mkdtemp(prefix="psvr_gpuq_")
+    r = subprocess.run([CLI, "aln", "-S", "-Q", "-o", os.path.join(tmp, "out.sam"), "-p", os.path.join(tmp, "ori.sam"),
+                        ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for got_fn, ext in (("out.sam", ".notori.sam.gz"), ("ori.sam", ".notori.ori.sam.gz")):
+        with gzip.open(os.path.join(ac.golden_dir(name), rname + ext), "rb") as f:
+            want = f.read()
+        assert open(os.path.join(tmp, got_fn), "rb").read() == want, "%s differs from the reference's -Q file" % got_fn
+
+
 def test_gpu_cli_bam_output_equals_sam_text():
     """Default output is BAM (like the reference's init_run): decode it with tests/bam_reader.py and compare every record,
     field for field and tag for tag, with the SAM text of a -S run of the same input; both files (-o and -p)."""

@@ -17,6 +17,14 @@ from test_emu_aln import normalise
 EMU = os.path.join(ac.HERE, "emu", "emu_aln")
 
 
+def free_port():
+    """A port nobody listens on right now (two runs of the suite on one box, or a leftover rendezvous, must not collide)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _rank_main(rank, world, port, workdir, outdir):
     import torch.distributed as dist
     sys.path.insert(0, ac.ROOT)
@@ -68,7 +76,7 @@ def test_two_rank_sharding_reproduces_the_single_stream_records():
     w = ac.workdir("fx1")
     outdir = tempfile.mkdtemp(prefix="psvr_gloo_")
     world = 2
-    mp.spawn(_rank_main, args=(world, 29533, w, outdir), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, free_port(), w, outdir), nprocs=world, join=True)
     metas = [json.load(open(os.path.join(outdir, "meta%d.json" % r))) for r in range(world)]
     assert metas[0]["lo"] == 0 and metas[0]["hi"] == metas[1]["lo"] and metas[1]["hi"] == 2000
     assert metas[1]["start"] == metas[0]["end"], "rank 1 must start where rank 0 ended"
@@ -94,9 +102,52 @@ def test_bench_launch_contract_selects_the_local_rank_device():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                         os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     import re
     got = sorted((json.loads(m) for m in re.findall(r"\{[^{}]*\"dry_run\"[^{}]*\}", r.stdout.decode())), key=lambda d: d["rank"])
     assert [d["rank"] for d in got] == [0, 1] and all(d["device"] == d["local_rank"] == d["rank"] and d["world"] == 2 for d in got)
+
+
+def _gather_main(rank, world, port, outdir):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ac.ROOT)
+    from pansvr_amd import dist as pd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group, device, how = pd.data_plane(False)
+    assert group is None and device is None
+    g = pd.BlockGather(device, group)
+    res = None
+    for step in range(3):                               # the buffers are kept across steps; block sizes change from step to step
+        n = 1000 + 777 * rank + 4096 * step * (rank + 1)
+        block = ((np.arange(n, dtype=np.int64) * (rank + 3) + step) % 251).astype(np.uint8)
+
+        def pack(buf):
+            buf[:n] = torch.from_numpy(block)
+            return n, [rank, step, 7]
+        res = g.gather(n, pack)
+        if rank == 0:
+            assert len(res) == world
+            for r, (buf, nb, meta) in enumerate(res):
+                want = ((np.arange(nb, dtype=np.int64) * (r + 3) + step) % 251).astype(np.uint8)
+                assert nb == 1000 + 777 * r + 4096 * step * (r + 1) and meta == [r, step, 7], (r, nb, meta)
+                assert np.array_equal(buf[:nb].numpy(), want), "block %d of step %d arrived damaged or out of order" % (r, step)
+        else:
+            assert res is None
+    if rank == 0:
+        open(os.path.join(outdir, "gather_ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_block_gather_keeps_block_order_and_bytes():
+    """The ordered gather of bench.py's N > 1 step (pansvr_amd/dist.py::BlockGather): three gloo ranks, blocks of different and changing
+    sizes -- rank 0 must end up with every rank's bytes, in rank order (= input order, the reference's output_results contract)."""
+    outdir = tempfile.mkdtemp(prefix="psvr_gather_")
+    mp.spawn(_gather_main, args=(3, free_port(), outdir), nprocs=3, join=True)
+    assert os.path.exists(os.path.join(outdir, "gather_ok"))

@@ -103,15 +103,27 @@ def run_config(anc_kw, reads_kw, stat, N_PAIRS, N_ORACLE, split):
     checksum = zlib.crc32(reads.tobytes()) ^ zlib.crc32(pairs.tobytes())
     print("fullsize: %d pairs, %d candidates, gain %d, checksum %08x" % (N_PAIRS, tot_cand, int(pairs["gain"].sum()), checksum))
     # --- prefix parity against the oracle
-    tmp = tempfile.mkdtemp(prefix="psvr_full_")
+    # (the reference's own objects, oracle/_ref/ref_aln, when they are there and RAM-backed storage can hold the dense first-level table
+    # their loader reads; the restatement oracle/aln_oracle -- pinned against them by the fx1..fx5 goldens -- otherwise)
+    import shutil
+    ref_exe = os.path.join(ac.ROOT, "oracle", "_ref", "ref_aln")
+    use_ref = os.path.exists(ref_exe) and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (6 << 30)
+    tmp = tempfile.mkdtemp(prefix="psvr_full_", dir="/dev/shm" if use_ref else None)
     small = {k: v for k, v in ix.items() if k != "hash"}
-    bench_data.write_index_dir(small, os.path.join(tmp, "idx"))
+    bench_data.write_index_dir(small, os.path.join(tmp, "idx"), dense_hash=ix["hash"] if use_ref else None)
     bench_data.write_fastq(os.path.join(tmp, "sample.fq"), bases, base_off, ori, isize, stat=stat, n_pairs=N_ORACLE)
     with open(os.path.join(tmp, "header.sam"), "w") as f:
         f.write("@SQ\tSN:chr1\tLN:250000000\n@SQ\tSN:chr2\tLN:250000000\n")
-    out = subprocess.run([ac.ORACLE_EXE, os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam")],
-                         stdout=subprocess.PIPE, check=True).stdout.decode()
-    want = [json.loads(l) for l in out.split("\n") if l.strip()]
+    base = [os.path.join(tmp, "idx"), os.path.join(tmp, "sample.fq"), os.path.join(tmp, "header.sam")]
+    try:
+        if use_ref:
+            out = subprocess.run([ref_exe, "-t", "1", "-R", str(N_ORACLE)] + base + ["--quiet"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+        else:
+            out = subprocess.run([ac.ORACLE_EXE] + base, stdout=subprocess.PIPE, check=True).stdout.decode()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("prefix parity against", "oracle/_ref/ref_aln (reference objects)" if use_ref else "oracle/aln_oracle")
+    want = [json.loads(l) for l in out.split("\n") if l.lstrip().startswith("{")][:N_ORACLE]
     got = records(reads, pairs, cig, ori, lens, 0, N_ORACLE)
     assert len(want) == N_ORACLE
     bad = [i for i in range(N_ORACLE) if want[i] != got[i]]

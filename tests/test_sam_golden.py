@@ -41,3 +41,22 @@ def test_formatter_writes_the_reference_sam_files(emu, name, rname):
             raise AssertionError("%s differs from the reference's file at line %d (%d vs %d lines)\nref: %r\ngot: %r"
                                  % (got_fn, first, len(wl), len(gl), wl[first][:600] if first < len(wl) else None, gl[first][:600] if first < len(gl) else None))
     assert golden_text(name, rname, ".sam.gz").count(b"\n") > 40
+
+
+NOT_ORI = [("fx1", "reads150"), ("fx2", "reads150")]
+
+
+@pytest.mark.parametrize("name,rname", NOT_ORI)
+def test_formatter_not_ori_option_matches_the_reference(emu, name, rname):
+    """`-Q` / --not-ori (read_realignment.cpp:485: output_BAM returns before writing an ORIGINAL primary): both files of the reference's
+    `fc_aln -t 1 -S -Q` run (tests/golden/<set>/<reads>.notori.*, written by ref_aln -Q) against the product formatter with not_ori set."""
+    w = ac.workdir(name)
+    tmp = tempfile.mkdtemp(prefix="psvr_samq_")
+    r = subprocess.run([emu, ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--no-records", "-Q",
+                        "--sam", os.path.join(tmp, "o.sam"), "--ori-sam", os.path.join(tmp, "p.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    for got_fn, ext in (("o.sam", ".notori.sam.gz"), ("p.sam", ".notori.ori.sam.gz")):
+        got, want = open(os.path.join(tmp, got_fn), "rb").read(), golden_text(name, rname, ext)
+        assert got == want, "%s differs from the reference's -Q file" % got_fn
+    # the option really drops records: the -Q main file is a proper subset of the default one
+    assert golden_text(name, rname, ".notori.sam.gz").count(b"\n") < golden_text(name, rname, ".sam.gz").count(b"\n")

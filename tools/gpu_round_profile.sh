@@ -5,7 +5,7 @@ TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-B="--cpu-pairs 0 --check-pairs 0 --no-e2e --no-cfg5"
+B="--cpu-pairs 0 --check-pairs 0 --no-e2e --no-cfg5 --one-pass"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters_available.txt 2>&1 || true
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python3 $R/bench.py --steps 2 --warmup 1 $B > $O/ks.log 2>&1

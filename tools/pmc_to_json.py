@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/pmc_latest.json from the two rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 0 --cpu-pairs 0`
-(5 engine passes per process: timed, timing, stats, two PCIe-inclusive).  usage: pmc_to_json.py <fetch.csv> <write.csv> <pairs_per_gpu> <out.json>"""
+"""profiles/pmc_latest.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) of
+`bench.py --one-pass --steps 1 --warmup 0 ...` (one engine pass per process: every counter value belongs to that one step).
+usage: pmc_to_json.py <fetch.csv> <write.csv> <pairs_per_gpu> <out.json> [<engine passes per process> [<commit>]]"""
 import collections
 import csv
 import json
@@ -15,8 +16,9 @@ def load(path):
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
-passes = 5.0
-out = {"pairs_per_gpu": int(sys.argv[3]), "passes_per_process": passes, "unit": "KiB", "kernels": {}}
+passes = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
+out = {"pairs_per_gpu": int(sys.argv[3]), "passes_per_process": passes, "unit": "KiB", "commit": sys.argv[6] if len(sys.argv) > 6 else None,
+       "command": "bench.py --one-pass --steps 1 --warmup 0", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = {"fetch_KiB_per_step": round(fetch.get(k, 0.0) / passes, 1), "write_KiB_per_step": round(write.get(k, 0.0) / passes, 1)}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
