@@ -59,6 +59,12 @@ struct DevIndex {
 	// optional: uid_hint[b] = last unipath that starts at or before position b << uid_shift, so the unipath of a position is found by
 	// bisecting between two neighbouring hints (a couple of loads) instead of over all n_seqf starts (14+ dependent loads per MEM)
 	const uint32_t *uid_hint; uint32_t uid_shift;
+	// optional, in front of (instead of) the occupancy bitmap: a Bloom filter over the 20-mers the index holds (the first 20 bases of its
+	// 22-mers), three bits in ONE 64-bit word per key (kmer_maybe_present).  16 MiB for a 12 M-k-mer index against the bitmap's 32 MiB:
+	// twice the share of it stays in an XCD's 4 MiB L2 -- a probe is one random 64-byte sector either way, and those sectors are what
+	// bounds the seeding kernel --, and it answers for the 20-mer itself, not for its 14-base bucket: a read k-mer that differs from an
+	// indexed one in its last six bases (every k-mer over a mismatch) passes the bitmap and fails here.
+	const uint64_t *bloom; uint32_t bloom_shift;    // word = (kmer * K) >> bloom_shift
 	// tests/emu only (PSVR_EMU_SPARSE_HASH): non-empty first-level buckets instead of the dense 2 GiB table
 	const uint32_t *sp_id; const uint64_t *sp_start; uint64_t sp_n, n_kmer;
 };
@@ -230,6 +236,30 @@ PSVR_HD bool bucket_occupied(const DevIndex &ix, uint64_t h)
 	return true;
 #else
 	return !ix.occ || ((ix.occ[h >> 5] >> (h & 31)) & 1u);
+#endif
+}
+
+// word and bit mask of a 20-mer in the Bloom filter
+PSVR_HD void bloom_slot(uint64_t kmer, uint32_t shift, uint64_t &word, uint64_t &mask)
+{
+	const uint64_t h = kmer * 0x9E3779B97F4A7C15ull;
+	const uint64_t g = (h ^ (h >> 32)) * 0xD6E8FEB86659FD93ull;
+	word = h >> shift;
+	mask = (1ull << (g >> 58)) | (1ull << ((g >> 52) & 63)) | (1ull << ((g >> 46) & 63));
+}
+// false: the index certainly holds no 22-mer that starts with this 20-mer (no false negatives: every indexed 20-mer has its bits set)
+PSVR_HD bool kmer_maybe_present(const DevIndex &ix, uint64_t kmer)
+{
+#ifdef PSVR_EMU_SPARSE_HASH
+	(void)ix, (void)kmer;
+	return true;
+#else
+	if (ix.bloom) {
+		uint64_t w, m;
+		bloom_slot(kmer, ix.bloom_shift, w, m);
+		return (ix.bloom[w] & m) == m;
+	}
+	return bucket_occupied(ix, kmer >> 12);
 #endif
 }
 
@@ -528,7 +558,7 @@ template <bool LOCAL> PSVR_HD void seed_strand_t(const Ctx &c, long long rs, con
 					if (off + kLenKmer - 1 <= msr || (is_str && seed_list_at(sl, (int)kn, rev, off) == 0)) { off += kSeedStep; continue; }
 					kmer = get_kmer(off, rb);
 					if (pass == 0) ++probes;
-					if (bucket_occupied(ix, kmer >> 12)) { stage = 1; break; }
+					if (kmer_maybe_present(ix, kmer)) { stage = 1; break; }
 					off += kSeedStep;
 				}
 				if (stage != 1) break;
@@ -858,6 +888,194 @@ PSVR_HDN inline void select_read(const Ctx &c, long long read)
 	int keep = n;
 	for (int k = 0; k < n; ++k) if (cc[k].chain_score + 30 < max_chain) { keep = k; break; }
 	c.n_ccand[read] = keep;
+}
+
+// ---- chain + select, the small case ------------------------------------------------------------------------
+// Nearly every read that has MEMs at all has them on ONE strand, in (uid, read_pos) order as the seed loop found them, and they merge
+// into one or two unipath seeds with a single reference position each (a read that matches its anchor but for substitutions: one; with an
+// indel: two; bench batch: 99.8 % of the reads with MEMs).  chain_read + select_read spend their time walking arrays of that size in
+// global memory through loops written for hundreds of seeds.  Here the same rules -- merge_seed_in_unipath, expand_seed,
+// Graph_handler::process / dynamic_programming_path (deBGA_index.cpp:151-251, graph.cpp:53-150), the sort_output loop and the candidate cut
+// of single_end_handler::align (rr.cpp:212-293,417-442) -- run on at most two seeds held in registers, and the records the later stages
+// read (USeed / PathN, Strand, ChainCand, counts) are written once.  Nothing is written before the read is known to fit; returns false
+// then, and chain_read + select_read take the read.
+PSVR_HDN inline bool chain_select_small(const Ctx &c, long long read)
+{
+	if (!c.active[read]) return true;
+	const DevIndex &ix = c.idx;
+	Strand &s0 = c.strand[read * 2], &s1 = c.strand[read * 2 + 1];
+	const uint32_t n0 = s0.mem_n, n1 = s1.mem_n;
+	if (n0 != 0 && n1 != 0) return false;
+	const int o = n1 != 0;                                               // the strand that has the MEMs (0 forward, 1 reverse)
+	Strand &st = o ? s1 : s0, &sx = o ? s0 : s1;
+	const uint32_t mem_i = o ? n1 : n0;
+	if (mem_i > 16) return false;
+	struct SU { uint64_t uid; uint32_t read_pos, uni_pos_off, length1, length2, pos_n, cov; };
+	SU u0, u1;
+	u0.uid = u1.uid = 0, u0.read_pos = u1.read_pos = u0.uni_pos_off = u1.uni_pos_off = u0.length1 = u1.length1 = u0.length2 = u1.length2 = u0.pos_n = u1.pos_n = u0.cov = u1.cov = 0;
+	int nvu = 0;
+	if (mem_i) {
+		const VMem *vm = c.mem.base + st.mem_off;
+		// merge_seed_in_unipath over MEMs that stand in (uid, read_pos) order already (a stable sort leaves them where they are): a group runs on
+		// while the next MEM lies in the same unipath, further right in it, at most 3 read bases behind its predecessor's end and on its diagonal
+		VMem first = vm[0], last = first;
+		uint32_t cov = first.length;
+		for (uint32_t j = 1; j <= mem_i; ++j) {
+			bool close = j == mem_i;
+			VMem x = last;
+			if (!close) {
+				x = vm[j];
+				if (x.uid != last.uid ? x.uid < last.uid : x.read_pos < last.read_pos) return false;      // not in sorted order: the generic path sorts
+				bool on = x.uid == first.uid && x.uni_pos_off > last.uni_pos_off;
+				if (on) {
+					const int diff = (int)(x.read_pos - last.read_pos - last.length);
+					const int ce = (int)((x.uni_pos_off - last.uni_pos_off) - (x.read_pos - last.read_pos));
+					on = diff <= 3 && ce == 0;
+					if (on) cov += diff > 0 ? x.length : (uint32_t)(diff + (int)x.length);
+				}
+				close = !on;
+			}
+			if (close) {
+				if (nvu == 2 || first.pos_n != 1) return false;           // a third seed, or a unipath with several reference positions
+				SU &u = nvu ? u1 : u0;
+				u.uid = first.uid, u.read_pos = first.read_pos, u.uni_pos_off = first.uni_pos_off, u.pos_n = first.pos_n, u.cov = cov;
+				u.length1 = last.read_pos + last.length - first.read_pos, u.length2 = last.uni_pos_off + last.length - first.uni_pos_off;   // (a group of one: its length)
+				++nvu;
+				first = x, cov = x.length;
+			}
+			last = x;
+		}
+	}
+	// expand_seed: one position per seed
+	USeed a, b;
+	PathN pa, pb;
+	const uint32_t n = (uint32_t)nvu;
+	{
+		const uint32_t r0 = n > 0 ? (uint32_t)(ix.pos[ix.posp[u0.uid]] + u0.uni_pos_off - 1) : 0u;
+		const uint32_t r1 = n > 1 ? (uint32_t)(ix.pos[ix.posp[u1.uid]] + u1.uni_pos_off - 1) : 0u;
+		a.seed_id = 0, a.read_begin = u0.read_pos, a.read_end = u0.read_pos + u0.length1 - 1, a.ref_begin = r0, a.ref_end = r0 + u0.length2 - 1, a.cov = u0.cov;
+		b.seed_id = 1, b.read_begin = u1.read_pos, b.read_end = u1.read_pos + u1.length1 - 1, b.ref_begin = r1, b.ref_end = r1 + u1.length2 - 1, b.cov = u1.cov;
+	}
+	if (n == 2 && (b.ref_end != a.ref_end ? b.ref_end < a.ref_end : b.ref_begin < a.ref_begin)) { const USeed t = a; a = b, b = t; }   // sort by (ref_end, ref_begin), stable
+	const bool is_str = c.is_str[read] != 0;
+	const int max_ref_dis = is_str ? 400 : 50, max_read_dis = is_str ? 400 : 50;
+	const uint32_t max_gap = is_str ? 20 : 50;
+	// (search_step = min(n, 40 | 80) = n: both scans see the whole list)
+	pa.dist = (int32_t)a.cov, pa.pre_node = -1, pa.used = 0, pa.brk = n;
+	pb.dist = (int32_t)b.cov, pb.pre_node = -1, pb.used = 0, pb.brk = 2;
+	if (n == 2) {
+		// the two seeds come from different groups (seed_id 0 and 1)
+		if (b.ref_end != a.ref_end && (int32_t)(b.ref_begin - a.ref_end) > max_ref_dis) pa.brk = 1;
+		int32_t cur = 0, pn = -1;
+		bool any = false;
+		if (pa.brk > 1 && b.ref_end != a.ref_end) {
+			const int32_t dis_ref = (int32_t)(b.ref_begin - a.ref_end), dis_read = (int32_t)(b.read_begin - a.read_end);
+			const uint32_t abs_gap = dis_read > dis_ref ? (uint32_t)(dis_read - dis_ref) : (uint32_t)(dis_ref - dis_read);
+			if (!(dis_read > max_read_dis) && !(abs_gap > max_gap)) {
+				const int32_t penalty = abs_gap == 0 ? 0 : (int32_t)((abs_gap >> 3) + 3);
+				uint32_t weight = 0;
+				bool edge = true;
+				if (dis_read == dis_ref) weight = b.cov - (uint32_t)((1 - dis_read) > 0 ? (1 - dis_read) : 0);
+				else if (dis_read > 0 && dis_ref > 0) weight = b.cov;
+				else if (dis_read >= -5 && dis_read <= 0 && dis_ref >= -5) weight = b.cov + (uint32_t)(dis_read < dis_ref ? dis_read : dis_ref);
+				else edge = false;
+				if (edge) {
+					any = true;
+					const int32_t temp = pa.dist + (int32_t)weight - penalty;
+					if (cur <= temp) cur = temp, pn = 0;
+				}
+			}
+		}
+		if (any) pb.dist = cur, pb.pre_node = pn;
+	}
+	uint64_t hs = 1469598103934665603ULL, hd = hs;
+	if (c.trace && n) {
+		for (uint32_t i = 0; i < n; ++i) {
+			const USeed &v = i ? b : a;
+			const PathN &q = i ? pb : pa;
+			hs = fnv1a(hs, v.read_begin); hs = fnv1a(hs, v.read_end); hs = fnv1a(hs, v.seed_id);
+			hs = fnv1a(hs, v.ref_begin); hs = fnv1a(hs, v.ref_end); hs = fnv1a(hs, v.cov);
+			hd = fnv1a(hd, (uint64_t)(int64_t)q.dist); hd = fnv1a(hd, (uint64_t)(int64_t)q.pre_node);
+		}
+	}
+	// ---- the chain selection (select_read / sort_output) on these nodes; the other strand has none
+	const long long item = (read >> 1) * 3 + (read & 1);
+	const int32_t rc_item = c.rcnt[item];
+	const long long ro = c.poff[read >> 1] + ((read & 1) ? c.rcnt[(read >> 1) * 3] : 0) + rc_item;
+	int draws = 0, ncc = 0;
+	uint32_t max_chain = 0;
+	ChainCand c0, c1;
+	c0.chain_score = c1.chain_score = 0, c0.max_index = c1.max_index = 0, c0.read_bg = c1.read_bg = 0, c0.ref_bg = c1.ref_bg = 0, c0.chr_id = c1.chr_id = 0, c0.direction = c1.direction = 0;
+	for (int it = 0; it < kMaxOut && n; ++it) {
+		// sort_output: the best unused chain end; tied ends draw
+		bool got = false;
+		ChainCand out;
+		for (;;) {
+			int maxi = -1, same = 1;
+			int32_t maxd = 0;
+			if (n == 2 && !pb.used) { const int32_t d = pb.dist; if (maxd < d) maxd = d, maxi = 1, same = 1; else if (maxd == d) same++; }
+			if (!pa.used) { const int32_t d = pa.dist; if (maxd < d) maxd = d, maxi = 0, same = 1; else if (maxd == d) same++; }
+			if (maxi < 0) break;
+			if (same > 1) {
+				const long long k = ro + draws - c.grand_base;
+				const int32_t r = (k >= 0 && k < c.grand_n) ? c.grand[k] : (*c.err = 2, 0);
+				++draws;
+				const uint32_t pick = (uint32_t)r % (uint32_t)same;
+				uint32_t seen = 0;
+				bool done = false;
+				if (n == 2 && !pb.used && pb.dist == maxd) { if (seen == pick) maxi = 1, done = true; else ++seen; }
+				if (!done && !pa.used && pa.dist == maxd) { if (seen == pick) maxi = 0; }
+			}
+			int used = 0, unused = 0, node = maxi;
+			for (;;) {
+				PathN &q = node ? pb : pa;
+				if (q.used) used++; else unused++;
+				q.used = 1;
+				if (q.pre_node == -1) break;
+				node = q.pre_node;
+			}
+			// (orig_first - orig_final <= 1 here: the bulk marking of rr.cpp:284 never applies)
+			if (used >= unused) continue;
+			const USeed &v = node ? b : a;
+			const int chr = get_chromosome_id(ix, v.ref_begin);
+			out.direction = o == 0 ? kFwd : kRev, out.max_index = (uint32_t)maxi, out.chain_score = (uint32_t)maxd, out.read_bg = v.read_begin, out.chr_id = chr;
+			out.ref_bg = v.ref_begin - ix.chr_end_n[chr - 1];
+			got = true;
+			break;
+		}
+		if (!got) break;
+		const uint32_t cs = out.chain_score;
+		if (cs > max_chain) max_chain = cs;
+		if (cs + 30 < max_chain || cs < 30) break;
+		if (ncc == 0) c0 = out; else c1 = out;
+		++ncc;
+	}
+	if (ncc == 2 && (c1.chain_score != c0.chain_score ? c1.chain_score > c0.chain_score : c1.max_index < c0.max_index)) { const ChainCand t = c0; c0 = c1, c1 = t; }
+	int keep = 0;
+	if (!(ncc == 0 || max_chain < 20)) {
+		keep = ncc;
+		if (c0.chain_score + 30 < max_chain) keep = 0;
+		else if (ncc == 2 && c1.chain_score + 30 < max_chain) keep = 1;
+	}
+	// ---- everything fits: write what chain_read + select_read would have left
+	long long ubase = 0;
+	if (n) {
+		ubase = arena_alloc(c.us, 2ull * n);                               // (same footprint as the generic path: second half = its merge-sort scratch)
+		if (ubase < 0) return true;                                        // arena full: flagged, the batch runs again with a larger one
+		c.us.base[ubase] = a, c.path[ubase] = pa;
+		if (n == 2) c.us.base[ubase + 1] = b, c.path[ubase + 1] = pb;
+	}
+	st.us_off = ubase, st.us_n = n;
+	if (c.trace && n) st.seed_hash = hs, st.chain_hash = hd;
+	sx.us_off = 0, sx.us_n = 0;
+	c.hcnt[read] = 0;
+	if (c.stats) stat_add(c, ST_SEEDS, n);
+	ChainCand *cc = c.ccand + read * 12;
+	if (ncc > 0) cc[0] = c0;
+	if (ncc > 1) cc[1] = c1;
+	c.rcnt[item] = rc_item + draws;
+	c.n_ccand[read] = keep;
+	return true;
 }
 
 PSVR_HD void get_refseq(const DevIndex &ix, uint8_t *ref, uint32_t len, uint32_t start)

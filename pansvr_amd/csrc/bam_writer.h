@@ -16,11 +16,23 @@
 #include <string.h>
 #include <zlib.h>
 #include <atomic>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 namespace psvr {
+
+// A byte buffer whose resize() does not zero what it adds: the record formatters reserve a bound, write through a raw pointer and
+// shrink to what they wrote (value-initialising the slack was a second pass over every output byte).
+template <class T> struct NoInitAlloc : std::allocator<T> {
+	template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+	NoInitAlloc() = default;
+	template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+	template <class U> void construct(U *p) { ::new ((void *)p) U; }
+	template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+typedef std::vector<uint8_t, NoInitAlloc<uint8_t>> Bytes;
 
 class BgzfWriter {
 	FILE *f_ = nullptr;
@@ -122,8 +134,8 @@ struct SamFields {
 
 class BamWriter {
 	BgzfWriter z_;
-	static void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
-	static void put16(std::vector<uint8_t> &v, uint16_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }
+	template <class V> static void put32(V &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+	template <class V> static void put16(V &v, uint16_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }
 	static int reg2bin(int64_t beg, int64_t end)             // SAMv1 section 5.3
 	{
 		--end;
@@ -134,7 +146,7 @@ class BamWriter {
 		if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
 		return 0;
 	}
-	static void put_int_tag(std::vector<uint8_t> &v, long long x)   // smallest type, as sam_parse1 chooses
+	template <class V> static void put_int_tag(V &v, long long x)   // smallest type, as sam_parse1 chooses
 	{
 		if (x < 0) {
 			if (x >= -128) v.push_back('c'), v.push_back((uint8_t)(int8_t)x);
@@ -146,7 +158,7 @@ class BamWriter {
 			else v.push_back('I'), put32(v, (uint32_t)x);
 		}
 	}
-	static bool put_tags(std::vector<uint8_t> &v, const std::string &tags)
+	template <class V> static bool put_tags(V &v, const std::string &tags)
 	{
 		size_t i = 0;
 		while (i < tags.size()) {
@@ -200,7 +212,7 @@ public:
 		return true;
 	}
 	// appends one encoded record (block_size + body) to `out`; thread-safe (touches no writer state)
-	static bool encode(const SamFields &s, std::vector<uint8_t> &rec_)
+	template <class V> static bool encode(const SamFields &s, V &rec_)
 	{
 		const size_t base = rec_.size();
 		if (s.qname.empty() || s.qname.size() > 254) return false;   // l_read_name is one byte (htslib: "query name too long")

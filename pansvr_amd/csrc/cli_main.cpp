@@ -113,7 +113,7 @@ struct OutFile {
 		return bam.open(fn.c_str(), H.text, refs, threads, level);
 	}
 	// formatted records (SAM lines or encoded BAM records) of a run of pairs, in order
-	void write_raw(const std::vector<uint8_t> &b) { if (b.empty()) return; if (is_bam) bam.write_raw(b.data(), b.size()); else fwrite(b.data(), 1, b.size(), sam); }
+	void write_raw(const psvr::Bytes &b) { if (b.empty()) return; if (is_bam) bam.write_raw(b.data(), b.size()); else fwrite(b.data(), 1, b.size(), sam); }
 	bool close() { if (is_bam) return bam.close(); return fclose(sam) == 0; }
 };
 
@@ -300,7 +300,7 @@ int main(int argc, char **argv)
 		FastqBatch fb;
 		std::vector<Block> blk;
 		long long pair_base = 0;
-		std::vector<std::vector<uint8_t>> mb, ob;   // formatted records of both files, per chunk of pairs
+		std::vector<psvr::Bytes> mb, ob;   // formatted records of both files, per chunk of pairs
 		int state = 0;              // 0 free, 1 loaded, 2 aligned, 3 formatted
 		bool last = false;          // end-of-input marker travelling through the stages
 		long long batch_pairs_done = 0;   // > 0 on the last piece of a reference-sized batch: that batch's pairs (the progress line)
@@ -368,7 +368,7 @@ int main(int argc, char **argv)
 			}
 			// ---- step 2: records of both files, formatted for runs of pairs on -t threads and written in input order
 			const long long chunk = 4096, nchunk = (P + chunk - 1) / chunk;
-			std::vector<std::vector<uint8_t>> &mb = J.mb, &ob = J.ob;
+			std::vector<psvr::Bytes> &mb = J.mb, &ob = J.ob;
 			mb.resize((size_t)nchunk), ob.resize((size_t)nchunk);
 			for (auto &v : mb) v.clear();        // (capacity is kept from the slot's previous batch: no growth copies in steady state)
 			for (auto &v : ob) v.clear();

@@ -530,8 +530,26 @@ __global__ __launch_bounds__(kBlock) void k_chain(Ctx c, const int32_t *list, co
 // chaining and chain selection of a read by the same thread, one launch: the selection walks what the chaining has just written
 __global__ __launch_bounds__(kBlock) void k_chain_select(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
-	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-	if (i < (long long)*cnt) { const long long r = list[i]; chain_read(c, r); select_read(c, r); }
+	const long long n = (long long)*cnt;          // (what k_chain_small left over: a fixed grid walks the list)
+	const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+	if (n <= 2 * nwaves) {
+		// a handful of reads: one per wavefront at a time.  The lanes of a wavefront that walk different reads' loops take turns, so 64 of
+		// these reads in one wavefront last as long as 64 reads one after the other (~80 us for the ~800 reads a 1 M-pair round leaves over)
+		if (threadIdx.x & 63) return;
+		for (long long i = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += nwaves) { const long long r = list[i]; chain_read(c, r); select_read(c, r); }
+		return;
+	}
+	for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { const long long r = list[i]; chain_read(c, r); select_read(c, r); }
+}
+// chain + select of the listed reads in registers (chain_select_small, aln_device.h); the few reads it declines -- MEMs on both strands,
+// more than two seeds, a unipath with several reference positions -- are listed for k_chain_select (one atomic per such read: a handful per
+// thousand)
+__global__ __launch_bounds__(kBlock) void k_chain_small(Ctx c, const int32_t *list, const unsigned int *cnt, int32_t *left, unsigned int *left_cnt)
+{
+	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (i >= (long long)*cnt) return;
+	const int32_t r = list[i];
+	if (!chain_select_small(c, r)) left[atomicAdd(left_cnt, 1u)] = r;
 }
 // the pairing stage over a list whose length only the device knows yet (right behind k_dirty / k_reselect, before the host has read the counts)
 __global__ __launch_bounds__(kBlock) void k_pair_dev(Ctx c, const int32_t *list, const unsigned long long *cnt)
@@ -1065,7 +1083,7 @@ struct GpuBE {
 	std::vector<std::pair<std::string, long long>> launches;   // for psvr_engine_stats
 	DevBuf plan_bucket, plan_hist, plan_idx, plan_poff, plan_plen, plan_bstart, plan_qpad, plan_tpad, pslab, strip_ws;
 	DpParams dpP;
-	bool dp_ready = false;
+	bool dp_ready = false, dp_lean = false;
 	static constexpr long long kTeamMinProblems = 32768;       // below this a round's DP problems go to the wavefront-per-alignment kernels
 	static constexpr int kSide = 4;                            // side streams: the DP kernels of a round are independent of each other
 	hipStream_t side[kSide] = {};
@@ -1135,7 +1153,9 @@ struct GpuBE {
 	// small transfers (counters, lists of a few thousand pairs) go through a pinned staging buffer: a copy to or from pageable
 	// memory costs several times the latency
 	void *pin = nullptr;
-	static constexpr size_t kPin = (size_t)4 << 20, kPinUse = kPin - 4096;   // the last 4 KB are st_dp's slot for an upload nobody waits for
+	// layout of the 4 MB buffer: [0, 1.5 MB) staging of the small readbacks; [1.5 MB, 4 MB - 4 KB) the long readback of d2h_early_late, which stays
+	// valid (the host reads the variant table in place) until the next one; the last 4 KB st_dp's slot for an upload nobody waits for
+	static constexpr size_t kPin = (size_t)4 << 20, kLateAt = (size_t)3 << 19, kPinUse = kLateAt;
 	void *pinned() { if (!pin && hipHostMalloc(&pin, kPin, hipHostMallocDefault) != hipSuccess) pin = nullptr; return pin; }
 	// Small uploads do not wait: they are staged in a ring of page-locked memory and ride the stream in order.  A slot is reused only
 	// after kUp bytes of later uploads, and every round of the engine synchronises the stream several times in between (its readbacks),
@@ -1181,6 +1201,31 @@ struct GpuBE {
 		}
 		d2h(h1, d1, n1), d2h(h2, d2, n2);
 	}
+	// Two small readbacks the host waits for (an event behind them), and a long one queued behind the event that it does NOT wait for: the
+	// caller goes on with what the small ones brought, and the long copy is there after the stream's next synchronisation (d2h_late_done
+	// makes sure).  Returns where the long one lands -- a region of the page-locked buffer that nothing else uses, valid until the next call
+	// -- or nullptr when it does not fit (nothing was queued for it then: the caller fetches it some other way).
+	hipEvent_t ev_early = nullptr;
+	bool late_pending = false;
+	int32_t *d2h_early_late(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, const void *dl, size_t nl)
+	{
+		if (!h2) n2 = 0;
+		if (!pinned() || n1 + n2 > kLateAt || (!ev_early && hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess)) {
+			if (n2) d2h2(h1, d1, n1, h2, d2, n2); else d2h(h1, d1, n1);
+			return nullptr;
+		}
+		char *p = (char *)pin;
+		note(hipMemcpyAsync(p, d1, n1, hipMemcpyDeviceToHost, stream));
+		if (n2) note(hipMemcpyAsync(p + n1, d2, n2, hipMemcpyDeviceToHost, stream));
+		note(hipEventRecord(ev_early, stream));
+		const bool fits = nl <= kPin - 4096 - kLateAt;
+		if (fits) { note(hipMemcpyAsync(p + kLateAt, dl, nl, hipMemcpyDeviceToHost, stream)); late_pending = true; }
+		note(hipEventSynchronize(ev_early));
+		memcpy(h1, p, n1);
+		if (n2) memcpy(h2, p + n1, n2);
+		return fits ? (int32_t *)(p + kLateAt) : nullptr;
+	}
+	void d2h_late_done() { if (late_pending) { note(hipStreamSynchronize(stream)); synced(); late_pending = false; } }
 	// four small readbacks with one synchronisation
 	void d2h4(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, void *h3, const void *d3, size_t n3, void *h4, const void *d4, size_t n4)
 	{
@@ -1200,6 +1245,7 @@ struct GpuBE {
 	{
 		if (pin) (void)hipHostFree(pin);
 		if (up_ring) (void)hipHostFree(up_ring);
+		if (ev_early) (void)hipEventDestroy(ev_early);
 		for (int i = 0; i < kSide; ++i) {
 			if (side[i]) (void)hipStreamSynchronize(side[i]), (void)hipStreamDestroy(side[i]);
 			if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
@@ -1225,11 +1271,30 @@ struct GpuBE {
 		}
 		note(hipGetLastError());
 	}
-	DevBuf mem_list;
+	DevBuf mem_list, left_list;
+	static bool chain_small_on() { static const bool v = getenv("PSVR_NO_CHAIN_SMALL") == nullptr; return v; }   // (A/B runs and tests: the generic kernel for every read)
 	void st_chain(const Ctx &c, const int32_t *w, long long n, int mate)
 	{
 		(void)w, (void)mate;
-		if (n > 0) { t0("k_chain_select"); hipLaunchKernelGGL(k_chain_select, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, (const int32_t *)(mem_list.as<int32_t>() + 4), (const unsigned int *)mem_list.p); t1(); }
+		if (n <= 0) return;
+		const int32_t *list = mem_list.as<int32_t>() + 4;
+		const unsigned int *cnt = (const unsigned int *)mem_list.p;
+		if (chain_small_on() && left_list.ensure((size_t)(n + 4) * 4) == hipSuccess) {
+			// the register-resident small case for (nearly) every read, then the generic pair of stages over what it left
+			note(hipMemsetAsync(left_list.p, 0, 4, stream));
+			t0("k_chain_small");
+			hipLaunchKernelGGL(k_chain_small, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, list, cnt, left_list.as<int32_t>() + 4, (unsigned int *)left_list.p);
+			t1();
+			list = left_list.as<int32_t>() + 4, cnt = (const unsigned int *)left_list.p;
+			const unsigned g = grid_for(n);
+			t0("k_chain_select");
+			hipLaunchKernelGGL(k_chain_select, dim3(g < 512u ? g : 512u), dim3(kBlock), 0, stream, c, list, cnt);
+			t1();
+		} else {
+			t0("k_chain_select");
+			hipLaunchKernelGGL(k_chain_select, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, list, cnt);
+			t1();
+		}
 		note(hipGetLastError());
 	}
 	void st_select(const Ctx &, const int32_t *, long long, int) {}      // (done by k_chain_select)
@@ -1492,6 +1557,9 @@ struct GpuBE {
 			int rc = make_dp_params(&kp, 0, &dpP);
 			if (rc) return rc;
 			note(dp_allow_big_lds());
+			// the engine reads score, mqe and the CIGAR of its pieces, never ez.max / max_q / max_t: when the z-drop rule cannot trigger for these
+			// scoring parameters (the reference's defaults), the team kernel runs without the per-diagonal maximum (PSVR_DP_NO_LEAN=1: A/B runs)
+			dp_lean = dp_zdrop_inert(dpP) && getenv("PSVR_DP_NO_LEAN") == nullptr;
 			dp_ready = true;
 		}
 		// upper bounds for the sequence buffers: every problem has qlen, tlen < 1600; size from the actual lens
@@ -1587,8 +1655,8 @@ struct GpuBE {
 		B.idx = plan_idx.as<int32_t>();
 		if (team.T.n_classes) {
 			t0("extd2_team_kernel");
-			team.launch_sweep(stream, B, dpP);
-			if (!fan) team.launch_finish(stream, B, dpP);
+			team.launch_sweep(stream, B, dpP, dp_lean);
+			if (!fan) team.launch_finish(stream, B, dpP, dp_lean);
 			t1();
 			PSVR_HIP(hipGetLastError());
 		}
@@ -1622,7 +1690,7 @@ struct GpuBE {
 		if (!team.T.n_classes && used > 2) used = side2_forked ? 3 : 2;   // (the side streams that were used)
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipEventRecord(ev_join[k], side[k]));
 		B.idx = plan_idx.as<int32_t>();
-		if (team.T.n_classes && fan) { team.launch_finish(stream, B, dpP); PSVR_HIP(hipGetLastError()); }
+		if (team.T.n_classes && fan) { team.launch_finish(stream, B, dpP, dp_lean); PSVR_HIP(hipGetLastError()); }
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipStreamWaitEvent(stream, ev_join[k], 0));
 		return PSVR_OK;
 	}
@@ -1647,10 +1715,24 @@ __global__ void k_build_occupancy(const uint64_t *hash, uint32_t *occ, long long
 	occ[w] = bits;
 }
 
+// the Bloom filter over the index's 20-mers (kmer_maybe_present, aln_device.h): a thread per first-level bucket, which holds the 22-mers
+// whose first 14 bases are its number; the low 16 bits of an entry are the 22-mer's last 8 bases
+__global__ void k_build_bloom(const uint64_t *hash, const uint32_t *kmer, long long nbuckets, unsigned long long *bloom, uint32_t shift)
+{
+	const long long h = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (h >= nbuckets) return;
+	const uint64_t lo = hash[h], hi = hash[h + 1];
+	for (uint64_t i = lo; i < hi; ++i) {
+		uint64_t w, m;
+		bloom_slot(((uint64_t)h << 12) | (uint64_t)(kmer[i] >> 4), shift, w, m);
+		atomicOr(bloom + w, (unsigned long long)m);
+	}
+}
+
 struct psvr_index {
 	int device = 0;
 	HostIndex host;          // small tables + strings stay on the host too (SAM formatting)
-	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, uid_hint;
+	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, uid_hint, bloom;
 	DevIndex dev;
 	int64_t bytes = 0;
 };
@@ -1718,6 +1800,25 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32
 	PSVR_HIP(hipGetLastError());
 	PSVR_HIP(hipDeviceSynchronize());
 	d.occ = ix->occ.as<uint32_t>();
+	// the Bloom filter over the 20-mers, sized to ~10 bits per k-mer (a power of two of 64-bit words; PSVR_BLOOM_LOG2=<log2 bytes> fixes
+	// the size, 0 leaves the occupancy bitmap as the only filter)
+	{
+		int lg = 0;
+		if (const char *e = getenv("PSVR_BLOOM_LOG2")) lg = atoi(e);
+		else { lg = 20; while (lg < 30 && ((uint64_t)8 << lg) < v->n_kmer * 10) ++lg; }
+		if (lg >= 16 && lg <= 32) {
+			const size_t bytes = (size_t)1 << lg;
+			PSVR_HIP(ix->bloom.alloc(bytes));
+			ix->bytes += (int64_t)bytes;
+			PSVR_HIP(hipMemset(ix->bloom.p, 0, bytes));
+			const uint32_t shift = (uint32_t)(64 - (lg - 3));
+			const long long NB = (long long)1 << 28;
+			hipLaunchKernelGGL(k_build_bloom, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, nullptr, d.hash, d.kmer, NB, (unsigned long long *)ix->bloom.p, shift);
+			PSVR_HIP(hipGetLastError());
+			PSVR_HIP(hipDeviceSynchronize());
+			d.bloom = ix->bloom.as<uint64_t>(), d.bloom_shift = shift;
+		}
+	}
 	// bracket table for the unipath-of-position search (aln_device.h mem_for_hit): one entry per 1024 positions
 	{
 		const uint32_t sh = 10;
@@ -1860,7 +1961,7 @@ extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_
 		ix->bytes += (int64_t)s0.bytes;
 	};
 	cp(ix->ref_seq, src->ref_seq), cp(ix->seq, src->seq), cp(ix->seqf, src->seqf), cp(ix->pos, src->pos), cp(ix->posp, src->posp), cp(ix->hash, src->hash);
-	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->uid_hint, src->uid_hint);
+	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->uid_hint, src->uid_hint), cp(ix->bloom, src->bloom);
 	if (he == hipSuccess) he = hipDeviceSynchronize();
 	if (he != hipSuccess) { delete ix; return set_error(PSVR_ERR_DEVICE, "psvr_index_clone: %s", hipGetErrorString(he)); }
 	DevIndex &d = ix->dev;
@@ -1869,6 +1970,7 @@ extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_
 	d.posp = ix->posp.as<uint64_t>(), d.hash = ix->hash.as<uint64_t>(), d.off = ix->off.as<uint64_t>(), d.kmer = ix->kmer.as<uint32_t>();
 	d.chr_end_n = ix->chr_end.as<uint32_t>(), d.chr_search_index = ix->chr_idx.as<uint32_t>(), d.sv = ix->sv.as<SvDev>();
 	d.occ = ix->occ.as<uint32_t>(), d.uid_hint = ix->uid_hint.as<uint32_t>();
+	if (src->bloom.p) d.bloom = ix->bloom.as<uint64_t>();
 	*out = ix;
 	return PSVR_OK;
 }
@@ -1894,7 +1996,7 @@ __global__ __launch_bounds__(kBlock) void k_b3_search_kmer(DevIndex ix, long lon
 	if (i >= n) return;
 	const uint64_t kmer = kmers[i] & 0xffffffffffull;
 	uint64_t first = 0;
-	const uint32_t nh = bucket_occupied(ix, kmer >> 12) ? probe_kmer(ix, kmer, first) : 0;
+	const uint32_t nh = kmer_maybe_present(ix, kmer) ? probe_kmer(ix, kmer, first) : 0;
 	found[i] = nh != 0;
 	range[2 * i] = nh ? (long long)first : 0, range[2 * i + 1] = nh ? (long long)(first + nh - 1) : -1;
 }

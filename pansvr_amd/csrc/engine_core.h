@@ -483,8 +483,12 @@ template <class BE> struct EngineCore {
 		void clear() { n = 0; }
 		int32_t *data() { return p; }
 		const int32_t &operator[](size_t i) const { return p[i]; }
+		// the table as a view of memory somebody else owns (the backend's page-locked readback region: no copy out of it)
+		bool alias = false;
+		void view(int32_t *ext, size_t want) { if (!alias) free(p); p = ext, n = want, cap = 0, alias = true; }
 		bool resize(size_t want)
 		{
+			if (alias) p = nullptr, cap = 0, alias = false;
 			if (want > cap) {
 				free(p);
 				cap = want + want / 4 + 1024;
@@ -494,7 +498,7 @@ template <class BE> struct EngineCore {
 			n = want;
 			return true;
 		}
-		~HostTable() { free(p); }
+		~HostTable() { if (!alias) free(p); }
 		HostTable() = default;
 		HostTable(const HostTable &) = delete;
 		HostTable &operator=(const HostTable &) = delete;
@@ -620,21 +624,33 @@ template <class BE> struct EngineCore {
 			pre_tot = false;
 			unsigned long long nnew_chg[2] = {0, 0};           // newly count-sensitive pairs; did any evaluated slot draw a different number than last time?
 			const bool want_vcnt = vcnt.empty() && V && work == nullptr;   // the variant slots' draw counts ride on the same synchronisation
-			if (want_vcnt && !vcnt.resize((size_t)3 * V)) { err = "host allocation failed (variant table)"; rc = PSVR_ERR_NOMEM; break; }
 			if (work == nullptr && nshadow == 0) {
-				// first round: which pairs the host walk below looks at is known already (unless a pair turns out count-sensitive just now:
-				// then once more), so the offset scans and the gather go out behind the totals and ONE synchronisation brings everything
-				// (the special pairs every variant of which draws alike leave the host's hands here: unmasked, class 1)
+				// first round: the offset scans go out behind the totals.  Two short readbacks instead of one long one: first the counters and
+				// the special pairs' classes (the pairs every variant of which draws alike leave the host's hands here: unmasked, class 1 --
+				// six of seven on the bench batch), with the variant slots' draw counts (1 MB) queued behind them; the host marks the classes
+				// and builds its list of the pairs that are left while that copy runs, and the gather for just those pairs brings it in.
+				// (One readback of everything had the host walk 20 k pairs, 17 k of them to find they were none of its business, behind a
+				// 1.4 MB copy: 0.39 ms of idle GPU per step.)
 				const bool classify = want_vcnt && !special.empty();
 				if (classify) be.st_special_class(c, d_special, (long long)special.size(), d_mask, d_sp_class);
 				enqueue_offset_scans();
-				build_listed();
-				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(),
-				                 nnew_chg, d_tops + 8, 16, want_vcnt ? vcnt.data() : nullptr, c.rcnt + 3 * P, want_vcnt ? (size_t)3 * V * 4 : 0,
-				                 classify ? h_sp_class.data() : nullptr, d_sp_class, classify ? special.size() : 0);
+				int32_t *late = want_vcnt ? be.d2h_early_late(nnew_chg, d_tops + 8, 16, classify ? h_sp_class.data() : nullptr, d_sp_class, classify ? special.size() : 0,
+				                                              c.rcnt + 3 * P, (size_t)3 * V * 4)
+				                          : (be.d2h(nnew_chg, d_tops + 8, 16), (int32_t *)nullptr);
 				if (classify) for (size_t i = 0; i < special.size(); ++i) if (h_sp_class[i] && is_special[i] == 1) is_special[i] = 2;
+				build_listed();
+				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0);
+				if (want_vcnt) {
+					be.d2h_late_done();                      // (the gather's synchronisation has brought the late copy in as well; no list, no gather: waits here)
+					if (late) vcnt.view(late, (size_t)3 * V);
+					else if (!vcnt.resize((size_t)3 * V)) { err = "host allocation failed (variant table)"; rc = PSVR_ERR_NOMEM; break; }
+					else be.d2h(vcnt.data(), c.rcnt + 3 * P, (size_t)3 * V * 4);
+				}
 				gathered = true;
-			} else if (want_vcnt) be.d2h2(nnew_chg, d_tops + 8, 16, vcnt.data(), c.rcnt + 3 * P, 3 * V * 4);
+			} else if (want_vcnt) {
+				if (!vcnt.resize((size_t)3 * V)) { err = "host allocation failed (variant table)"; rc = PSVR_ERR_NOMEM; break; }
+				be.d2h2(nnew_chg, d_tops + 8, 16, vcnt.data(), c.rcnt + 3 * P, 3 * V * 4);
+			}
 			else be.d2h(nnew_chg, d_tops + 8, 16);
 			const unsigned long long nnew = nnew_chg[0];
 			// A re-run round in which every slot drew exactly as often as at its previous evaluation leaves every offset where it is: the

@@ -69,8 +69,12 @@ struct TeamPlan {
 	// scratch of class c's wavefront w at ws_base[c] + w * ws_need[c] (sized by the class's longest query)
 	unsigned long long ws_base[PSVR_DP_NUM_LDS_CLASSES], ws_need[PSVR_DP_NUM_LDS_CLASSES];
 };
-template <int LANES, int CPL> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);          // ksw_kernels.hip: the sweep, a row per lane and step
-template <int LANES, int CPL> __global__ void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T);   // z-drop / end rules and traceback, a thread per alignment
+template <int LANES, int CPL, int LEAN> __global__ void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T);          // ksw_kernels.hip: the sweep, a row per lane and step
+template <int LANES, int CPL, int LEAN> __global__ void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T);   // z-drop / end rules and traceback, a thread per alignment
+// the z-drop rule cannot trigger whatever the sequences are: a gap of any length costs at most q2 (e2 == 0), so an anti-diagonal's maximum
+// is never more than 2 q2 below the running maximum (one insertion + one deletion from the cell that holds it); the team kernel's LEAN
+// variant (no per-diagonal maximum) is exact then, for a caller that reads neither ez.max nor max_q / max_t
+inline bool dp_zdrop_inert(const DpParams &P) { return P.e2 == 0 && (P.zdrop < 0 || P.zdrop >= 2 * P.q2) && !(P.flag & PSVR_EZ_EXTZ_ONLY); }
 // the tiny / team kernels need the lean regime (values fit int8, band never clips) and only the flags they implement
 __host__ __device__ inline bool dp_tiny_ok(const DpParams &P, bool fast_ok) { return fast_ok && P.nowrap_ok && !P.skip && (P.w < 0 || P.w >= PSVR_DP_TINY_MAX); }
 // lanes per alignment of the team kernel for the class of problems with n_strips16 16-column strips

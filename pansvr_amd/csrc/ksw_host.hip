@@ -1,6 +1,7 @@
 // ksw_host.hip -- host side of seam B2 (psvr_extd2_batch / psvr_dp_plan_*): parameter
 // preparation (ksw2_extd2_sse.c:60-98), size-class planning and kernel launches.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -216,7 +217,9 @@ extern "C" int psvr_dp_plan_launch(psvr_dp_plan_t *pl, const uint8_t *d_qseq, co
 		PSVR_HIP(hipGetLastError());
 	}
 	B.idx = pl->d_idx.as<int32_t>();
-	team.launch(stream, B, pl->P);
+	// (tests: PSVR_DP_FORCE_LEAN=1 sends a plan whose parameters make the z-drop rule inert through the variant the engine's own launches
+	// use; ez.max / max_q / max_t of its problems are then not filled in)
+	team.launch(stream, B, pl->P, getenv("PSVR_DP_FORCE_LEAN") != nullptr && dp_zdrop_inert(pl->P));
 	PSVR_HIP(hipGetLastError());
 	return PSVR_OK;
 }

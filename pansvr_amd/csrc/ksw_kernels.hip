@@ -501,7 +501,12 @@ __global__ __launch_bounds__(64) void extd2_tiny_kernel(DpBatch B, DpParams P, i
 #define PSVR_TEAM_WAVES 3          /* wavefronts per SIMD the register allocation aims at: 2 lanes x 8 columns needs 168 VGPRs (3 per SIMD); 1 x 16 at two per
                                       SIMD runs as fast (1.84 vs 1.88 ms), 2 x 8 at two 2.29 ms, 4 x 4 at five 2.17 ms, 4 x 8 at three 2.54 ms: profiles/r03e */
 #endif
-template <int LANES, int CPL>
+// LEAN = 1: no per-anti-diagonal maximum (M[], K[], G[], the D[r] records).  That maximum feeds ksw_apply_zdrop and ez.max / max_q / max_t
+// only.  With e2 == 0 a gap of ANY length costs at most q2, so every anti-diagonal behind the cell that holds the running maximum has a cell
+// reachable from it by one insertion and one deletion: its maximum is at least max - 2 q2, and with zdrop >= 2 q2 (the reference's defaults:
+// 32 / 0, zdrop 400) the rule `max - H > zdrop + l * e2` can never hold -- dp_zdrop_inert().  The engine's own launches (seam B1 reads
+// score, mqe and the CIGAR of its pieces) then run this variant; psvr_extd2_batch, whose ksw_extz_t carries max / max_q / max_t, never does.
+template <int LANES, int CPL, int LEAN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WAVES, 8))) void extd2_team_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
 	static_assert(CPL == 4 || CPL == 8 || CPL == 16, "columns per lane: direction bytes go out as dwords");
@@ -597,6 +602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 			const int st = max(0, d - qlen + 1), en = min(tlen - 1, d);
 			K[jj] = st + ((en - st) & ~3) - cb;
 		}
+		(void)M, (void)K, (void)G;
 		uint8_t *const Ein = (s & 1) ? uE0 : uE1, *const Eout = (s & 1) ? uE1 : uE0;
 		// what a step reads from memory (query base, the previous strip's boundary values, the diagonal's running maximum) is
 		// loaded one step ahead, so the loads have a whole step to arrive
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 		int d_cur = kNone, out_prev = kNone;
 		if (s > 0) {
 			e_prev = (unsigned)at4(Ein, 0);
-			if (0 <= ksteps - LANES) d_cur = at4(uD, c0);
+			if (!LEAN && 0 <= ksteps - LANES) d_cur = at4(uD, c0);
 		}
 		unsigned q_cur = ql == 0 ? query[0] : 0u;                       // query[k - ql] for k = 0 (raw byte: masking it here would wait for the load)
 		for (int kv = 0; kv < LANES - 1; ++kv) {
@@ -638,6 +644,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 			for (int g = 0; g < CPL / 4; ++g) dst[g] = dirw[g];
 		}
 		// what is still on its way through the lanes: anti-diagonals c0 + ksteps and later, none of which an earlier strip wrote
+		if (LEAN) { __threadfence_block(); continue; }
 		if (LANES > 1) {
 			const int inc = __builtin_amdgcn_update_dpp(kNone, out_prev, 0x101, 0xf, 0xf, false);
 			const int m0 = __builtin_amdgcn_update_dpp(kNone, M[0], 0x101, 0xf, 0xf, false);   // the neighbour's first is this lane's last
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 // dependent loads (a record per anti-diagonal, a direction byte per CIGAR step); inside the sweep kernel, one lane per team at three
 // wavefronts per SIMD, they took 0.39 of 2.21 ms on the DP micro-benchmark (profiles/r03e).  Thread t of block b serves team t % PB of the sweep's
 // block (b * 64 + t) / PB and finds that wavefront's scratch the way it did.
-template <int LANES, int CPL>
+template <int LANES, int CPL, int LEAN>
 __global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
 	constexpr int SW = CPL * LANES, PB = 64 / LANES, kWinRows = 8;
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpPara
 		for (int u = 0; u < 8; ++u) {
 			const int r = min(r0 + u, n_rows - 1);
 			const int w23 = at4(uD23, r);
-			kd[u] = at4(uD, r), h2[u] = (int)(short)(w23 & 0xffff), h3[u] = w23 >> 16;   // the high half holds a value only where the last query row meets the diagonal
+			kd[u] = LEAN ? 0 : at4(uD, r), h2[u] = (int)(short)(w23 & 0xffff), h3[u] = w23 >> 16;   // the high half holds a value only where the last query row meets the diagonal
 		}
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpPara
 			const int max_t = H_en0 == max_H ? en0 : st0 + ((0x7fff - (key & 0xffff)) & 4095);
 			if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - (((en0 + 16) & ~15) - 1);
 			if (r - st0 == qlen - 1 && h3[u] > ez.mqe) ez.mqe = h3[u], ez.mqe_t = st0;
-			if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) stop = true;
+			if (!LEAN && ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) stop = true;   // (LEAN: the rule cannot hold, see the sweep; ez.max / max_q / max_t stay as reset)
 			else if (r == n_rows - 1) ez.score = H_en0;                      // en0 == tlen - 1 on the last diagonal
 		}
 	}
@@ -762,8 +769,10 @@ __global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpPara
 	}
 	write_ez(out, ez, n_cigar);
 }
-template __global__ void extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>(DpBatch, DpParams, TeamPlan);
-template __global__ void extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 0>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 0>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 1>(DpBatch, DpParams, TeamPlan);
+template __global__ void extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 1>(DpBatch, DpParams, TeamPlan);
 
 // ------------------------------------------------------------------------------------------
 // general path: DP state in LDS laid out exactly like the reference's flat image

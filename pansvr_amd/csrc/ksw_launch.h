@@ -61,18 +61,21 @@ struct TeamLaunch {
 		T.ws_base[c] = ws_next;
 		ws_next += T.ws_need[c] * (unsigned long long)blocks;
 	}
-	void launch_sweep(hipStream_t stream, const DpBatch &B, const DpParams &P) const
+	// lean: the variant without the per-diagonal maximum -- only for a caller that has checked dp_zdrop_inert(P) and reads neither ez.max nor max_q / max_t
+	void launch_sweep(hipStream_t stream, const DpBatch &B, const DpParams &P, bool lean = false) const
 	{
 		if (!T.n_classes) return;
-		hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		if (lean) hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 1>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
+		else hipLaunchKernelGGL((extd2_team_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 0>), dim3((unsigned)T.first_block[T.n_classes]), dim3(64), 0, stream, B, P, T);
 	}
-	void launch_finish(hipStream_t stream, const DpBatch &B, const DpParams &P) const
+	void launch_finish(hipStream_t stream, const DpBatch &B, const DpParams &P, bool lean = false) const
 	{
 		if (!T.n_classes) return;
 		const unsigned blocks = (unsigned)T.first_block[T.n_classes], pb = 64u / PSVR_DP_TEAM_LANES;
-		hipLaunchKernelGGL((extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL>), dim3((blocks * pb + 63u) / 64u), dim3(64), 0, stream, B, P, T);
+		if (lean) hipLaunchKernelGGL((extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 1>), dim3((blocks * pb + 63u) / 64u), dim3(64), 0, stream, B, P, T);
+		else hipLaunchKernelGGL((extd2_team_finish_kernel<PSVR_DP_TEAM_LANES, PSVR_DP_TEAM_CPL, 0>), dim3((blocks * pb + 63u) / 64u), dim3(64), 0, stream, B, P, T);
 	}
-	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P) const { launch_sweep(stream, B, P), launch_finish(stream, B, P); }
+	void launch(hipStream_t stream, const DpBatch &B, const DpParams &P, bool lean = false) const { launch_sweep(stream, B, P, lean), launch_finish(stream, B, P, lean); }
 };
 // the class index a launch's `lds` value names (team kernel: index + 1 = number of 16-column strips)
 inline int dp_class_of(int lds)

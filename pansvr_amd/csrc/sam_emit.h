@@ -87,6 +87,56 @@ inline void sam_rev_qual(std::string &q)             // getReverseStr_qual_char,
 
 struct EmitStats { std::atomic<long long> dropped{0}; };
 
+// the SAM text of a record goes into the output buffer through a raw pointer: the constructor reserves a bound for the record,
+// the fields are appended without a capacity check each, close() gives back what was not used
+struct RawOut {
+	Bytes &v;
+	size_t at;
+	uint8_t *p;
+	RawOut(Bytes &buf, size_t bound) : v(buf), at(buf.size())
+	{
+		if (v.capacity() < at + bound) v.reserve((at + bound) * 2 + (1 << 16));
+		v.resize(at + bound);                          // (Bytes does not zero what it adds)
+		p = v.data() + at;
+	}
+	void close() { v.resize((size_t)(p - v.data())); }
+	void put(const char *s, size_t n) { memcpy(p, s, n), p += n; }
+	void put(const std::string &s) { put(s.data(), s.size()); }
+	void ch(char c) { *p++ = (uint8_t)c; }
+	void num(long long x)
+	{
+		char b[24];
+		int n = 24;
+		unsigned long long u = x < 0 ? 0ull - (unsigned long long)x : (unsigned long long)x;
+		do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+		if (x < 0) b[--n] = '-';
+		put(b + n, (size_t)(24 - n));
+	}
+	void tag_int(const char *tag5, long long x) { ch('\t'), put(tag5, 5), num(x); }
+};
+// SEQ / QUAL of a record: forward = the read through htslib's 4-bit code (nt16_char), reverse = getReverseStr_char /
+// getReverseStr_qual_char (the even-length quirk: the middle pair is swapped back) -- byte tables instead of a switch per base
+struct SeqTables {
+	uint8_t rc[256], n16[256];
+	SeqTables() { for (int c = 0; c < 256; ++c) rc[c] = (uint8_t)sam_rc_char((char)c), n16[c] = (uint8_t)nt16_char((char)c); }
+};
+inline const SeqTables &seq_tables() { static const SeqTables t; return t; }
+inline void put_seq_qual(RawOut &o, const char *t, const char *qt, int n, bool reverse)
+{
+	const SeqTables &T = seq_tables();
+	uint8_t *sq = o.p, *ql = sq + n + 1;
+	if (reverse) {
+		for (int i = 0; i < n; ++i) sq[i] = T.rc[(uint8_t)t[n - 1 - i]];      // A C G T N only: already what the 4-bit code gives back
+		for (int i = 0; i < n; ++i) ql[i] = (uint8_t)qt[n - 1 - i];
+		if (!(n & 1) && n >= 2) ql[n / 2 - 1] = (uint8_t)qt[n / 2 - 1], ql[n / 2] = (uint8_t)qt[n / 2];   // loop bound len/2 + 1: the middle pair is swapped back
+	} else {
+		for (int i = 0; i < n; ++i) sq[i] = T.n16[(uint8_t)t[i]];
+		memcpy(ql, qt, (size_t)n);
+	}
+	sq[n] = '\t';
+	o.p += 2 * n + 1;
+}
+
 class SamEmitter {
 public:
 	const HeaderInfo *H = nullptr;
@@ -96,9 +146,9 @@ public:
 	EmitStats *stats = nullptr;
 
 private:
-	static void put(std::vector<uint8_t> &d, const char *p, size_t n) { d.insert(d.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
-	static void put(std::vector<uint8_t> &d, const std::string &s) { put(d, s.data(), s.size()); }
-	static void put_int(std::vector<uint8_t> &d, long long v)          // %lld without the format machinery
+	static void put(Bytes &d, const char *p, size_t n) { d.insert(d.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
+	static void put(Bytes &d, const std::string &s) { put(d, s.data(), s.size()); }
+	static void put_int(Bytes &d, long long v)          // %lld without the format machinery
 	{
 		char b[24];
 		int n = 24;
@@ -107,7 +157,7 @@ private:
 		if (v < 0) b[--n] = '-';
 		put(d, b + n, (size_t)(24 - n));
 	}
-	static void put_tag_int(std::vector<uint8_t> &d, const char *tag5, long long v) { put(d, "\t", 1), put(d, tag5, 5), put_int(d, v); }
+	static void put_tag_int(Bytes &d, const char *tag5, long long v) { put(d, "\t", 1), put(d, tag5, 5), put_int(d, v); }
 	static void cigar_text(const psvr_cand_t &c, const uint32_t *cig, std::string &s)
 	{
 		char b[32];
@@ -137,7 +187,7 @@ private:
 		return true;
 	}
 	// one record after the sam_parse1 -> sam_format1 round trip
-	bool emit(std::vector<uint8_t> &dst, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar, bool has_mate, int mate_chr, uint32_t mate_pos,
+	bool emit(Bytes &dst, const std::string &name, int flag, int chr_id, uint32_t ref_bg, int mapq, const std::string &cigar, bool has_mate, int mate_chr, uint32_t mate_pos,
 	          int isize, const std::string &seq, const std::string &qual, const std::string &tags, const char *err_line) const
 	{
 		const int pos = (int)ref_bg;                               // printed with %d
@@ -220,7 +270,7 @@ private:
 
 public:
 	// output_BAM for both reads of pair p (batch-local index); r = local read index base 2 * p
-	void main_pair(const FastqBatch &B, const ResultView &V, long long p, std::vector<uint8_t> &dst) const
+	void main_pair(const FastqBatch &B, const ResultView &V, long long p, Bytes &dst) const
 	{
 		const psvr_pair_result_t &pr = V.pairs[p - V.pair0];
 		if (!pr.gain) return;
@@ -239,6 +289,7 @@ public:
 			B.seq(r, t, n);
 			const int read_l = n;
 			cg.clear();
+			const psvr_cand_t *pcd = nullptr;
 			if (is_ori) {
 				chr_id = ori.chr_id, direction = ori.direction, mapq = ori.mapq, ref_bg = ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg, align_score = ori.align_score;
 				if (ori.read_bg > 0) { snprintf(b, sizeof b, "%dS", (int)(int16_t)(uint16_t)ori.read_bg); cg += b; }
@@ -247,7 +298,7 @@ public:
 			} else {
 				const psvr_cand_t &cd = V.cands[rr.cand_off + rr.primary];
 				chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
-				cigar_text(cd, V.cig, cg);
+				if (as_bam) cigar_text(cd, V.cig, cg); else pcd = &cd;        // (the SAM path prints the operations straight into the record)
 			}
 			if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
 			const int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
@@ -259,64 +310,57 @@ public:
 				const int pos = (int)ref_bg;
 				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
 				if (nn <= 0 || nn > 254 || qn != read_l) { drop("@sam_parse1 ERROR"); continue; }
-				put(dst, nt, (size_t)nn), put(dst, "\t", 1), put_int(dst, flag), put(dst, "\t", 1);
+				const char *svs = sv->print_string(rr.prim_sv_id);
+				const char *mvs = rr.has_mate ? sv->print_string(rr.mate_sv_id) : nullptr;
+				const psvr_cand_t *sc = rr.secondary >= 0 ? &V.cands[rr.cand_off + rr.secondary] : nullptr;
+				const char *vid = sc ? sv->vcf_id(sc->sv_id) : nullptr;
 				const std::string &rn = H->names[(size_t)chr_id];
-				put(dst, rn), put(dst, "\t", 1), put_int(dst, pos), put(dst, "\t", 1), put_int(dst, mapq), put(dst, "\t", 1);
-				if (cg.empty()) put(dst, "*", 1); else put(dst, cg);
-				put(dst, "\t", 1);
+				const bool mate_named = rr.has_mate && rr.mate_chr_id >= 0 && rr.mate_chr_id < (int)H->names.size();
+				RawOut o(dst, (size_t)nn + (size_t)cn + 2 * (size_t)read_l + cg.size() + (pcd ? (size_t)pcd->n_cigar * 8 : 0) + rn.size() + (mate_named ? H->names[(size_t)rr.mate_chr_id].size() : 0) +
+				                  (svs ? strlen(svs) : 0) + (mvs ? strlen(mvs) : 0) + (vid ? strlen(vid) : 0) + 512);
+				o.put(nt, (size_t)nn), o.ch('\t'), o.num(flag), o.ch('\t');
+				o.put(rn), o.ch('\t'), o.num(pos), o.ch('\t'), o.num(mapq), o.ch('\t');
+				if (pcd && pcd->n_cigar) {
+					for (uint32_t j = 0; j < pcd->n_cigar; ++j) { const uint32_t w = V.cig[pcd->cigar_off + j]; o.num((int)(int16_t)(w >> 4)), o.ch("MIDNSHP=XB"[w & 0xf]); }
+				} else if (cg.empty()) o.ch('*'); else o.put(cg);
+				o.ch('\t');
 				if (rr.has_mate) {
 					const int mp = (int)rr.mate_ref_bg, mc = rr.mate_chr_id;
-					const bool mate_ok = mc >= 0 && mc < (int)H->names.size() && !(mp - 1 < 0);
-					if (!mate_ok) put(dst, "*", 1); else if (mc == chr_id) put(dst, "=", 1); else put(dst, H->names[(size_t)mc]);
-					put(dst, "\t", 1), put_int(dst, mp);
-				} else put(dst, "*\t0", 3);
-				put(dst, "\t", 1), put_int(dst, isize), put(dst, "\t", 1);
-				{   // SEQ through the reverse complement (getReverseStr_char) and htslib's 4-bit code; QUAL through getReverseStr_qual_char
-					const size_t at = dst.size();
-					dst.resize(at + (size_t)(2 * read_l + 1));
-					uint8_t *sq = &dst[at], *ql = sq + read_l + 1;
-					if (direction == 0) {
-						for (int i = 0; i < read_l; ++i) sq[i] = (uint8_t)sam_rc_char(t[read_l - 1 - i]);      // A C G T N only: already what the 4-bit code gives back
-						for (int i = 0; i < read_l; ++i) ql[i] = (uint8_t)qt[read_l - 1 - i];
-						if (!(read_l & 1) && read_l >= 2) ql[read_l / 2 - 1] = (uint8_t)qt[read_l / 2 - 1], ql[read_l / 2] = (uint8_t)qt[read_l / 2];   // loop bound len/2 + 1: the middle pair is swapped back
-					} else {
-						for (int i = 0; i < read_l; ++i) sq[i] = (uint8_t)nt16_char(t[i]);
-						memcpy(ql, qt, (size_t)read_l);
-					}
-					sq[read_l] = '\t';
-				}
-				put_tag_int(dst, "AS:i:", (int)align_score), put_tag_int(dst, "OS:i:", (int)ori.align_score);
-				put(dst, "\tOA:Z:", 6), put_int(dst, ori.chr_id), put(dst, ",", 1), put_int(dst, (int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg)), put(dst, ",", 1);
-				put_int(dst, (int)ori.read_bg), put(dst, ",", 1), put_int(dst, (int)ori.mapq), put(dst, rr.unmapped ? ",U;" : ",M;", 3);
-				if (!is_ori) put_tag_int(dst, "CS:i:", (int)chain_score);
-				const char *svs = sv->print_string(rr.prim_sv_id);
-				if (svs) put(dst, "\tSV:Z:", 6), put(dst, svs, strlen(svs));
-				const char *mvs = rr.has_mate ? sv->print_string(rr.mate_sv_id) : nullptr;
-				if (mvs) put(dst, "\tMV:Z:", 6), put(dst, mvs, strlen(mvs));
-				if (rr.secondary >= 0) {
-					const psvr_cand_t &sc = V.cands[rr.cand_off + rr.secondary];
-					const char *vid = sv->vcf_id(sc.sv_id);
-					put(dst, "\tXA:Z:", 6), put_int(dst, sc.chr_id), put(dst, ",", 1), put_int(dst, (int)sc.ref_bg), put(dst, ",", 1), put_int(dst, (int)sc.read_bg), put(dst, ",", 1);
-					put_int(dst, (int)sc.align_score), put(dst, sc.direction == 1 ? ",F," : ",R,", 3);
-					if (vid) put(dst, vid, strlen(vid)); else put(dst, "*", 1);
-					put(dst, ";", 1);
+					const bool mate_ok = mate_named && !(mp - 1 < 0);
+					if (!mate_ok) o.ch('*'); else if (mc == chr_id) o.ch('='); else o.put(H->names[(size_t)mc]);
+					o.ch('\t'), o.num(mp);
+				} else o.put("*\t0", 3);
+				o.ch('\t'), o.num(isize), o.ch('\t');
+				put_seq_qual(o, t, qt, read_l, direction == 0);   // SEQ through the reverse complement and htslib's 4-bit code; QUAL through getReverseStr_qual_char
+				o.tag_int("AS:i:", (int)align_score), o.tag_int("OS:i:", (int)ori.align_score);
+				o.put("\tOA:Z:", 6), o.num(ori.chr_id), o.ch(','), o.num((int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg)), o.ch(',');
+				o.num((int)ori.read_bg), o.ch(','), o.num((int)ori.mapq), o.put(rr.unmapped ? ",U;" : ",M;", 3);
+				if (!is_ori) o.tag_int("CS:i:", (int)chain_score);
+				if (svs) o.put("\tSV:Z:", 6), o.put(svs, strlen(svs));
+				if (mvs) o.put("\tMV:Z:", 6), o.put(mvs, strlen(mvs));
+				if (sc) {
+					o.put("\tXA:Z:", 6), o.num(sc->chr_id), o.ch(','), o.num((int)sc->ref_bg), o.ch(','), o.num((int)sc->read_bg), o.ch(',');
+					o.num((int)sc->align_score), o.put(sc->direction == 1 ? ",F," : ",R,", 3);
+					if (vid) o.put(vid, strlen(vid)); else o.ch('*');
+					o.ch(';');
 				}
 				{   // RC:Z = the comment as parse_ori_mapping_rst leaves it (see rewrite_comment)
-					put(dst, "\tRC:Z:", 6);
-					const size_t at = dst.size();
-					put(dst, ct, (size_t)cn);
+					o.put("\tRC:Z:", 6);
+					uint8_t *at = o.p;
+					memcpy(at, ct, (size_t)cn);
 					int32_t cut[10];
 					parse_ori_span(ct, cn, cut);
 					size_t len = (size_t)cn;
 					for (int q = 0; q < 10; ++q) {
 						if (cut[q] < 0) continue;
-						if (cut[q] < cn - 1) dst[at + (size_t)cut[q]] = ',';
+						if (cut[q] < cn - 1) at[(size_t)cut[q]] = ',';
 						else if ((size_t)cut[q] < len) len = (size_t)cut[q];
 					}
-					for (size_t i = 0; i < len; ++i) if (dst[at + i] == 0) { len = i; break; }       // (%s stops at a NUL)
-					dst.resize(at + len);
+					if (const void *z = memchr(at, 0, len)) len = (size_t)((const uint8_t *)z - at);       // (%s stops at a NUL)
+					o.p += len;
 				}
-				put(dst, "\n", 1);
+				o.ch('\n');
+				o.close();
 				continue;
 			}
 			seq.assign(t, (size_t)n);
@@ -347,7 +391,7 @@ public:
 		}
 	}
 	// the second file (rr.cpp:776-797): pairs neither the original aligner nor the re-aligner placed well
-	void ori_pair(const FastqBatch &B, const ResultView &V, long long p, std::vector<uint8_t> &dst) const
+	void ori_pair(const FastqBatch &B, const ResultView &V, long long p, Bytes &dst) const
 	{
 		const psvr_pair_result_t &pr = V.pairs[p - V.pair0];
 		if (!(pr.max_score <= min_filter_score && B.ori[2 * p].chr_id != -1 && B.ori[2 * p + 1].chr_id != -1)) return;
@@ -381,29 +425,21 @@ public:
 				const int pos = (int)rb, chr_id = ori.chr_id;
 				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
 				if (!acceptable(std::string(nt, (size_t)nn), orr[k].cigar, std::string("x"), std::string("x")) || qn != n) { drop("@ori_bam_sam_parse1 ERROR"); continue; }
-				put(dst, nt, (size_t)nn), put(dst, "\t", 1), put_int(dst, orr[k].flag), put(dst, "\t", 1), put(dst, H->names[(size_t)chr_id]), put(dst, "\t", 1);
-				put_int(dst, pos), put(dst, "\t", 1), put_int(dst, orr[k].mapq), put(dst, "\t", 1);
-				if (orr[k].cigar.empty()) put(dst, "*", 1); else put(dst, orr[k].cigar);
-				put(dst, "\t", 1);
 				const int mp = orr[k].mate_pos, mc = orr[k].mate_chr;
-				const bool mate_ok = mc >= 0 && mc < (int)H->names.size() && !(mp - 1 < 0);
-				if (!mate_ok) put(dst, "*", 1); else if (mc == chr_id) put(dst, "=", 1); else put(dst, H->names[(size_t)mc]);
-				put(dst, "\t", 1), put_int(dst, mp), put(dst, "\t", 1), put_int(dst, orr[k].isize), put(dst, "\t", 1);
-				const size_t at = dst.size();
-				dst.resize(at + (size_t)(2 * n + 1));
-				uint8_t *sq = &dst[at], *ql = sq + n + 1;
-				if (orr[k].flag & 0x10) {
-					for (int i = 0; i < n; ++i) sq[i] = (uint8_t)sam_rc_char(t[n - 1 - i]);
-					for (int i = 0; i < n; ++i) ql[i] = (uint8_t)qt[n - 1 - i];
-					if (!(n & 1) && n >= 2) ql[n / 2 - 1] = (uint8_t)qt[n / 2 - 1], ql[n / 2] = (uint8_t)qt[n / 2];
-				} else {
-					for (int i = 0; i < n; ++i) sq[i] = (uint8_t)nt16_char(t[i]);
-					memcpy(ql, qt, (size_t)n);
-				}
-				sq[n] = '\t';
-				if (!orr[k].tags.empty()) put(dst, "\t", 1), put(dst, orr[k].tags);
-				put_tag_int(dst, "MS:i:", pr.max_score);
-				put(dst, "\n", 1);
+				const bool mate_named = mc >= 0 && mc < (int)H->names.size();
+				RawOut o(dst, (size_t)nn + 2 * (size_t)n + orr[k].cigar.size() + orr[k].tags.size() + H->names[(size_t)chr_id].size() + (mate_named ? H->names[(size_t)mc].size() : 0) + 256);
+				o.put(nt, (size_t)nn), o.ch('\t'), o.num(orr[k].flag), o.ch('\t'), o.put(H->names[(size_t)chr_id]), o.ch('\t');
+				o.num(pos), o.ch('\t'), o.num(orr[k].mapq), o.ch('\t');
+				if (orr[k].cigar.empty()) o.ch('*'); else o.put(orr[k].cigar);
+				o.ch('\t');
+				const bool mate_ok = mate_named && !(mp - 1 < 0);
+				if (!mate_ok) o.ch('*'); else if (mc == chr_id) o.ch('='); else o.put(H->names[(size_t)mc]);
+				o.ch('\t'), o.num(mp), o.ch('\t'), o.num(orr[k].isize), o.ch('\t');
+				put_seq_qual(o, t, qt, n, (orr[k].flag & 0x10) != 0);
+				if (!orr[k].tags.empty()) o.ch('\t'), o.put(orr[k].tags);
+				o.tag_int("MS:i:", pr.max_score);
+				o.ch('\n');
+				o.close();
 				continue;
 			}
 			B.seq(r, t, n), seq.assign(t, (size_t)n);

@@ -37,6 +37,17 @@ struct CpuBE {
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2) { memcpy(h1, d1, n1), memcpy(h2, d2, n2); }
 	void d2h4(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, void *h3, const void *d3, size_t n3, void *h4, const void *d4, size_t n4) { d2h2(h1, d1, n1, h2, d2, n2), d2h2(h3, d3, n3, h4, d4, n4); }
+	// (GPU backend: two small readbacks now, one long one queued behind them; here everything is there at once)
+	std::vector<int32_t> late_buf;
+	int32_t *d2h_early_late(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, const void *dl, size_t nl)
+	{
+		memcpy(h1, d1, n1);
+		if (h2 && n2) memcpy(h2, d2, n2);
+		late_buf.resize(nl / 4 + 1);
+		memcpy(late_buf.data(), dl, nl);
+		return late_buf.data();
+	}
+	void d2h_late_done() {}
 	void fill_i64(long long *p, long long n, int stride, int off, long long v) { for (long long i = 0; i < n; ++i) p[off + i * stride] = v; }
 	static long long pr(const int32_t *w, long long i) { return w ? w[i] : i; }
 	void fill_iota(int32_t *p, long long n) { for (long long i = 0; i < n; ++i) p[i] = (int32_t)i; }
@@ -78,8 +89,20 @@ struct CpuBE {
 	void st_prep(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) prep_read(c, pr(w, i) * 2 + mate); }
 	void st_str(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) str_detect(c, pr(w, i) * 2 + mate); }
 	void st_seed(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < 2 * n; ++i) seed_strand(c, (pr(w, i >> 1) * 2 + mate) * 2 + (i & 1)); }
-	void st_chain(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) chain_read(c, pr(w, i) * 2 + mate); }
-	void st_select(const Ctx &c, const int32_t *w, long long n, int mate) { for (long long i = 0; i < n; ++i) select_read(c, pr(w, i) * 2 + mate); }
+	// chaining + chain selection of a read in one go, like the GPU backend: the register-resident small case first, the generic pair for what
+	// it declines (PSVR_EMU_NO_SMALL=1: the generic pair for every read)
+	long long n_small = 0, n_generic = 0;
+	void st_chain(const Ctx &c, const int32_t *w, long long n, int mate)
+	{
+		static const bool no_small = getenv("PSVR_EMU_NO_SMALL") != nullptr;
+		for (long long i = 0; i < n; ++i) {
+			const long long r = pr(w, i) * 2 + mate;
+			if (!no_small && chain_select_small(c, r)) { ++n_small; continue; }
+			++n_generic;
+			chain_read(c, r), select_read(c, r);
+		}
+	}
+	void st_select(const Ctx &, const int32_t *, long long, int) {}
 	void st_walk(const Ctx &c, const int32_t *w, long long n)
 	{
 		for (long long i = 0; i < 2 * n; ++i) walk_read(c, pr(w, i >> 1) * 2 + (i & 1));
@@ -255,12 +278,13 @@ int main(int argc, char **argv)
 		if (fsam) {       // the engine's arrays ARE the compact form (headers + candidate list + CIGAR arena)
 			ResultView V;
 			V.hdr = core.c.rh, V.pairs = core.c.pres, V.cands = core.c.cand, V.cig = core.c.cig.base;
-			std::vector<uint8_t> a, b;
+			Bytes a, b;
 			for (long long p = 0; p < fb.n_pairs(); ++p) em.main_pair(fb, V, p, a), em.ori_pair(fb, V, p, b);
 			fwrite(a.data(), 1, a.size(), fsam), fwrite(b.data(), 1, b.size(), fori);
 		}
 		core.commit();
 		fprintf(stderr, "[emu] stream_end %lld %lld %lld\n", core.grand_pos, core.hrand_pos[0], core.hrand_pos[1]);
+		fprintf(stderr, "[emu] chain+select: %lld reads by the small case, %lld by the generic pair\n", be.n_small, be.n_generic);
 		pair_base += fb.n_pairs();
 		fprintf(stderr, "[emu] batch of %lld pairs: %lld rounds, %lld pair-runs (+%lld pairing-only, +%lld shadow, %lld sensitive, %lld window misses), %lld DP problems, %lld candidates\n", fb.n_pairs(), core.stats.rounds,
 		        core.stats.pairs_run, core.stats.pair_only, core.stats.shadow_runs, core.stats.sensitive, core.stats.window_miss, core.stats.dp_problems, core.stats.cands);

@@ -138,3 +138,33 @@ def test_gpu_empty_and_degenerate():
     assert res[0]["score"] == 2 and res[0]["cigar"] == [1 << 4]
     for r in res[1:]:   # qlen<=0 or tlen<=0: the reference returns right after ksw_reset_extz
         assert r["n_cigar"] == 0 and r["score"] == -0x40000000 and r["max"] == 0
+
+
+def test_gpu_lean_team_kernel_matches_oracle(monkeypatch):
+    """The variant of the team kernel the engine's own DP launches run when the z-drop rule cannot trigger (e2 == 0, zdrop >= 2 q2: the
+    reference's defaults 2/-12, 16+1k | 32+0k, zdrop 400, band 200): no per-anti-diagonal maximum is kept, so ez.max / max_q / max_t are
+    not produced -- every other field and the CIGAR must be the oracle's.  PSVR_DP_FORCE_LEAN routes psvr_extd2_batch through it."""
+    monkeypatch.setenv("PSVR_DP_FORCE_LEAN", "1")
+    from ksw_cases import mutate
+    rng = np.random.RandomState(99)
+    cases = []
+    for k in range(3000):
+        ql = int(rng.randint(17, 200))
+        q = rand_seq(rng, ql)
+        t = mutate(rng, q, 0.04, 0.02, 0.02)
+        if k % 3:                                       # an extension: the window is the piece + 30
+            t = (t + rand_seq(rng, ql + 30))[:min(ql + 30, 201)]
+        else:                                           # an end-to-end piece
+            t = t[:201] or rand_seq(rng, 3)
+        cases.append(case(q, t))                        # the defaults of ksw_cases.DEF are the aln path's parameters
+    got = run_gpu(cases, "extd2")
+    skip = ("max", "max_q", "max_t")
+    bad = []
+    for i, (c, g) in enumerate(zip(cases, got)):
+        want = run_oracle(c, "extd2")
+        assert want["zdropped"] == 0                   # what makes the variant legal
+        a = {k: v for k, v in want.items() if k not in skip}
+        b = {k: v for k, v in g.items() if k not in skip}
+        if a != b:
+            bad.append((i, len(c["query"]), len(c["target"]), diff(want, g)))
+    assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:3])
