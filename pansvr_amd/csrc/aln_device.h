@@ -46,6 +46,8 @@ static const int kMemSlot = 32;                                     // MEMs per 
 
 struct SvDev { uint32_t chr_id; uint32_t st_pos; int32_t end_offset; int32_t pad; };
 
+struct HitRec { uint64_t kp; uint32_t uid, ul, ur, pos_n; uint32_t pad[2]; };   // 32 bytes: one sector, two 16-byte loads
+
 struct DevIndex {
 	const uint64_t *ref_seq, *seq, *seqf, *pos, *posp, *hash, *off;
 	const uint32_t *kmer;
@@ -65,6 +67,11 @@ struct DevIndex {
 	// bounds the seeding kernel --, and it answers for the 20-mer itself, not for its 14-base bucket: a read k-mer that differs from an
 	// indexed one in its last six bases (every k-mer over a mismatch) passes the bitmap and fails here.
 	const uint64_t *bloom; uint32_t bloom_shift;    // word = (kmer * K) >> bloom_shift
+	// optional: per index entry (22-mer occurrence) what UNITIG_MEM_search derives from it -- its position in the unipath sequence array, its
+	// unipath, the room to the unipath's two ends, the unipath's number of reference positions -- in one 32-byte record.  Looked up per hit
+	// these are off[hit], two bracket-table entries, three or four steps of a bisection over the unipath starts, the two starts again and
+	// two position-list offsets: ten loads each waiting for the one before, in a kernel whose lanes wait for memory four cycles of five.
+	const struct HitRec *hitrec;
 	// tests/emu only (PSVR_EMU_SPARSE_HASH): non-empty first-level buckets instead of the dense 2 GiB table
 	const uint32_t *sp_id; const uint64_t *sp_start; uint64_t sp_n, n_kmer;
 };
@@ -445,13 +452,32 @@ PSVR_HD int ctz64(uint64_t x)
 // number of consecutive j in [0,max) with A[ia + j] == B[ib + j] (2-bit packed, 32 bases per step)
 PSVR_HD uint32_t match_right(const uint64_t *A, uint64_t ia, const uint64_t *B, uint64_t ib, uint32_t max)
 {
+	// 128 bases per turn, the (up to) five words of A a turn needs requested together: A is the index's unipath sequence, in global memory, and a
+	// window at a time was one memory round trip per 32 bases of the MEM (a 150-base read that matches: five in a row); the words are
+	// exactly those the window-at-a-time loop reads
 	uint32_t n = 0;
 	while (n < max) {
-		uint64_t x = window32(A, ia + n) ^ window32(B, ib + n);
-		x = (x | (x >> 1)) & 0x5555555555555555ull;
-		uint32_t lim = max - n < 32 ? max - n : 32;
-		if (x) { uint32_t k = (uint32_t)clz64(x) >> 1; return n + (k < lim ? k : lim); }
-		n += lim;
+		const uint64_t ka = (ia + n) >> 5;
+		const unsigned sa = (unsigned)((ia + n) & 31) << 1;
+		const uint32_t rem = max - n;
+		const int nw = rem >= 128 ? 4 : (int)((rem + 31) >> 5);
+		uint64_t wa[5];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+		for (int q = 0; q < 5; ++q) wa[q] = (q < nw || (q == nw && sa != 0)) ? A[ka + q] : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+		for (int q = 0; q < 4; ++q) {
+			if (q >= nw) break;
+			const uint64_t xa = sa ? (wa[q] << sa) | (wa[q + 1] >> (64 - sa)) : wa[q];
+			uint64_t x = xa ^ window32(B, ib + n + 32u * (uint32_t)q);
+			x = (x | (x >> 1)) & 0x5555555555555555ull;
+			const uint32_t left = rem - 32u * (uint32_t)q, lim = left < 32 ? left : 32;
+			if (x) { const uint32_t k = (uint32_t)clz64(x) >> 1; return n + 32u * (uint32_t)q + (k < lim ? k : lim); }
+		}
+		n += rem < 128 ? rem : 128;
 	}
 	return max;
 }
@@ -498,8 +524,10 @@ PSVR_HD uint32_t probe_kmer(const DevIndex &ix, uint64_t kmer, uint64_t &first_h
 }
 
 // UNITIG_MEM_search (deBGA_index.cpp:105-146) for index entry `hit`; returns right_i
-PSVR_HD uint32_t mem_for_hit(const DevIndex &ix, uint64_t hit, const uint64_t *rb, uint32_t off, int L, VMem &m)
+// what the index alone says about entry `hit` (the part of UNITIG_MEM_search that does not look at the read)
+PSVR_HDN inline HitRec hit_record(const DevIndex &ix, uint64_t hit)
 {
+	HitRec h;
 	const uint64_t kp = ix.off[hit];
 	long long lo2 = 0, hi2 = (long long)ix.n_seqf - 1, uid = -1;
 	if (ix.uid_hint) {                                      // same search, started from a bracket that is known to hold the answer
@@ -515,12 +543,20 @@ PSVR_HD uint32_t mem_for_hit(const DevIndex &ix, uint64_t hit, const uint64_t *r
 	}
 	if (uid < 0) uid = hi2;
 	const uint64_t f0 = ix.seqf[uid], f1 = ix.seqf[uid + 1];
-	const uint32_t ul = (uint32_t)(kp - f0), ur = (uint32_t)(f1 - (kp + kLenKmer));
+	h.kp = kp, h.uid = (uint32_t)uid, h.ul = (uint32_t)(kp - f0), h.ur = (uint32_t)(f1 - (kp + kLenKmer));
+	h.pos_n = (uint32_t)(ix.posp[uid + 1] - ix.posp[uid]), h.pad[0] = h.pad[1] = 0;
+	return h;
+}
+PSVR_HD uint32_t mem_for_hit(const DevIndex &ix, uint64_t hit, const uint64_t *rb, uint32_t off, int L, VMem &m)
+{
+	const HitRec h = ix.hitrec ? ix.hitrec[hit] : hit_record(ix, hit);
+	const uint64_t kp = h.kp, uid = h.uid;
+	const uint32_t ul = h.ul, ur = h.ur;
 	const uint32_t lmax = ul < off ? ul : off, rmax0 = (uint32_t)(L - (int)off - kLenKmer), rmax = ur < rmax0 ? ur : rmax0;
 	const uint32_t li = 1 + match_left(ix.seq, kp, rb, off, lmax);
 	const uint32_t ri = 1 + match_right(ix.seq, kp + kLenKmer, rb, (uint64_t)off + kLenKmer, rmax);
 	m.uid = (uint64_t)uid, m.seed_id = 0, m.read_pos = off + 1 - li, m.uni_pos_off = ul + 1 - li;
-	m.length = kLenKmer + li + ri - 2, m.pos_n = (uint32_t)(ix.posp[uid + 1] - ix.posp[uid]), m.pad = 0;
+	m.length = kLenKmer + li + ri - 2, m.pos_n = h.pos_n, m.pad = 0;
 	return ri;
 }
 
@@ -556,13 +592,20 @@ template <bool LOCAL> PSVR_HD void seed_strand_t(const Ctx &c, long long rs, con
 			while (stage != 2 && off < kn) {
 				while (off < kn) {                        // stage 0
 					if (off + kLenKmer - 1 <= msr || (is_str && seed_list_at(sl, (int)kn, rev, off) == 0)) { off += kSeedStep; continue; }
-					kmer = get_kmer(off, rb);
 					if (pass == 0) ++probes;
+					kmer = get_kmer(off, rb);
 					if (kmer_maybe_present(ix, kmer)) { stage = 1; break; }
+#if defined(PSVR_DIAG_SEED) && PSVR_DIAG_SEED == 2     /* timing experiment: a strand whose first k-mer is refused is done (results are wrong) */
+					if (n == 0) { off = kn; break; }
+#endif
 					off += kSeedStep;
 				}
 				if (stage != 1) break;
+#if defined(PSVR_DIAG_SEED) && PSVR_DIAG_SEED == 1     /* timing experiment: no hash gather, no MEMs (results are wrong) */
+				nh = 0;
+#else
 				nh = probe_kmer(ix, kmer, first_hit);     // stage 1
+#endif
 				if (nh == 0 || nh > (uint32_t)kUniPosNMax) { off += kSeedStep; stage = 0; }
 				else stage = 2;
 			}
@@ -1518,31 +1561,85 @@ PSVR_HDN inline void assemble_candidate(const Ctx &c, long long cwi)
 	assemble_store(c, cwi, ar, arena_alloc(c.cig, (unsigned long long)(m > 0 ? m : 0)));
 }
 
+// PE_score's view of one alignment of a read: a candidate record or the original alignment (rr.hpp:476-534)
+struct PeItem { uint32_t align_score, chr_id, ref_bg; int32_t direction, is_ori, sv_id, end_offset; };
+PSVR_HD PeItem pe_item_of(const psvr_cand_t &d, int32_t end_offset)
+{
+	PeItem p;
+	p.align_score = d.align_score, p.chr_id = (uint32_t)d.chr_id, p.ref_bg = d.ref_bg, p.direction = d.direction, p.is_ori = 0, p.sv_id = d.sv_id, p.end_offset = end_offset;
+	return p;
+}
+
 // rest of single_end_handler::align (rr.cpp:453-475)
 // `rr`: the read's header -- c.rh[read] itself, or a copy in registers that the caller stores in one piece (k_finalize_pair);
 // only its cand_off (set by walk_read) is read here
-PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr)
+// `items` (optional, three entries): the pairing stage's view of the read's first three results, handed on in registers -- the
+// pairing would otherwise load the records this function has just stored, one dependent round trip per item it looks at.
+// Up to three candidates (all but a handful of reads) are loaded together, sorted and finished in registers and stored once; the
+// stages around this one are bound by the number of scattered 64-byte sectors they touch and by chains of dependent loads.
+PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr, PeItem *items = nullptr)
 {
 	rr.unmapped = c.unmapped[read], rr.early_out = !c.active[read], rr.is_str = c.is_str[read], rr.reserved = 0, rr.reserved2 = 0;
 	rr.primary = rr.secondary = -1, rr.has_mate = 0, rr.mate_chr_id = 0, rr.mate_ref_bg = 0, rr.prim_sv_id = rr.mate_sv_id = -1;
 	int n = c.active[read] ? c.n_ccand[read] : 0;
 	if (n <= 0) rr.cand_off = 0;                      // walk_read set it for the reads that have candidates
 	psvr_cand_t *cd = c.cand + rr.cand_off;
-	for (int i = 1; i < n; ++i) {                                        // cmp_align_score (rr.hpp:310-315), stable
+	auto before = [](const psvr_cand_t &x, const psvr_cand_t &y) { return x.align_score != y.align_score ? x.align_score > y.align_score : x.max_index < y.max_index; };   // cmp_align_score (rr.hpp:310-315)
+	if (n <= 3) {
+		psvr_cand_t x0 = {}, x1 = {}, x2 = {};
+		if (n > 0) x0 = cd[0];
+		if (n > 1) x1 = cd[1];
+		if (n > 2) x2 = cd[2];
+		bool moved = false;                                                // the stable insertion sort on three registers
+		if (n > 1 && before(x1, x0)) { const psvr_cand_t t = x0; x0 = x1, x1 = t; moved = true; }
+		if (n > 2 && before(x2, x1)) {
+			{ const psvr_cand_t t = x1; x1 = x2, x2 = t; }
+			moved = true;
+			if (before(x1, x0)) { const psvr_cand_t t = x0; x0 = x1, x1 = t; }
+		}
+		const int n_in = n;
+		if (n > 0 && x0.align_score < 40) n = 0;
+		const uint32_t second = n > 1 ? x1.align_score : 0;
+		SvDev s0 = {}, s1 = {}, s2 = {};
+		if (n > 0) s0 = c.idx.sv[x0.sv_id < 0 ? x0.chr_id : x0.sv_id];
+		if (n > 1) s1 = c.idx.sv[x1.sv_id < 0 ? x1.chr_id : x1.sv_id];
+		if (n > 2) s2 = c.idx.sv[x2.sv_id < 0 ? x2.chr_id : x2.sv_id];
+		auto finish = [&](psvr_cand_t &x, const SvDev &sd, bool first) {
+			if (x.sv_id < 0) {                                              // (a record that went through here before -- reselect_pair puts such
+				x.sv_id = x.chr_id;                                         // records into a new list -- has its genome coordinates already)
+				x.chr_id = (int32_t)sd.chr_id;
+				x.ref_bg += sd.st_pos;
+				if (x.ref_bg >= 0x7fffffffu) x.ref_bg = 5;
+			}
+			x.mapq = 0;
+			if (first) { const int32_t d = (int32_t)(x.align_score - second); x.mapq = (uint8_t)(d > 40 ? 40 : d); }
+		};
+		if (n > 0) finish(x0, s0, true);
+		if (n > 1) finish(x1, s1, false);
+		if (n > 2) finish(x2, s2, false);
+		const int n_st = n > 0 ? n : (moved ? n_in : 0);                    // (a list that is dropped keeps its sorted order in memory, as before)
+		if (n_st > 0) cd[0] = x0;
+		if (n_st > 1) cd[1] = x1;
+		if (n_st > 2) cd[2] = x2;
+		if (items) items[0] = pe_item_of(x0, s0.end_offset), items[1] = pe_item_of(x1, s1.end_offset), items[2] = pe_item_of(x2, s2.end_offset);
+		rr.n_result = n;
+		return;
+	}
+	for (int i = 1; i < n; ++i) {                                        // stable
 		psvr_cand_t x = cd[i];
 		int j = i;
-		while (j > 0 && (x.align_score != cd[j - 1].align_score ? x.align_score > cd[j - 1].align_score : x.max_index < cd[j - 1].max_index)) { cd[j] = cd[j - 1]; --j; }
+		while (j > 0 && before(x, cd[j - 1])) { cd[j] = cd[j - 1]; --j; }
 		cd[j] = x;
 	}
 	if (n > 0 && cd[0].align_score < 40) n = 0;
 	for (int i = 0; i < n; ++i) {                                        // a record is loaded, changed and stored as a whole
 		psvr_cand_t x = cd[i];
-		if (x.sv_id < 0) {                                                // (a record that went through here before -- reselect_pair puts such
-			const int sv = x.chr_id;                                      // records into a new list -- has its genome coordinates already)
-			const SvDev &s = c.idx.sv[sv];
+		if (x.sv_id < 0) {
+			const int sv = x.chr_id;
+			const SvDev &sd = c.idx.sv[sv];
 			x.sv_id = sv;
-			x.chr_id = (int32_t)s.chr_id;
-			x.ref_bg += s.st_pos;
+			x.chr_id = (int32_t)sd.chr_id;
+			x.ref_bg += sd.st_pos;
 			if (x.ref_bg >= 0x7fffffffu) x.ref_bg = 5;
 		}
 		x.mapq = 0;
@@ -1553,28 +1650,28 @@ PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr)
 		cd[i] = x;
 	}
 	rr.n_result = n;
+	if (items) for (int k = 0; k < 3; ++k) if (k < n) { const psvr_cand_t &d = c.cand[rr.cand_off + k]; items[k] = pe_item_of(d, c.idx.sv[d.sv_id].end_offset); }
 }
 PSVR_HDN inline void finalize_read(const Ctx &c, long long read) { finalize_read(c, read, c.rh[read]); }
 
 // PE_score::read_get_best_pairing_results + set_primary_secondary_mate (rr.hpp:476-534)
-struct PeItem { uint32_t align_score, chr_id, ref_bg; int32_t direction, is_ori, sv_id, end_offset; };
-
 PSVR_HD PeItem pe_item(const Ctx &c, long long read, int i, const psvr_read_hdr_t &rr)
 {
-	PeItem p;
 	if (i < rr.n_result) {
 		const psvr_cand_t &d = c.cand[rr.cand_off + i];
-		p.align_score = d.align_score, p.chr_id = (uint32_t)d.chr_id, p.ref_bg = d.ref_bg, p.direction = d.direction, p.is_ori = 0, p.sv_id = d.sv_id;
-		p.end_offset = c.idx.sv[d.sv_id].end_offset;
-	} else {
-		const psvr_ori_t &o = c.ori[src_read(c, read)];
-		p.align_score = o.align_score, p.chr_id = (uint32_t)o.chr_id, p.ref_bg = o.ref_bg >= 0x7fffffffu ? 1u : o.ref_bg, p.direction = o.direction, p.is_ori = 1, p.sv_id = -1, p.end_offset = 0;
+		return pe_item_of(d, c.idx.sv[d.sv_id].end_offset);
 	}
+	PeItem p;
+	const psvr_ori_t &o = c.ori[src_read(c, read)];
+	p.align_score = o.align_score, p.chr_id = (uint32_t)o.chr_id, p.ref_bg = o.ref_bg >= 0x7fffffffu ? 1u : o.ref_bg, p.direction = o.direction, p.is_ori = 1, p.sv_id = -1, p.end_offset = 0;
 	return p;
 }
 
 // h0 / h1: the two reads' headers (c.rh[2 pair], c.rh[2 pair + 1] or copies in registers, see finalize_read)
-PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_read_hdr_t &h1)
+// pre0 / pre1 (optional, three entries each): the reads' first three result items as finalize_read left them in registers.  Without them
+// they are loaded here, together and before the loops -- every combination the loops look at was a pair of dependent loads (candidate
+// record, then its SV's end offset) in the middle of the pairing.
+PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_read_hdr_t &h1, const PeItem *pre0 = nullptr, const PeItem *pre1 = nullptr)
 {
 	const long long r0 = pair * 2, r1 = r0 + 1;
 	const long long item = pair * 3 + 2;
@@ -1594,15 +1691,26 @@ PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_
 	const int nr0 = n0, nr1 = n1;
 	if (!c.unmapped[r0]) n0++;
 	if (!c.unmapped[r1]) n1++;
+	PeItem q0[3], q1[3], o0, o1;
+	for (int k = 0; k < 3; ++k) q0[k] = PeItem(), q1[k] = PeItem();
+	o0 = PeItem(), o1 = PeItem();
+	if (pre0) { q0[0] = pre0[0], q0[1] = pre0[1], q0[2] = pre0[2]; }
+	else { if (nr0 > 0) q0[0] = pe_item(c, r0, 0, h0); if (nr0 > 1) q0[1] = pe_item(c, r0, 1, h0); if (nr0 > 2) q0[2] = pe_item(c, r0, 2, h0); }
+	if (pre1) { q1[0] = pre1[0], q1[1] = pre1[1], q1[2] = pre1[2]; }
+	else { if (nr1 > 0) q1[0] = pe_item(c, r1, 0, h1); if (nr1 > 1) q1[1] = pe_item(c, r1, 1, h1); if (nr1 > 2) q1[2] = pe_item(c, r1, 2, h1); }
+	if (n0 > nr0) o0 = pe_item(c, r0, nr0, h0);                          // the original alignments
+	if (n1 > nr1) o1 = pe_item(c, r1, nr1, h1);
+	auto item0 = [&](int i) { return i >= nr0 ? o0 : i == 0 ? q0[0] : i == 1 ? q0[1] : i == 2 ? q0[2] : pe_item(c, r0, i, h0); };
+	auto item1 = [&](int j) { return j >= nr1 ? o1 : j == 0 ? q1[0] : j == 1 ? q1[1] : j == 2 ? q1[2] : pe_item(c, r1, j, h1); };
 	auto get_isize = [&](int p1, int p2, int d1, int d2) {
 		if (d1 == d2) return 0;
 		int is = nrl + ((d1 == kFwd) ? (p2 - p1) : (p1 - p2));
 		return (is < max_isize && is > min_isize) ? is : 0;
 	};
 	auto store = [&](int i, int j) {   // i / j = -1 for NULL
-		PeItem a, b;
-		if (i >= 0) a = pe_item(c, r0, i, h0);
-		if (j >= 0) b = pe_item(c, r1, j, h1);
+		PeItem a = PeItem(), b = PeItem();
+		if (i >= 0) a = item0(i);
+		if (j >= 0) b = item1(j);
 		int ISIZE = 0;
 		if (i >= 0 && j >= 0 && a.chr_id == b.chr_id) {
 			int s1p1 = (int)a.ref_bg, s1p2 = s1p1 + (a.is_ori ? 0 : a.end_offset);
@@ -1642,7 +1750,6 @@ PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_
 	c.pres[pair] = pr;
 	if (!gain) return;
 	for (int e = 0; e < 2; ++e) {                                        // set_primary_secondary_mate
-		const long long rd = e == 0 ? r0 : r1;
 		const int mine = e == 0 ? m1 : m2, other = e == 0 ? m2 : m1;
 		const int nmine = e == 0 ? nr0 : nr1, nother = e == 0 ? nr1 : nr0;
 		if (mine < 0) continue;
@@ -1652,10 +1759,10 @@ PSVR_HD void pair_reads(const Ctx &c, long long pair, psvr_read_hdr_t &h0, psvr_
 		rr.secondary = -1;
 		if (is_ori && nmine > 0) rr.secondary = 0;
 		else if (nmine > 1) rr.secondary = mine == 0 ? 1 : 0;          // rst_idx == position after the final sort
-		PeItem me = pe_item(c, rd, mine, rr);
+		const PeItem me = e == 0 ? item0(mine) : item1(mine);
 		rr.prim_sv_id = me.sv_id;
 		if (other >= 0) {
-			PeItem mt = pe_item(c, e == 0 ? r1 : r0, other, e == 0 ? h1 : h0);
+			const PeItem mt = e == 0 ? item1(other) : item0(other);
 			(void)nother;
 			if (mt.chr_id != 0xffffffffu) {
 				// The reference handles read 0 first and stores the SV of an ORIGINAL primary in the shared `ori` object

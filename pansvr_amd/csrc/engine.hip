@@ -649,8 +649,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *
 	// stores per read, each lane to its own line, and the pairing read them back)
 	psvr_read_hdr_t h[2];
 	h[0].cand_off = c.rh[2 * p].cand_off, h[1].cand_off = c.rh[2 * p + 1].cand_off;
-	finalize_read(c, 2 * p, h[0]), finalize_read(c, 2 * p + 1, h[1]);
-	pair_reads(c, p, h[0], h[1]);
+	PeItem it0[3], it1[3];                                                 // the pairing's view of the records, handed on in registers
+	finalize_read(c, 2 * p, h[0], it0), finalize_read(c, 2 * p + 1, h[1], it1);
+	pair_reads(c, p, h[0], h[1], it0, it1);
 	static_assert(sizeof(psvr_read_hdr_t) == 48, "header size");
 	const uint4 *src = (const uint4 *)h;
 	uint4 *dst = (uint4 *)(c.rh + 2 * p);
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void k_dp_lens(DpPlanDev d, int w, int tiny
 		int kind = dp_classify(x.qlen, x.tlen, w, true, 0, false, &need, tiny_ok != 0, team_ok != 0);
 		int cls = 0;
 		while (cls < PSVR_DP_NUM_LDS_CLASSES - 1 && dp_lds_class_bytes(cls) < need) ++cls;
-		d.plen[i] = (kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
+		d.plen[i] = dp_kind_uses_slab(kind) ? (int32_t)((dp_p_bytes(x.qlen, x.tlen, w) + 255) >> 8) : 0;
 		const int b = dp_bucket_of(kind, cls, x.qlen);
 		d.bucket[i] = b;
 		if (kind == PSVR_DP_KIND_STRIP) atomicMax(&lq[cls], (unsigned int)x.qlen);
@@ -1609,7 +1610,7 @@ struct GpuBE {
 		long long bstart[512], acc = 0;
 		memset(bstart, 0, sizeof bstart);
 		std::vector<Launch3> ls;
-		const int kind_order[PSVR_DP_NUM_KINDS - 1] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
+		const int kind_order[PSVR_DP_NUM_KINDS - 1] = {0, 14, 13, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 11};
 		for (int ko = 0; ko < PSVR_DP_NUM_KINDS - 1; ++ko)
 			for (int cls = PSVR_DP_NUM_LDS_CLASSES - 1; cls >= 0; --cls) {
 				int b = kind_order[ko] * PSVR_DP_NUM_LDS_CLASSES + cls;
@@ -1729,10 +1730,16 @@ __global__ void k_build_bloom(const uint64_t *hash, const uint32_t *kmer, long l
 	}
 }
 
+// DevIndex::hitrec: a thread per index entry
+__global__ void k_build_hitrec(DevIndex ix, uint64_t n, HitRec *out)
+{
+	const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+	if (i < n) out[i] = hit_record(ix, i);
+}
 struct psvr_index {
 	int device = 0;
 	HostIndex host;          // small tables + strings stay on the host too (SAM formatting)
-	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, uid_hint, bloom;
+	DevBuf ref_seq, seq, seqf, pos, posp, hash, off, kmer, chr_end, chr_idx, sv, occ, uid_hint, bloom, hitrec;
 	DevIndex dev;
 	int64_t bytes = 0;
 };
@@ -1839,6 +1846,15 @@ static int index_upload(psvr_index *ix, const psvr_index_view_t *v, const uint32
 		}
 		PSVR_HIP(up(ix->uid_hint, hint.data(), hint.size() * 4, 0));
 		d.uid_hint = ix->uid_hint.as<uint32_t>(), d.uid_shift = sh;
+	}
+	// the per-entry records of UNITIG_MEM_search's index-only part (32 B per 22-mer occurrence; PSVR_NO_HITREC=1: derived per hit as before)
+	if (v->n_off && !getenv("PSVR_NO_HITREC")) {
+		PSVR_HIP(ix->hitrec.alloc((size_t)v->n_off * sizeof(HitRec)));
+		ix->bytes += (int64_t)(v->n_off * sizeof(HitRec));
+		hipLaunchKernelGGL(k_build_hitrec, dim3((unsigned)((v->n_off + 255) / 256)), dim3(256), 0, nullptr, d, (uint64_t)v->n_off, ix->hitrec.as<HitRec>());
+		PSVR_HIP(hipGetLastError());
+		PSVR_HIP(hipDeviceSynchronize());
+		d.hitrec = ix->hitrec.as<HitRec>();
 	}
 	return PSVR_OK;
 }
@@ -1961,7 +1977,7 @@ extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_
 		ix->bytes += (int64_t)s0.bytes;
 	};
 	cp(ix->ref_seq, src->ref_seq), cp(ix->seq, src->seq), cp(ix->seqf, src->seqf), cp(ix->pos, src->pos), cp(ix->posp, src->posp), cp(ix->hash, src->hash);
-	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->uid_hint, src->uid_hint), cp(ix->bloom, src->bloom);
+	cp(ix->off, src->off), cp(ix->kmer, src->kmer), cp(ix->chr_end, src->chr_end), cp(ix->chr_idx, src->chr_idx), cp(ix->sv, src->sv), cp(ix->occ, src->occ), cp(ix->uid_hint, src->uid_hint), cp(ix->bloom, src->bloom), cp(ix->hitrec, src->hitrec);
 	if (he == hipSuccess) he = hipDeviceSynchronize();
 	if (he != hipSuccess) { delete ix; return set_error(PSVR_ERR_DEVICE, "psvr_index_clone: %s", hipGetErrorString(he)); }
 	DevIndex &d = ix->dev;
@@ -1971,6 +1987,7 @@ extern "C" int psvr_index_clone(const psvr_index_t *src, int device, psvr_index_
 	d.chr_end_n = ix->chr_end.as<uint32_t>(), d.chr_search_index = ix->chr_idx.as<uint32_t>(), d.sv = ix->sv.as<SvDev>();
 	d.occ = ix->occ.as<uint32_t>(), d.uid_hint = ix->uid_hint.as<uint32_t>();
 	if (src->bloom.p) d.bloom = ix->bloom.as<uint64_t>();
+	if (src->hitrec.p) d.hitrec = ix->hitrec.as<HitRec>();
 	*out = ix;
 	return PSVR_OK;
 }

@@ -642,8 +642,13 @@ template <class BE> struct EngineCore {
 				be.gather_listed(d_noff, c.poff, d_ctot, listed.data(), (long long)listed.size(), pre.data(), cur_off.data(), cur_tot.data(), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0);
 				if (want_vcnt) {
 					be.d2h_late_done();                      // (the gather's synchronisation has brought the late copy in as well; no list, no gather: waits here)
-					if (late) vcnt.view(late, (size_t)3 * V);
+					// the table is read at random by the walk below: out of the page-locked region the DMA engine has just written every
+					// row is a miss to memory (~170 ns per pair measured: 0.45 ms for 2.9 k pairs); one streaming copy (1 MB, ~35 us) puts it in
+					// the CPU's caches (PSVR_VCNT_VIEW=1: read it in place, for A/B runs)
+					static const bool in_place = getenv("PSVR_VCNT_VIEW") != nullptr;
+					if (late && in_place) vcnt.view(late, (size_t)3 * V);
 					else if (!vcnt.resize((size_t)3 * V)) { err = "host allocation failed (variant table)"; rc = PSVR_ERR_NOMEM; break; }
+					else if (late) memcpy(vcnt.data(), late, (size_t)3 * V * 4);
 					else be.d2h(vcnt.data(), c.rcnt + 3 * P, (size_t)3 * V * 4);
 				}
 				gathered = true;

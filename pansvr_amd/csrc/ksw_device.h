@@ -57,6 +57,7 @@ struct DpBatch { // device pointers of one batch
 #define PSVR_DP_TINY_MAX 16            // extd2_tiny_kernel: qlen, tlen <= 16, one thread per alignment
 static const int kDpWaves = 4;   // alignments (wavefronts) per workgroup of the register-resident kernels
 template <int K, bool PG> __global__ void extd2_reg_kernel(DpBatch B, DpParams P);   // ksw_kernels.hip
+template <int K> __global__ void extd2_ring_kernel(DpBatch B, DpParams P);             // ksw_kernels.hip: the same sweep on a ring of 64 K columns that slides with the band
 template <int VAR> __global__ void extd2_lds_kernel(DpBatch B, DpParams P); // ksw_kernels.hip
 __global__ void extd2_tiny_kernel(DpBatch B, DpParams P, int max_rows);        // ksw_kernels.hip
 // all size classes of the team kernel go out in ONE launch (a class alone rarely fills the chip): block b serves class c with
@@ -135,11 +136,15 @@ __host__ __device__ inline int dp_lds_kernel_need(int qlen, int tlen, int varian
 // Direction bytes stay in LDS only while the whole footprint is at most this (keeps >= 32 waves per CU resident);
 // larger problems stream them to an HBM slab and trace back through L2
 #define PSVR_DP_PG_THRESHOLD 4096
-#define PSVR_DP_NUM_KINDS 13
-// kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM),
+#define PSVR_DP_NUM_KINDS 15
+#define PSVR_DP_KIND_RING3 13          // extd2_ring_kernel<3>: any tlen, band (+ its 16-lane rounding) within 192 columns
+#define PSVR_DP_KIND_RING4 14          // extd2_ring_kernel<4>: ... within 256 columns
+// kinds whose direction bytes live in the HBM slab (DpBatch::pslab)
+__host__ __device__ inline bool dp_kind_uses_slab(int kind) { return kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY) || kind >= PSVR_DP_KIND_RING3; }
+// kind: 1..5 = extd2_reg_kernel<kind,false> (direction bytes in LDS), 6..10 = extd2_reg_kernel<kind-5,true> (in HBM), 13 / 14 = extd2_ring_kernel<3 / 4>,
 // 11 = extd2_tiny_kernel (one thread per alignment; *need = 512 x anti-diagonals, which bins the problems by size),
 // 0 = general kernel, -1 = unsupported; *need = dynamic LDS bytes
-__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool tiny_ok = false, bool team_ok = true)
+__host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_ok, int variant, bool skip, int *need, bool tiny_ok = false, bool team_ok = true, bool ring_ok = true)
 {
 	if (qlen <= 0 || tlen <= 0 || skip) { *need = 0; return 1; }
 	if (PSVR_DP_USE_TINY && tiny_ok && qlen <= PSVR_DP_TINY_MAX && tlen <= PSVR_DP_TINY_MAX) { *need = (qlen + tlen - 1) * 512; return PSVR_DP_KIND_TINY; }
@@ -157,6 +162,17 @@ __host__ __device__ inline int dp_classify(int qlen, int tlen, int w, bool fast_
 		if (n <= PSVR_DP_PG_THRESHOLD) { *need = (int)n; return (T + 63) / 64; }
 		*need = ((qlen + 16 + 15) & ~15) + 16;
 		return 5 + (T + 63) / 64;
+	}
+	if (fast_ok && ring_ok) {
+		// wider than the register-resident kernels' 320 columns: the ring kernels, when the columns an anti-diagonal can touch -- the band,
+		// w + 1 wide at most (and never wider than the shorter sequence), plus the 16-lane rounding at both ends, the stale-score block and
+		// the left neighbour of its first column -- fit their ring.  LDS: the query image and the target.
+		const int wf = w < 0 ? (qlen > tlen ? qlen : tlen) : w, sh = qlen < tlen ? qlen : tlen;
+		const int span = (wf < sh - 1 ? wf : sh - 1) + 33;
+		if (span <= 256) {
+			*need = ((qlen + 16 + 15) & ~15) + ((tlen + 15) & ~15) + 16;
+			return span <= 192 ? PSVR_DP_KIND_RING3 : PSVR_DP_KIND_RING4;
+		}
 	}
 	int g = dp_lds_kernel_need(qlen, tlen, variant);
 	*need = g;

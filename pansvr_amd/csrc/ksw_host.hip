@@ -121,6 +121,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	}
 	const int fast_flags = PSVR_EZ_EXTZ_ONLY | PSVR_EZ_REV_CIGAR | PSVR_EZ_SCORE_ONLY;
 	const bool fast_ok = variant == 0 && (par->flag & ~fast_flags) == 0;
+	const bool ring_ok = getenv("PSVR_DP_NO_RING") == nullptr;      // (A/B runs: wide shapes through the general kernel)
 	// bucket = kind * classes + lds class
 	std::vector<std::vector<int32_t>> bucket(PSVR_DP_NUM_KINDS * kNumLdsClasses);
 	std::vector<int64_t> poff(n, 0);
@@ -132,9 +133,9 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 			return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld: qlen=%d tlen=%d exceeds %d", (long long)i, ql, tl, kMaxLen);
 		}
 		int need = 0;
-		int kind = dp_classify(ql, tl, par->w, fast_ok, variant, pl->P.skip != 0, &need, dp_tiny_ok(pl->P, fast_ok));
+		int kind = dp_classify(ql, tl, par->w, fast_ok, variant, pl->P.skip != 0, &need, dp_tiny_ok(pl->P, fast_ok), true, ring_ok);
 		if (kind < 0) { delete pl; return set_error(PSVR_ERR_UNSUPPORTED, "problem %lld needs %d B of LDS", (long long)i, need); }
-		if ((kind == 0 || (kind > 5 && kind < PSVR_DP_KIND_TINY)) && ql > 0 && tl > 0) {
+		if (dp_kind_uses_slab(kind) && ql > 0 && tl > 0) {
 			poff[i] = pslab;
 			pslab += (dp_p_bytes(ql, tl, par->w) + 255) & ~(int64_t)255;
 		}
@@ -145,7 +146,7 @@ extern "C" int psvr_dp_plan_create(int device, int64_t n, const int32_t *qlen, c
 	std::vector<int32_t> idx;
 	idx.reserve(n);
 	// general kernel first, then the HBM-direction-byte kernels, then the LDS ones; large LDS classes first
-	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 12, 11};
+	const int kind_order[PSVR_DP_NUM_KINDS] = {0, 14, 13, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 12, 11};
 	for (int ko = 0; ko < PSVR_DP_NUM_KINDS; ++ko)
 		for (int cls = kNumLdsClasses - 1; cls >= 0; --cls) {
 			auto &b = bucket[kind_order[ko] * kNumLdsClasses + cls];

@@ -140,6 +140,147 @@ __device__ __forceinline__ void dp_main_loop(const DpParams &P, const uint8_t *t
 #undef W8
 }
 
+// The same sweep for matrices wider than 64 K columns whose BAND fits 64 K columns (`fc_sv`'s contig re-alignment: q/t up to 3100 at
+// w = 132, SignalAssembly.hpp:418-420,463; reads beyond 320 bases on the `aln` path at its fixed w = 200): the lanes hold a RING of
+// R = 64 K columns -- column t lives in slot t mod R (chunk (t mod R) / 64, lane t mod 64) -- that slides along the matrix with the band.
+// The reference's per-column arrays (u, v, x, y, x2, y2, s, H) are only ever touched inside [st, max(en, fresh_end)] of the current
+// anti-diagonal (ksw2_extd2_sse.c:125-140,158-173), that interval moves right monotonically and is at most w + 32 columns wide, so a
+// column that has fallen out of it on the left is dead and its slot is given to column t + R -- with the arrays' initial values
+// (:100-121) -- when that one comes into reach on the right.  The neighbour (r-1, t-1) is the lane to the left as before, lane 0 of
+// chunk c receiving lane 63 of chunk c-1 and chunk 0 that of chunk K-1 (read before any chunk is updated).  Everything else -- the
+// 16-lane block rounding, the stale-score lanes, the 8-bit wrap of every add/sub -- is dp_main_loop's, cell for cell.
+template <int K>
+__device__ __forceinline__ void dp_ring_loop(const DpParams &P, const uint8_t *target, int lane, int qlen, int tlen, int w, int rowb, int n_rows,
+                                             const uint8_t *QR, uint8_t *Pm, EzAcc &ez)
+{
+	constexpr int R = 64 * K;
+	const int neg_qe = s8(-P.q - P.e), neg_qe2 = s8(-P.q2 - P.e2);
+	const int qe8 = s8(P.q + P.e), qe28 = s8(P.q2 + P.e2);
+	int u[K], v[K], x[K], y[K], x2[K], y2[K], s[K], H[K], tb[K], tc[K];
+#pragma unroll
+	for (int c = 0; c < K; ++c) {
+		const int t = c * 64 + lane;
+		tc[c] = t;
+		u[c] = v[c] = x[c] = y[c] = neg_qe;
+		x2[c] = y2[c] = neg_qe2;
+		s[c] = 0;
+		H[c] = PSVR_KSW_NEG_INF;
+		tb[c] = t < tlen ? target[t] : 0;
+	}
+	__builtin_amdgcn_wave_barrier();      // the query / target images were written by this wave's own lanes (LDS is in-order per wave)
+
+	int last_st = -1;
+	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
+	for (int r = 0; r < n_rows; ++r) {
+		int st0, en0, st, en;
+		if (!band_limits(r, qlen, tlen, w, st0, en0, st, en)) { ez.zdropped = 1; break; }
+		const bool adv = st > 0 && st > last_st;   // (r-1,st-1) was computed last round (:143)
+		const int ur = r == 0 ? neg_qe : r < P.long_thres ? s8(-P.e) : r == P.long_thres ? s8(P.long_diff) : s8(-P.e2);
+		const int fresh_end = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;  // score groups of 16 from st0 (:159)
+		const int qbase = qlen - 1 - r;
+		const int en1 = st0 + (en0 - st0) / 4 * 4;
+		const int reach = en > fresh_end ? en : fresh_end;
+		// a slot whose next column has come into reach starts over with the arrays' initial values (:100-121) -- before its neighbour to the
+		// right, which may enter the band on this very diagonal (en moves 16 columns at a time), looks at it.  Its old column lies left of
+		// st - 1 (the interval [st - 1, reach] is at most w + 33 <= R columns wide), so nobody reads that one again.
+#pragma unroll
+		for (int c = 0; c < K; ++c) {
+			if (tc[c] + R <= reach) {
+				tc[c] += R;
+				u[c] = v[c] = x[c] = y[c] = neg_qe;
+				x2[c] = y2[c] = neg_qe2;
+				s[c] = 0;
+				H[c] = PSVR_KSW_NEG_INF;
+				tb[c] = tc[c] < tlen ? target[tc[c]] : 0;
+			}
+		}
+		// the neighbours' values of the previous diagonal that cross a chunk boundary, and H[en0-1] (:322), before anything is updated
+		int cx[K], cv[K], cx2[K];
+#pragma unroll
+		for (int c = 0; c < K; ++c) {
+			const int src = (c + K - 1) % K;
+			cx[c] = __builtin_amdgcn_readlane(x[src], 63);
+			cv[c] = __builtin_amdgcn_readlane(v[src], 63);
+			cx2[c] = __builtin_amdgcn_readlane(x2[src], 63);
+		}
+		int h_prev = 0;
+		if (en0 > 0) {
+			const int j = (en0 - 1) % R;
+#pragma unroll
+			for (int c = 0; c < K; ++c)
+				if ((j >> 6) == c) h_prev = __builtin_amdgcn_readlane(H[c], j & 63);
+		}
+		int bh = (int)0x80000000; unsigned bk = 0xffffffffu;
+		uint8_t *prow = Pm + (size_t)r * rowb - st;
+#pragma unroll
+		for (int c = 0; c < K; ++c) {
+			const int t = tc[c];
+			const bool act = (t >= st) & (t <= en);
+			const bool ovr = (en >= r) & (t == r);                                  // (:153-156); lane r is always inside [st,en]
+			const int yy = ovr ? neg_qe : y[c], yy2 = ovr ? neg_qe2 : y2[c], ut = ovr ? ur : u[c];
+			int xt1 = dpp_wave_shr1(x[c], cx[c]), vt1 = dpp_wave_shr1(v[c], cv[c]), x2t1 = dpp_wave_shr1(x2[c], cx2[c]);   // (r-1,t-1)
+			const bool bnd = (t == st) & !adv;                                       // (:142-152)
+			xt1 = bnd ? neg_qe : xt1, x2t1 = bnd ? neg_qe2 : x2t1, vt1 = bnd ? (st > 0 ? neg_qe : ur) : vt1;
+			const bool fresh = (t >= st0) & (t <= fresh_end);                          // fresh score (:158-173)
+			const int qb = QR[fresh ? qbase + t : 0];
+			int sc = tb[c] == qb ? P.sc_mch : P.sc_mis;
+			sc = ((tb[c] == P.m1) | (qb == P.m1)) ? P.sc_N : sc;
+			const int sv = fresh ? sc : s[c];
+			s[c] = sv;
+			int z = sv;
+			int a = s8(xt1 + vt1), b = s8(yy + ut), a2 = s8(x2t1 + vt1), b2 = s8(yy2 + ut);
+			int d = a > z ? 1 : 0;   z = max(z, a);
+			d = b > z ? 2 : d;       z = max(z, b);
+			d = a2 > z ? 3 : d;      z = max(z, a2);
+			d = b2 > z ? 4 : d;      z = max(z, b2);
+			z = min(z, P.sc_mch);
+			const int un = s8(z - vt1), vn = s8(z - ut);
+			int tmp = s8(z - P.q);
+			a = s8(a - tmp), b = s8(b - tmp);
+			tmp = s8(z - P.q2);
+			a2 = s8(a2 - tmp), b2 = s8(b2 - tmp);
+			d |= (a > 0 ? 0x08 : 0) | (b > 0 ? 0x10 : 0) | (a2 > 0 ? 0x20 : 0) | (b2 > 0 ? 0x40 : 0);
+			u[c] = act ? un : u[c], v[c] = act ? vn : v[c];
+			x[c] = act ? s8(max(a, 0) - qe8) : x[c];
+			y[c] = act ? s8(max(b, 0) - qe8) : y[c];
+			x2[c] = act ? s8(max(a2, 0) - qe28) : x2[c];
+			y2[c] = act ? s8(max(b2, 0) - qe28) : y2[c];
+			if (act & (with_cigar != 0)) prow[t] = (uint8_t)d;
+			// exact H tracking (:316-351)
+			const int hold = H[c];
+			int hn = (t == en0) ? (en0 > 0 ? h_prev + un : hold + vn) : (((t >= st0) & (t < en0)) ? hold + vn : hold);
+			hn = r == 0 ? (t == 0 ? vn - P.qe_pre : hold) : hn;
+			hn = act ? hn : hold;
+			H[c] = hn;
+			const bool valid = (t >= st0) & (t <= en0);
+			const unsigned rank = t == en0 ? 0u : (t < en1 ? 1u + (unsigned)((t - st0) & 3) * 4096u + (unsigned)(t - st0)
+			                                                : 1u + 4u * 4096u + (unsigned)(t - st0));
+			const bool better = valid & ((hn > bh) | ((hn == bh) & (rank < bk)));
+			bh = better ? hn : bh, bk = better ? rank : bk;
+		}
+		const int max_H = wave_max_i32(bh);
+		const unsigned long long top = __ballot(bh == max_H);
+		unsigned rk;
+		if (__popcll(top) == 1) rk = (unsigned)__builtin_amdgcn_readlane((int)bk, __ffsll((unsigned long long)top) - 1);
+		else rk = wave_min_u32(bh == max_H ? bk : 0xffffffffu);
+		const int max_t = rk == 0 ? en0 : st0 + (int)((rk - 1u) & 4095u);
+		int H_en0 = 0, H_st0 = 0;
+		{
+			const int je = en0 % R, js = st0 % R;
+#pragma unroll
+			for (int c = 0; c < K; ++c) {
+				if ((je >> 6) == c) H_en0 = __builtin_amdgcn_readlane(H[c], je & 63);
+				if ((js >> 6) == c) H_st0 = __builtin_amdgcn_readlane(H[c], js & 63);
+			}
+		}
+		if (en0 == tlen - 1 && H_en0 > ez.mte) ez.mte = H_en0, ez.mte_q = r - en;
+		if (r - st0 == qlen - 1 && H_st0 > ez.mqe) ez.mqe = H_st0, ez.mqe_t = st0;
+		if (ez.apply_zdrop(max_H, r, max_t, P.zdrop, P.e2)) break;
+		if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H_en0;
+		last_st = st;
+	}
+}
+
 // The sweep for problems whose band never clips the matrix and whose in-band values fit int8 (P.nowrap_ok &&
 // dp_band_never_binds): the common case on the `aln` path (qlen <= 200, tlen <= 201).  Same results as dp_main_loop, far
 // fewer instructions per anti-diagonal:
@@ -288,8 +429,10 @@ __device__ __forceinline__ void dp_lean_loop(const DpParams &P, const uint8_t *t
 
 // kDpWaves independent alignments per workgroup (one per wavefront, no inter-wave communication): single-wave workgroups
 // run into the workgroups-per-CU limit long before the wave slots are full
-template <int K, bool PG>
-__global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpParams P)
+// RING: the matrix is wider than 64 K columns but its band is not (dp_ring_loop); the target is staged in LDS behind the query image
+// (a slot that is handed on fetches its new column's base from there), the direction bytes are in the HBM slab (PG)
+template <int K, bool PG, bool RING>
+__device__ __forceinline__ void extd2_wave_body(const DpBatch &B, const DpParams &P)
 {
 	extern __shared__ __align__(16) uint8_t lds_all[];
 	// everything per-alignment is wave-uniform; threadIdx.x >> 6 is not provably so for the compiler, and without the
@@ -320,10 +463,15 @@ __global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpP
 	uint8_t *Pm = PG ? B.pslab + (uni64(B.p_off[pid]) << B.p_unit_shift) : lds + qimg;
 	const int p_end = n_rows * rowb + 16;
 	for (int i = lane; i < qimg; i += 64) QR[i] = i < qlen ? query[qlen - 1 - i] : 0;
+	if (RING) {
+		uint8_t *TG = lds + qimg;
+		for (int i = lane; i < tlen; i += 64) TG[i] = target[i];
+		dp_ring_loop<K>(P, TG, lane, qlen, tlen, w, rowb, n_rows, QR, Pm, ez);
+	}
 	// 8-bit wrap-around only has to be emulated when it can be observed: if the band never clips the matrix, in-band cells
 	// never read a lane outside the band (dp_band_never_binds) and all in-band values fit int8 for these scoring parameters
 	// (P.nowrap_ok, make_dp_params), so the sign-extension after every add/sub is dropped
-	if (P.nowrap_ok && dp_band_never_binds(qlen, tlen, w)) dp_lean_loop<K>(P, target, lane, qlen, tlen, rowb, n_rows, QR, Pm, ez);
+	else if (P.nowrap_ok && dp_band_never_binds(qlen, tlen, w)) dp_lean_loop<K>(P, target, lane, qlen, tlen, rowb, n_rows, QR, Pm, ez);
 	else dp_main_loop<K, true>(P, target, lane, qlen, tlen, w, rowb, n_rows, QR, Pm, ez);
 	const int with_cigar = !(P.flag & PSVR_EZ_SCORE_ONLY);
 	int n_cigar = 0;
@@ -352,6 +500,12 @@ __global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpP
 	}
 	if (lane == 0) write_ez(out, ez, n_cigar);
 }
+template <int K, bool PG>
+__global__ __launch_bounds__(64 * kDpWaves) void extd2_reg_kernel(DpBatch B, DpParams P) { extd2_wave_body<K, PG, false>(B, P); }
+template <int K>
+__global__ __launch_bounds__(64 * kDpWaves) void extd2_ring_kernel(DpBatch B, DpParams P) { extd2_wave_body<K, true, true>(B, P); }
+template __global__ void extd2_ring_kernel<3>(DpBatch, DpParams);
+template __global__ void extd2_ring_kernel<4>(DpBatch, DpParams);
 
 template __global__ void extd2_reg_kernel<1, false>(DpBatch, DpParams);
 template __global__ void extd2_reg_kernel<2, false>(DpBatch, DpParams);

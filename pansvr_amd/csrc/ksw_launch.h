@@ -9,7 +9,7 @@ inline const char *dp_kind_name(int kind, int variant)
 {
 	static const char *n[PSVR_DP_NUM_KINDS] = {"extd2_lds_kernel", "extd2_reg_kernel<1,lds>", "extd2_reg_kernel<2,lds>", "extd2_reg_kernel<3,lds>", "extd2_reg_kernel<4,lds>",
 	                                           "extd2_reg_kernel<5,lds>", "extd2_reg_kernel<1,hbm>", "extd2_reg_kernel<2,hbm>", "extd2_reg_kernel<3,hbm>", "extd2_reg_kernel<4,hbm>",
-	                                           "extd2_reg_kernel<5,hbm>", "extd2_tiny_kernel", "extd2_team_kernel"};
+	                                           "extd2_reg_kernel<5,hbm>", "extd2_tiny_kernel", "extd2_team_kernel", "extd2_ring_kernel<3>", "extd2_ring_kernel<4>"};
 	if (kind == 0 && variant == 1) return "extz2_lds_kernel";
 	return n[kind];
 }
@@ -37,6 +37,8 @@ inline void dp_launch_kind(int kind, int variant, unsigned count, int lds, hipSt
 	case 8: hipLaunchKernelGGL((extd2_reg_kernel<3, true>), g, b, lds, stream, B, P); break;
 	case 9: hipLaunchKernelGGL((extd2_reg_kernel<4, true>), g, b, lds, stream, B, P); break;
 	case 10: hipLaunchKernelGGL((extd2_reg_kernel<5, true>), g, b, lds, stream, B, P); break;
+	case PSVR_DP_KIND_RING3: hipLaunchKernelGGL(extd2_ring_kernel<3>, g, b, lds, stream, B, P); break;
+	case PSVR_DP_KIND_RING4: hipLaunchKernelGGL(extd2_ring_kernel<4>, g, b, lds, stream, B, P); break;
 	default:
 		if (variant == 0) hipLaunchKernelGGL(extd2_lds_kernel<0>, g, b, lds, stream, B, P);
 		else hipLaunchKernelGGL(extd2_lds_kernel<1>, g, b, lds, stream, B, P);
@@ -91,7 +93,7 @@ inline hipError_t dp_allow_big_lds()
 #define PSVR_ATTR(k) do { hipError_t x = hipFuncSetAttribute((const void *)(k), hipFuncAttributeMaxDynamicSharedMemorySize, PSVR_DP_MAX_LDS); if (x != hipSuccess) e = x; } while (0)
 	PSVR_ATTR((extd2_reg_kernel<1, false>)); PSVR_ATTR((extd2_reg_kernel<2, false>)); PSVR_ATTR((extd2_reg_kernel<3, false>));
 	PSVR_ATTR((extd2_reg_kernel<4, false>)); PSVR_ATTR((extd2_reg_kernel<5, false>));
-	PSVR_ATTR(extd2_lds_kernel<0>); PSVR_ATTR(extd2_lds_kernel<1>);
+	PSVR_ATTR(extd2_lds_kernel<0>); PSVR_ATTR(extd2_lds_kernel<1>); PSVR_ATTR(extd2_ring_kernel<3>); PSVR_ATTR(extd2_ring_kernel<4>);
 #undef PSVR_ATTR
 	return e;
 }

@@ -125,7 +125,16 @@ struct CpuBE {
 	void st_assemble(const Ctx &c, long long b, long long e) { for (long long i = b; i < e; ++i) assemble_candidate(c, i); }
 	void st_finalize(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < 2 * n; ++i) finalize_read(c, pr(w, i >> 1) * 2 + (i & 1)); }
 	void st_pair(const Ctx &c, const int32_t *w, long long n) { for (long long i = 0; i < n; ++i) pair_reads(c, pr(w, i)); }
-	void st_finalize_pair(const Ctx &c, const int32_t *w, long long n) { st_finalize(c, w, n); st_pair(c, w, n); }
+	// as k_finalize_pair does it: both headers built in place, the pairing's items handed on from finalize_read
+	void st_finalize_pair(const Ctx &c, const int32_t *w, long long n)
+	{
+		for (long long i = 0; i < n; ++i) {
+			const long long p = pr(w, i);
+			PeItem it0[3], it1[3];
+			finalize_read(c, 2 * p, c.rh[2 * p], it0), finalize_read(c, 2 * p + 1, c.rh[2 * p + 1], it1);
+			pair_reads(c, p, c.rh[2 * p], c.rh[2 * p + 1], it0, it1);
+		}
+	}
 	void st_scan(const int32_t *cnt, long long n, int stride, int off, long long base, long long *out)
 	{
 		long long acc = base;

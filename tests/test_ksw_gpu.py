@@ -168,3 +168,38 @@ def test_gpu_lean_team_kernel_matches_oracle(monkeypatch):
         if a != b:
             bad.append((i, len(c["query"]), len(c["target"]), diff(want, g)))
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:3])
+
+
+def test_gpu_ring_kernels_match_oracle():
+    """Matrices wider than the register-resident kernels' 320 columns whose band fits a ring of 192 / 256 columns (extd2_ring_kernel<3 / 4>):
+    `fc_sv`'s contig re-alignment (2/-10, 24+2k | 32+1k, w = zdrop = 132, SignalAssembly.hpp:418-420,463) and the `aln` path's own parameters at
+    w = 200 on long reads; band widths either side of the two ring sizes' limits (w + 33 <= 192: 159 | 160; <= 256: 223 | 224, the latter
+    goes to the general kernel), extensions with a far longer target (the band runs along the query and off the matrix), z-drops in the middle,
+    N bases, every flag of the fast path."""
+    from ksw_cases import mutate
+    rng = np.random.RandomState(31337)
+    cases = []
+    shapes = [(321, 321), (340, 500), (500, 340), (777, 801), (1200, 1150), (1599, 1629), (2048, 2047), (3100, 3000), (330, 3100), (3100, 330), (640, 641)]
+    for k in range(150):
+        ql, tl = shapes[k % len(shapes)] if k < 44 else (int(rng.randint(200, 1800)), int(rng.randint(321, 1800)))
+        q = rand_seq(rng, ql)
+        t = mutate(rng, q, 0.03, 0.01, 0.01, maxindel=int(rng.choice([8, 40, 150])))
+        t = (t + rand_seq(rng, tl))[:tl] if len(t) < tl else t[:tl]
+        if k % 7 == 0:                                   # a diverged stretch: z-drop candidates
+            a = int(rng.randint(0, max(1, min(ql, tl) - 120)))
+            t[a:a + 100] = rand_seq(rng, len(t[a:a + 100]))
+        if k % 5 == 0:
+            q[int(rng.randint(ql))] = 4
+            t[int(rng.randint(tl))] = 4
+        flag = int(rng.choice([0, 0, 0x40, 0x80, 0xC0, 0x01]))
+        if k % 2:
+            cases.append(case(q, t, match=2, mismatch=10, q=24, e=2, q2=32, e2=1, w=132, zdrop=132, flag=flag))
+        else:
+            cases.append(case(q, t, w=int(rng.choice([200, 200, 159, 160, 223, 224, 64, 20])), zdrop=int(rng.choice([400, 400, 100, -1])), flag=flag))
+    got = run_gpu(cases, "extd2")
+    bad = []
+    for i, (c, g) in enumerate(zip(cases, got)):
+        want = run_oracle(c, "extd2", cap=16384)
+        if g != want:
+            bad.append((i, c["w"], c["flag"], len(c["query"]), len(c["target"]), diff(want, g)))
+    assert not bad, "%d/%d mismatches, first: %r" % (len(bad), len(cases), bad[:3])
