@@ -1677,8 +1677,12 @@ struct GpuBE {
 					}
 					++used;
 				} else {
-					const int k = used % kSide;
-					if (used < kSide) PSVR_HIP(hipStreamWaitEvent(side[k], ev_fork, 0));
+					// beside the team kernel's finish launch: the two largest classes each on a side stream of their own, every other launch one
+					// after the other on a third -- together they are shorter than one of the large ones.  Dealt round-robin over four side streams
+					// the short ones waited behind the long ones for a hardware queue and ran after the finish launch, 0.12 ms of the step
+					// (profiles/r04f_step_timeline.txt)
+					const int k = used < 2 ? used : 2;
+					if (used <= 2) PSVR_HIP(hipStreamWaitEvent(side[k], ev_fork, 0));
 					s2 = side[k], ++used;
 				}
 			}
@@ -1689,6 +1693,7 @@ struct GpuBE {
 			PSVR_HIP(hipGetLastError());
 		}
 		if (!team.T.n_classes && used > 2) used = side2_forked ? 3 : 2;   // (the side streams that were used)
+		if (team.T.n_classes && used > 3) used = 3;
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipEventRecord(ev_join[k], side[k]));
 		B.idx = plan_idx.as<int32_t>();
 		if (team.T.n_classes && fan) { team.launch_finish(stream, B, dpP, dp_lean); PSVR_HIP(hipGetLastError()); }

@@ -503,6 +503,32 @@ template <class BE> struct EngineCore {
 		HostTable(const HostTable &) = delete;
 		HostTable &operator=(const HostTable &) = delete;
 	} vcnt;
+	// The host walk's view of the variant table: per host-resolved special pair the rows of its variant slots, (c1, 2 D + adoptable), copied
+	// out of the 1 MB table once per batch in walk order.  The walk visits a few thousand pairs once per step with cold caches: through
+	// special[] by search, the table by row and three more per-pair arrays it paid ~170 ns of cache misses per pair (0.5 ms for 2.9 k
+	// pairs); over arrays laid out in the order it walks them the prefetchers keep up.
+	struct HwRow { int32_t c1, d_ok; };
+	std::vector<HwRow> hw_rows;
+	std::vector<int32_t> sp_row0;                     // per special pair: its first row in hw_rows (-1: none)
+	std::vector<int32_t> l_si;                        // per entry of the walk's list: its index in special[] (-1: a window-resolved pair)
+	void build_rows()
+	{
+		if (vcnt.empty()) return;
+		const size_t nl = l_si.size();
+		for (size_t k = 0; k < nl; ++k) {
+			if (k + 12 < nl && l_si[k + 12] >= 0) __builtin_prefetch(&vcnt[3 * (size_t)(special[(size_t)l_si[k + 12]].vslot - P)]);
+			const int32_t si = l_si[k];
+			if (si < 0 || sp_row0[(size_t)si] >= 0) continue;
+			const Special &sp = special[(size_t)si];
+			sp_row0[(size_t)si] = (int32_t)hw_rows.size();
+			const int32_t *vc = &vcnt[3 * (size_t)(sp.vslot - P)];
+			for (int v = 0; v < sp.nvar; ++v, vc += 3) {
+				// adoptable: the two reads of that variant slot drew at least the forced residues (see the walk)
+				HwRow r; r.c1 = vc[0], r.d_ok = 2 * (vc[0] + vc[1] + vc[2]) + ((vc[0] >= sp.n1 && vc[1] >= sp.n2) ? 1 : 0);
+				hw_rows.push_back(r);
+			}
+		}
+	}
 	std::vector<Win> wins;                            // window-resolved (tie-sensitive) pairs, ascending
 	std::vector<char> is_special;                     // a special pair whose prediction failed falls back to the window method
 	std::vector<int32_t> adopted, adopt_pair, adopt_slot;   // per special pair: the variant slot whose records it carries (-1 none); this walk's new adoptions
@@ -538,6 +564,7 @@ template <class BE> struct EngineCore {
 		h_sp_class.assign(special.size(), 0);
 		dp_done = 0, cw_done = 0, any_h = false;
 		vcnt.clear(), wins.clear(), is_special.assign(special.size(), 1);
+		hw_rows.clear(), sp_row0.assign(special.size(), -1);
 		adopted.assign(special.size(), -1), adopted_at.assign(special.size(), -1), adopt_pair.clear(), adopt_slot.clear();
 		have_run = true;
 		int rc = iterate(trace, want_stats, depth, stats_ptr, false);
@@ -588,14 +615,16 @@ template <class BE> struct EngineCore {
 				}
 			};
 			auto build_listed = [&]() {
-				listed.clear();
-				for (size_t i = 0; i < special.size(); ++i) if (is_special[i] == 1) listed.push_back(special[i].pair);   // (2: resolved on the device)
-				if (!wins.empty()) {                              // both parts are ascending: merge instead of sorting 80 k entries again
-					const size_t mid = listed.size();
-					for (const Win &w : wins) listed.push_back(w.pair);
-					std::inplace_merge(listed.begin(), listed.begin() + mid, listed.end());
+				listed.clear(), l_si.clear();
+				size_t wi = 0;                                    // both parts are ascending: merged on the way
+				for (size_t i = 0; i < special.size(); ++i) {
+					if (is_special[i] != 1) continue;            // (2: resolved on the device; 0: window-resolved, among `wins`)
+					for (; wi < wins.size() && wins[wi].pair < special[i].pair; ++wi) listed.push_back(wins[wi].pair), l_si.push_back(-1);
+					listed.push_back(special[i].pair), l_si.push_back((int32_t)i);
 				}
+				for (; wi < wins.size(); ++wi) listed.push_back(wins[wi].pair), l_si.push_back(-1);
 				pre.resize(listed.size()), cur_off.resize(listed.size()), cur_tot.resize(listed.size()), res.resize(listed.size());
+				build_rows();                                    // (once the table is there; the first round calls it again when it has arrived)
 			};
 			if (!skip_eval) {
 			stats.rounds++;
@@ -650,6 +679,7 @@ template <class BE> struct EngineCore {
 					else if (!vcnt.resize((size_t)3 * V)) { err = "host allocation failed (variant table)"; rc = PSVR_ERR_NOMEM; break; }
 					else if (late) memcpy(vcnt.data(), late, (size_t)3 * V * 4);
 					else be.d2h(vcnt.data(), c.rcnt + 3 * P, (size_t)3 * V * 4);
+					build_rows();
 				}
 				gathered = true;
 			} else if (want_vcnt) {
@@ -708,27 +738,28 @@ template <class BE> struct EngineCore {
 				}
 				const auto walk_t0 = std::chrono::steady_clock::now();
 				long long acc = 0;
-				size_t si = 0, wi = 0;
+				size_t wi = 0;
 				for (size_t i = 0; i < listed.size(); ++i) {
 					const int32_t s = listed[i];
 					const long long t = grand_pos + pre[i] + acc;
 					int32_t D = cur_tot[i];
-					while (si < special.size() && special[si].pair < s) ++si;
-					while (wi < wins.size() && wins[wi].pair < s) ++wi;
-					if (si < special.size() && special[si].pair == s && is_special[si] == 2) {
+					const int32_t sidx = l_si[i];
+					if (sidx >= 0 && is_special[(size_t)sidx] == 2) {
 						// classified while this list was on its way: its total stands whatever its offset (and is part of `pre` for the pairs behind it)
 						res[i] = D;
 						continue;
 					}
-					if (si < special.size() && special[si].pair == s && is_special[si] == 1 && !vcnt.empty()) {
+					if (sidx >= 0 && is_special[(size_t)sidx] == 1 && sp_row0[(size_t)sidx] >= 0) {
+						const size_t si = (size_t)sidx;
 						const Special &sp = special[si];
+						const HwRow *rows = &hw_rows[(size_t)sp_row0[si]];
 						grand.ensure(t + 64);
 						int code = 0, sh2 = 0;
 						for (int j = 0; j < sp.n1; ++j) code |= (grand.host[t + j] & 3) << sh2, sh2 += 2;
-						const int32_t c1 = vcnt[3 * (sp.vslot - P + code)];          // mate 0 does not depend on mate 1's residues
+						const int32_t c1 = rows[code].c1;                           // mate 0 does not depend on mate 1's residues
 						for (int j = 0; j < sp.n2; ++j) code |= (grand.host[t + c1 + j] & 3) << sh2, sh2 += 2;
-						const int32_t *vc = &vcnt[3 * (sp.vslot - P + code)];
-						D = vc[0] + vc[1] + vc[2];
+						const HwRow vr = rows[code];
+						D = vr.d_ok >> 1;
 						// The two reads of that variant slot drew nothing but the forced residues: their records ARE this pair's at any offset
 						// (adopted below instead of running the pair again where its draws have moved to).  If the slot's pairing stage drew
 						// too, the adoption runs the pairing again at the pair's offset (adopt_variant): again whenever the offset moves.
@@ -736,19 +767,22 @@ template <class BE> struct EngineCore {
 						// leaves the candidates and the counts as they are; the device declines otherwise and the pair runs in full)
 						// (the same slot at another offset is adopted again even if nothing of it depends on the offset: the adoption is also what
 						// tells mark_dirty that the pair stands where it belongs -- left alone it ran in full, 3.7 k pairs per rebase of the bench batch)
-						if (vc[0] >= sp.n1 && vc[1] >= sp.n2 && (adopted[si] != sp.vslot + code || adopted_at[si] != t)) {
+						if ((vr.d_ok & 1) && (adopted[si] != sp.vslot + code || adopted_at[si] != t)) {
 							adopted[si] = sp.vslot + code, adopted_at[si] = t;
 							adopt_pair.push_back(s), adopt_slot.push_back(sp.vslot + code);
 						}
-					} else if (wi < wins.size() && wins[wi].pair == s) {
-						Win &w = wins[wi];
-						w.eval_off = cur_off[i], w.eval_tot = cur_tot[i];
-						long long best = std::llabs(t - w.eval_off);
-						for (size_t k = 0; k < w.off.size(); ++k) {
-							long long d = std::llabs(w.off[k] - t);
-							if (d < best) best = d, D = w.tot[k];
+					} else if (sidx < 0) {
+						while (wi < wins.size() && wins[wi].pair < s) ++wi;
+						if (wi < wins.size() && wins[wi].pair == s) {
+							Win &w = wins[wi];
+							w.eval_off = cur_off[i], w.eval_tot = cur_tot[i];
+							long long best = std::llabs(t - w.eval_off);
+							for (size_t k = 0; k < w.off.size(); ++k) {
+								long long d = std::llabs(w.off[k] - t);
+								if (d < best) best = d, D = w.tot[k];
+							}
+							if (best != 0) stats.window_miss++;
 						}
-						if (best != 0) stats.window_miss++;
 					}
 					res[i] = D, acc += D;
 					cur_off[i] = t;                                  // where the pair must be evaluated next
