@@ -544,12 +544,16 @@ __global__ __launch_bounds__(kBlock) void k_chain_select(Ctx c, const int32_t *l
 // chain + select of the listed reads in registers (chain_select_small, aln_device.h); the few reads it declines -- MEMs on both strands,
 // more than two seeds, a unipath with several reference positions -- are listed for k_chain_select (one atomic per such read: a handful per
 // thousand)
+// `left` == nullptr: the thread takes the read through the generic pair of stages itself.  A handful of reads per thousand: their
+// wavefronts last ~50 us longer, beside 17 k others -- a launch of its own for them was ~50 us of a nearly empty chip per mate.
 __global__ __launch_bounds__(kBlock) void k_chain_small(Ctx c, const int32_t *list, const unsigned int *cnt, int32_t *left, unsigned int *left_cnt)
 {
 	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i >= (long long)*cnt) return;
 	const int32_t r = list[i];
-	if (!chain_select_small(c, r)) left[atomicAdd(left_cnt, 1u)] = r;
+	if (chain_select_small(c, r)) return;
+	if (left) left[atomicAdd(left_cnt, 1u)] = r;
+	else chain_read(c, r), select_read(c, r);
 }
 // the pairing stage over a list whose length only the device knows yet (right behind k_dirty / k_reselect, before the host has read the counts)
 __global__ __launch_bounds__(kBlock) void k_pair_dev(Ctx c, const int32_t *list, const unsigned long long *cnt)
@@ -1282,6 +1286,15 @@ struct GpuBE {
 		const unsigned int *cnt = (const unsigned int *)mem_list.p;
 		if (chain_small_on() && left_list.ensure((size_t)(n + 4) * 4) == hipSuccess) {
 			// the register-resident small case for (nearly) every read, then the generic pair of stages over what it left
+			// (PSVR_CHAIN_LEFT_LIST=1: the declined reads go to a list and a launch of their own, as until round 4 -- A/B runs)
+			static const bool left_launch = getenv("PSVR_CHAIN_LEFT_LIST") != nullptr;
+			if (!left_launch) {
+				t0("k_chain_small");
+				hipLaunchKernelGGL(k_chain_small, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, list, cnt, (int32_t *)nullptr, (unsigned int *)nullptr);
+				t1();
+				note(hipGetLastError());
+				return;
+			}
 			note(hipMemsetAsync(left_list.p, 0, 4, stream));
 			t0("k_chain_small");
 			hipLaunchKernelGGL(k_chain_small, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, list, cnt, left_list.as<int32_t>() + 4, (unsigned int *)left_list.p);
