@@ -1590,12 +1590,19 @@ PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr, Pe
 		if (n > 0) x0 = cd[0];
 		if (n > 1) x1 = cd[1];
 		if (n > 2) x2 = cd[2];
+		// (field by field: a copy of the whole struct -- its reserved[] bytes are an array -- keeps all three records in scratch memory)
+		auto swap = [](psvr_cand_t &a, psvr_cand_t &b) {
+#define PSVR_SW(f) { const auto t = a.f; a.f = b.f; b.f = t; }
+			PSVR_SW(align_score) PSVR_SW(chain_score) PSVR_SW(ref_bg) PSVR_SW(read_bg) PSVR_SW(chr_id) PSVR_SW(sv_id) PSVR_SW(max_index) PSVR_SW(n_cigar) PSVR_SW(cigar_off)
+			PSVR_SW(direction) PSVR_SW(mapq)                                  // (reserved[]: zero in every record)
+#undef PSVR_SW
+		};
 		bool moved = false;                                                // the stable insertion sort on three registers
-		if (n > 1 && before(x1, x0)) { const psvr_cand_t t = x0; x0 = x1, x1 = t; moved = true; }
+		if (n > 1 && before(x1, x0)) { swap(x0, x1); moved = true; }
 		if (n > 2 && before(x2, x1)) {
-			{ const psvr_cand_t t = x1; x1 = x2, x2 = t; }
+			swap(x1, x2);
 			moved = true;
-			if (before(x1, x0)) { const psvr_cand_t t = x0; x0 = x1, x1 = t; }
+			if (before(x1, x0)) swap(x0, x1);
 		}
 		const int n_in = n;
 		if (n > 0 && x0.align_score < 40) n = 0;
@@ -1650,7 +1657,12 @@ PSVR_HD void finalize_read(const Ctx &c, long long read, psvr_read_hdr_t &rr, Pe
 		cd[i] = x;
 	}
 	rr.n_result = n;
-	if (items) for (int k = 0; k < 3; ++k) if (k < n) { const psvr_cand_t &d = c.cand[rr.cand_off + k]; items[k] = pe_item_of(d, c.idx.sv[d.sv_id].end_offset); }
+	if (items) {                                                         // (static indices: the items stay in registers)
+		const psvr_cand_t &d0 = c.cand[rr.cand_off], &d1 = c.cand[rr.cand_off + 1], &d2 = c.cand[rr.cand_off + 2];
+		if (n > 0) items[0] = pe_item_of(d0, c.idx.sv[d0.sv_id].end_offset);
+		if (n > 1) items[1] = pe_item_of(d1, c.idx.sv[d1.sv_id].end_offset);
+		if (n > 2) items[2] = pe_item_of(d2, c.idx.sv[d2.sv_id].end_offset);
+	}
 }
 PSVR_HDN inline void finalize_read(const Ctx &c, long long read) { finalize_read(c, read, c.rh[read]); }
 

@@ -610,7 +610,10 @@ template <class T> __device__ __forceinline__ long long block_arena_alloc(const 
 	return b < 0 ? -1 : b + (long long)mine;
 }
 // (four wavefronts per SIMD: the rare scratch-buffer replay of stale_compare must not cost the common path a wavefront)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
+#ifndef PSVR_WALK_WAVES
+#define PSVR_WALK_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PSVR_WALK_WAVES, 8))) void k_walk(Ctx c, const int32_t *list, const unsigned int *cnt)
 {
 	const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // one thread per read, looping over its (few) candidates
 	const long long read = i < (long long)*cnt ? (long long)list[i] : -1;  // no early exit: the reservations are made by the whole workgroup
@@ -644,7 +647,10 @@ __global__ __launch_bounds__(kBlock) void k_pair(Ctx c, const int32_t *work, lon
 	if (i < n) pair_reads(c, pair_of(work, i));
 }
 // tail of both reads (finalize_read) and the pairing in one pass: the thread pairs the records it has just written
-__global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *work, long long n)
+#ifndef PSVR_FIN_WAVES
+#define PSVR_FIN_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PSVR_FIN_WAVES, 8))) void k_finalize_pair(Ctx c, const int32_t *work, long long n)
 {
 	long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -657,10 +663,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pair(Ctx c, const int32_t *
 	finalize_read(c, 2 * p, h[0], it0), finalize_read(c, 2 * p + 1, h[1], it1);
 	pair_reads(c, p, h[0], h[1], it0, it1);
 	static_assert(sizeof(psvr_read_hdr_t) == 48, "header size");
-	const uint4 *src = (const uint4 *)h;
+	uint4 w[6];
+	__builtin_memcpy(w, h, sizeof w);                                      // (a copy between locals: registers; a pointer cast put the headers in scratch memory)
 	uint4 *dst = (uint4 *)(c.rh + 2 * p);
 #pragma unroll
-	for (int k = 0; k < 6; ++k) dst[k] = src[k];
+	for (int k = 0; k < 6; ++k) dst[k] = w[k];
 }
 // compaction of the dirty pairs into the two work lists: kDirtyItems pairs per thread (pair = workgroup base + k * blockDim + thread, the
 // loads stay coalesced), ranks inside a wavefront from ballots, one LDS atomic per list, wavefront and k, and ONE global atomic per list
