@@ -57,6 +57,8 @@ def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
     state = {"turn": 0, "pos": [2, 0, 0], "err": None}
     cv = threading.Condition()
     res = [None] * n_batches
+    done = [0.0] * n_batches              # when a batch's records were in the caller's buffers
+    phase = [(0.0, 0.0, 0.0, 0.0)] * n_batches
     # warm-up: every slot's engine allocates its buffers, every output buffer set is allocated and touched by one transfer
     for e in engs:
         e.upload(pb, po, pr)
@@ -69,20 +71,26 @@ def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
         try:
             for k in range(s, n_batches, slots):
                 e = engs[s]
+                ta = time.time()
                 e.upload(pb, po, pr)
+                tb = time.time()
                 with cv:
                     while state["turn"] != k and state["err"] is None:
                         cv.wait()
                     if state["err"] is not None:
                         return
                     pos = list(state["pos"])
+                tc = time.time()
                 e.set_stream_pos(pos)
                 e.run()
                 end = e.stream_end()
+                td = time.time()
                 with cv:
                     state["pos"], state["turn"] = end, k + 1
                     cv.notify_all()
                 res[k] = e.download_compact(outs[k])
+                done[k] = time.time()
+                phase[k] = (tb - ta, tc - tb, td - tc, done[k] - td)     # upload, wait for the turn, run, download
         except Exception as ex:          # noqa: BLE001 -- surfaced below
             with cv:
                 state["err"] = ex
@@ -116,7 +124,7 @@ def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
     for o in outs:
         o.close()
     hb.close()
-    return dt, sums, serial, ts
+    return dt, sums, serial, ts, done, phase
 
 
 def main():
@@ -441,12 +449,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_pipeline:
         # ... and the overlapped rate: three job slots, upload(N+1) | run(N) | download_compact(N-1) through the same entry points
         try:
-            nb = 8
-            pdt, psums, ssums, sdt = pipelined_abi(aln, index, aln.default_params((150, 200, 400, 600)), (pb, po, pr), n_batches=nb, slots=3)
-            pcie["pipelined"] = {"reads_per_s": round(2 * args.pairs * nb / pdt, 1), "ms_per_batch": round(pdt / nb * 1e3, 2), "batches": nb, "slots": 3,
+            nb = int(os.environ.get("PSVR_BENCH_PIPE_BATCHES", "12"))
+            slots = int(os.environ.get("PSVR_BENCH_PIPE_SLOTS", "3"))
+            pdt, psums, ssums, sdt, done, phase = pipelined_abi(aln, index, aln.default_params((150, 200, 400, 600)), (pb, po, pr), n_batches=nb, slots=slots)
+            done = sorted(done)
+            steady = (done[-1] - done[1]) / (nb - 2) if nb > 3 else pdt / nb       # between the hand-overs of the second and the last batch: no fill of the pipeline
+            pcie["pipelined"] = {"reads_per_s": round(2 * args.pairs * nb / pdt, 1), "ms_per_batch": round(pdt / nb * 1e3, 2), "batches": nb, "slots": slots,
+                                 "sustained_reads_per_s": round(2 * args.pairs / steady, 1), "sustained_ms_per_batch": round(steady * 1e3, 2),
                                  "equal_to_serial": psums == ssums, "serial_ms_per_batch_incl_checksum": round(sdt / nb * 1e3, 2),
-                                 "note": "8 batches of the bench batch back to back (the draw streams continue from batch to batch), 3 engines on their own HIP queues driven by 3 host threads: "
-                                         "upload(N+1) | run(N) | download_compact(N-1); page-locked buffers allocated and touched before the clock starts; the records of every batch == the serial path's (crc32)"}
+                                 "phase_ms_mean": dict(zip(("upload", "wait_turn", "run", "download"), [round(1e3 * sum(p[i] for p in phase[2:]) / max(len(phase) - 2, 1), 2) for i in range(4)])),
+                                 "note": "%d batches of the bench batch back to back (the draw streams continue from batch to batch), %d engines on their own HIP queues driven by %d host threads: "
+                                         "upload(N+1) | run(N) | download_compact(N-1); page-locked buffers allocated and touched before the clock starts; the records of every batch == the serial path's "
+                                         "(crc32).  reads_per_s: all batches over the whole wall, the first upload and the last download included; sustained_*: the interval between hand-overs once "
+                                         "the pipeline is full" % (nb, slots, slots)}
         except Exception as ex:          # noqa: BLE001
             pcie["pipelined"] = {"error": repr(ex)[:300]}
     pin_in.close()

@@ -484,6 +484,41 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		seed_strand_t<true>(c, rs, mine);
 	} else seed_strand_t<false>(c, rs, nullptr);
 }
+// The device's pass over an uploaded batch (EngineCore::upload): a lane per pair counts the 'N' bases of its two reads -- aligned dwords,
+// the bytes outside the read masked off, zero bytes of x ^ 'NNNN' counted exactly -- applies the early-out rule (a read the reference
+// returns on before it draws, rr.cpp:413-414, or one shorter than a k-mer, draws nothing), appends (pair, n0 | n1 << 8) for the pairs that
+// will draw, and folds the longest read into one maximum per wavefront.
+__global__ __launch_bounds__(kBlock) void k_scan_batch(const char *bases, const long long *off, const psvr_ori_t *ori, long long P, int match, int32_t *list, unsigned int *cnt_lmax)
+{
+	const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	int lmax = 0, nn[2] = {0, 0};
+	if (p < P) {
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const long long r = 2 * p + k, o = off[r], L = off[r + 1] - o;
+			lmax = max(lmax, (int)(L < 0x7fffffff ? L : 0x7fffffff));
+			const psvr_ori_t q = ori[r];
+			const bool unm = q.unmapped || (uint32_t)q.chr_id > 24u;
+			if ((!unm && q.align_score == (uint32_t)(L * match)) || L < kLenKmer || L > kMaxReadLen) continue;
+			const uintptr_t a0 = (uintptr_t)(bases + o), a1 = a0 + (uintptr_t)L;
+			int n = 0;
+			for (uintptr_t a = a0 & ~(uintptr_t)3; a < a1; a += 4) {
+				uint32_t x = *(const uint32_t *)a ^ 0x4E4E4E4Eu;                    // 'N' bytes become zero
+				if (a < a0) x |= 0xffffffffu >> (8 * (4 - (unsigned)(a0 - a)));       // bytes in front of the read
+				if (a + 4 > a1) x |= 0xffffffffu << (8 * (unsigned)(a1 - a));        // bytes behind it
+				const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in every zero byte
+				n += __popc(z);
+			}
+			nn[k] = n < 255 ? n : 255;
+		}
+		if (nn[0] + nn[1] >= 1) {
+			const unsigned at = atomicAdd(cnt_lmax, 1u);
+			list[2 * (size_t)at] = (int32_t)p, list[2 * (size_t)at + 1] = nn[0] | (nn[1] << 8);
+		}
+	}
+	lmax = wave_max_i32(lmax);
+	if ((threadIdx.x & 63) == 0 && lmax > 0) atomicMax(cnt_lmax + 1, (unsigned int)lmax);
+}
 // K3 chain: merge, expand, sort, sparse chaining DP
 // Compaction of the items a predicate keeps into list[0 .. *cnt): kListItems items per thread (item = block base + k * blockDim + thread,
 // so a wavefront's loads stay coalesced), ranks inside a wavefront from ballots, one LDS atomic per wavefront and ONE global atomic per
@@ -1195,6 +1230,24 @@ struct GpuBE {
 			return;
 		}
 		note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); note(hipStreamSynchronize(stream)); synced();
+	}
+	// a large upload that the caller waits for later (EngineCore::upload: the host's passes over the batch run beside it)
+	void h2d_start(void *d, const void *h, size_t n) { if (n) note(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream)); }
+	void h2d_wait() { note(hipStreamSynchronize(stream)); synced(); }
+	// EngineCore::upload's pass over the batch (k_scan_batch); also the wait for the batch's copies, which are ahead of it on the stream
+	DevBuf scan_out;
+	bool scan_batch(const char *bases, const long long *off, const psvr_ori_t *ori, long long P, int match, int32_t *list, int *lmax, std::vector<int32_t> &out)
+	{
+		if (scan_out.ensure(64) != hipSuccess) return false;
+		note(hipMemsetAsync(scan_out.p, 0, 8, stream));
+		hipLaunchKernelGGL(k_scan_batch, dim3(grid_for(P)), dim3(kBlock), 0, stream, bases, off, ori, P, match, list, (unsigned int *)scan_out.p);
+		note(hipGetLastError());
+		unsigned int h[2] = {0, 0};
+		d2h(h, scan_out.p, 8);
+		*lmax = (int)h[1];
+		out.resize((size_t)2 * h[0]);
+		if (h[0]) d2h(out.data(), list, (size_t)h[0] * 8);
+		return last == hipSuccess;
 	}
 	void d2h(void *h, const void *d, size_t n)
 	{

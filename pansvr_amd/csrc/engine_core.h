@@ -105,7 +105,7 @@ template <class BE> struct EngineCore {
 	uint8_t *d_sens = nullptr;                       // per pair: known count-sensitive
 	int32_t *d_slist = nullptr;                      // newly detected sensitive pairs
 	char *d_bases = nullptr; long long *d_off = nullptr; psvr_ori_t *d_ori = nullptr;   // the uploaded batch
-	long long cap_S = 0, cap_bases = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
+	long long cap_S = 0, cap_P = 0; int cap_lm = 0;                        // what the per-batch buffers were sized for
 	uint8_t *d_force = nullptr, *d_mask = nullptr;   // forced draws per read; per pair: resolved on the host (special or sensitive)
 	// the special pairs on the device: the list, which of them draw the same number under every residue assignment (resolved there, not in the
 	// host walk), the variant slot each of those carries and the offset it was adopted at
@@ -150,6 +150,7 @@ template <class BE> struct EngineCore {
 	{
 		for (void *p : owned) be.dfree(p);
 		owned.clear();
+		free_inputs();
 		free_arenas();
 		for (void *p : {(void *)d_grand, (void *)d_hrand[0], (void *)d_hrand[1], (void *)dp.qlen, (void *)dp.tlen, (void *)dp.q_off,
 		                (void *)dp.t_off, (void *)dp.qbuf, (void *)dp.tbuf, (void *)dp.ez, (void *)dp.cig})
@@ -214,77 +215,72 @@ template <class BE> struct EngineCore {
 	}
 
 	// ---- batch upload: allocate everything sized by the batch
+	// the batch's three arrays on the device, in buffers of their own (kept while the next batch fits), and the list the device's pass
+	// over the batch leaves: (pair, n0 | n1 << 8) for every pair a read of which will draw for N bases
+	long long in_cap_bases = 0, in_cap_R = 0;
+	int32_t *d_nlist = nullptr;
+	void free_inputs()
+	{
+		for (void *p : {(void *)d_bases, (void *)d_off, (void *)d_ori, (void *)d_nlist}) if (p) be.dfree(p);
+		d_bases = nullptr, d_off = nullptr, d_ori = nullptr, d_nlist = nullptr, in_cap_bases = in_cap_R = 0;
+	}
 	int upload(long long n_pairs, const char *bases, const int64_t *base_off, const psvr_ori_t *ori)
 	{
 		P = n_pairs, R = 2 * n_pairs;
 		// a block of a larger batch may be handed over as a window of the batch's arrays: offsets then start at base_off[0] > 0
 		const long long b0 = R ? base_off[0] : 0;
 		total_bases = R ? base_off[R] - b0 : 0;
+		// The three arrays go to the device first, and the DEVICE looks at them (scan_batch: the longest read, the pairs whose reads will
+		// draw for N bases; early-out reads draw nothing, rr.cpp:414 returns first).  Until round 4 the host made those passes over every
+		// base before the transfer started -- 5 of an upload's 12 ms for 1 M pairs on eight threads, which a pipeline's three job slots
+		// took from the thread that drives the runs: the overlapped rate through the ABI was bound by it.
+		if (!d_bases || total_bases > in_cap_bases || R > in_cap_R) {
+			free_inputs();
+			in_cap_bases = total_bases + total_bases / 8 + 64, in_cap_R = R + R / 8 + 2;
+			d_bases = (char *)be.dalloc((size_t)in_cap_bases + 64);     // slack: the prep kernel loads whole 32-base groups
+			d_off = (long long *)be.dalloc((size_t)(in_cap_R + 1) * 8);
+			d_ori = (psvr_ori_t *)be.dalloc((size_t)in_cap_R * sizeof(psvr_ori_t));
+			d_nlist = (int32_t *)be.dalloc((size_t)(in_cap_R / 2 + 2) * 8);
+			if (!d_bases || !d_off || !d_ori || !d_nlist) { free_inputs(); err = "device allocation failed (batch)"; return PSVR_ERR_NOMEM; }
+		}
+		special.clear(), h_n_idx.clear();
+		V = 0;
 		int lmax = 0;
-		for (long long r = 0; r < R; ++r) { long long l = base_off[r + 1] - base_off[r]; if (l > lmax) lmax = (int)l; }
-		if (lmax > kMaxReadLen) { err = "read longer than MAX_READ_LEN 1600"; return PSVR_ERR_UNSUPPORTED; }
+		if (R > 0) {
+			be.h2d_start(d_bases, bases + b0, total_bases);
+			be.h2d_start(d_off, base_off, (R + 1) * 8);
+			be.h2d_start(d_ori, ori, R * sizeof(psvr_ori_t));
+			std::vector<int32_t> nl;                                     // (pair, counts) pairs as the device appended them
+			if (!be.scan_batch(d_bases - b0, d_off, d_ori, P, c.par.match, d_nlist, &lmax, nl)) { err = "device pass over the batch failed"; return PSVR_ERR_DEVICE; }
+			// (scan_batch has synchronised: the caller's arrays are free again)
+			if (lmax > kMaxReadLen) { err = "read longer than MAX_READ_LEN 1600"; return PSVR_ERR_UNSUPPORTED; }
+			std::vector<std::pair<int32_t, int32_t>> srt(nl.size() / 2);
+			for (size_t i = 0; i < srt.size(); ++i) srt[i] = {nl[2 * i], nl[2 * i + 1]};
+			std::sort(srt.begin(), srt.end());
+			for (const auto &e : srt) {
+				const int n0 = e.second & 0xff, n1 = (e.second >> 8) & 0xff;   // (counts saturate at 255: anything beyond 3 is "many")
+				h_n_idx.push_back(e.first);
+				if (n0 + n1 <= 3) { special.push_back(Special{e.first, (uint8_t)n0, (uint8_t)n1, (int32_t)(P + V), 1 << (2 * (n0 + n1))}); V += 1ll << (2 * (n0 + n1)); }
+			}
+		}
 		c.n_pairs = P;
 		int lm = (lmax + 31) & ~31;
 		if (lm < 32) lm = 32;
-		// pairs whose reads will draw for 1..3 N bases (early-out reads draw nothing: rr.cpp:414 returns first).  The scan reads every base
-		// once: on a few host threads for a large batch (it was a third of an upload's wall on one).
-		special.clear();
-		V = 0;
-		{
-			auto n_of = [&](long long p, int *nn) {
-				for (int k = 0; k < 2; ++k) {
-					const long long r = 2 * p + k;
-					const char *b = bases + base_off[r];
-					const long long L = base_off[r + 1] - base_off[r];
-					int n = 0;
-					for (const char *q = (const char *)memchr(b, 'N', L); q; q = (const char *)memchr(q + 1, 'N', b + L - (q + 1))) ++n;
-					const bool unm = ori[r].unmapped || (uint32_t)ori[r].chr_id > 24u;
-					if ((!unm && ori[r].align_score == (uint32_t)(L * c.par.match)) || L < kLenKmer) n = 0;
-					nn[k] = n;
-				}
-			};
-			const int nt = P >= 200000 ? 8 : 1;
-			std::vector<std::vector<Special>> part((size_t)nt);
-			std::vector<std::vector<int32_t>> npart((size_t)nt);
-			auto scan = [&](int t) {
-				const long long p0 = P * t / nt, p1 = P * (t + 1) / nt;
-				for (long long p = p0; p < p1; ++p) {
-					int nn[2];
-					n_of(p, nn);
-					if (nn[0] + nn[1] >= 1) npart[(size_t)t].push_back((int32_t)p);
-					if (nn[0] + nn[1] >= 1 && nn[0] + nn[1] <= 3) part[(size_t)t].push_back(Special{(int32_t)p, (uint8_t)nn[0], (uint8_t)nn[1], 0, 1 << (2 * (nn[0] + nn[1]))});
-				}
-			};
-			std::vector<std::thread> th;
-			for (int t = 1; t < nt; ++t) th.emplace_back(scan, t);
-			scan(0);
-			for (std::thread &t : th) t.join();
-			for (auto &v : part)
-				for (Special sp : v) { sp.vslot = (int32_t)(P + V); special.push_back(sp); V += sp.nvar; }
-			h_n_idx.clear();
-			for (auto &v : npart) h_n_idx.insert(h_n_idx.end(), v.begin(), v.end());
-		}
 		const long long shadow_cap = P / 16 + 8192;
 		S = P + V + shadow_cap;
 		c.n_slots = S;
-		// a pipeline feeds batch after batch of similar size: keep every per-batch buffer (and the arenas) while the new batch fits
-		const bool fits = !owned.empty() && S <= cap_S && lm <= cap_lm && total_bases <= cap_bases && P <= cap_P;
+		// keep every per-batch buffer (and the arenas) while the new batch fits
+		const bool fits = !owned.empty() && S <= cap_S && lm <= cap_lm && P <= cap_P;
+		c.bases = d_bases - b0, c.base_off = d_off, c.ori = d_ori;
 		if (fits) {
-			be.h2d(d_bases, bases + b0, total_bases);
-			be.h2d(d_off, base_off, (R + 1) * 8);
-			be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
-			c.bases = d_bases - b0;
 			upload_variants();
 			return PSVR_OK;
 		}
 		for (void *p : owned) be.dfree(p);
 		owned.clear();
-		cap_S = S, cap_lm = lm, cap_bases = total_bases, cap_P = P;
+		cap_S = S, cap_lm = lm, cap_P = P;
 		c.lmax = lm;
 		c.wmax = c.lmax / 32 + 2;
-		d_bases = alloc<char>(total_bases + 64);     // slack: the prep kernel loads whole 32-base groups
-		d_off = alloc<long long>(R + 1);
-		d_ori = alloc<psvr_ori_t>(R);
 		const long long RS = 2 * S;                                 // reads incl. shadow slots
 		c.poff = alloc<long long>(S), c.rcnt = alloc<int32_t>(3 * S), d_noff = alloc<long long>(S);
 		c.hoff = alloc<long long>(RS), c.hcnt = alloc<int32_t>(RS), d_nhoff = alloc<long long>(RS);
@@ -331,10 +327,6 @@ template <class BE> struct EngineCore {
 		free_arenas();
 		if (!alloc_arenas()) { err = "device allocation failed (arenas)"; return PSVR_ERR_NOMEM; }
 		c.err = d_flags + 6, c.stale_open = d_flags + 7, c.any_h = d_flags + 8;
-		be.h2d(d_bases, bases + b0, total_bases);
-		be.h2d(d_off, base_off, (R + 1) * 8);
-		be.h2d(d_ori, ori, R * sizeof(psvr_ori_t));
-		c.bases = d_bases - b0, c.base_off = d_off, c.ori = d_ori;
 		upload_variants();
 		return PSVR_OK;
 	}

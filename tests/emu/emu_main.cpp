@@ -34,6 +34,28 @@ struct CpuBE {
 	void d2d(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
 	void scatter_u8_dev(uint8_t *a, const int32_t *idx, long long n, uint8_t v) { scatter_u8(a, idx, n, v); }
 	void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
+	void h2d_start(void *d, const void *h, size_t n) { memcpy(d, h, n); }
+	void h2d_wait() {}
+	// the pass over an uploaded batch (k_scan_batch on the device): longest read, pairs whose reads will draw for N bases
+	bool scan_batch(const char *bases, const long long *off, const psvr_ori_t *ori, long long P, int match, int32_t *, int *lmax, std::vector<int32_t> &out)
+	{
+		out.clear();
+		*lmax = 0;
+		for (long long p = 0; p < P; ++p) {
+			int nn[2] = {0, 0};
+			for (int k = 0; k < 2; ++k) {
+				const long long r = 2 * p + k, L = off[r + 1] - off[r];
+				if (L > *lmax) *lmax = (int)L;
+				const bool unm = ori[r].unmapped || (uint32_t)ori[r].chr_id > 24u;
+				if ((!unm && ori[r].align_score == (uint32_t)(L * match)) || L < kLenKmer || L > kMaxReadLen) continue;
+				int n = 0;
+				for (long long i = 0; i < L; ++i) n += bases[off[r] + i] == 'N';
+				nn[k] = n < 255 ? n : 255;
+			}
+			if (nn[0] + nn[1] >= 1) out.push_back((int32_t)p), out.push_back(nn[0] | (nn[1] << 8));
+		}
+		return true;
+	}
 	void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
 	void d2h2(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2) { memcpy(h1, d1, n1), memcpy(h2, d2, n2); }
 	void d2h4(void *h1, const void *d1, size_t n1, void *h2, const void *d2, size_t n2, void *h3, const void *d3, size_t n3, void *h4, const void *d4, size_t n4) { d2h2(h1, d1, n1, h2, d2, n2), d2h2(h3, d3, n3, h4, d4, n4); }
