@@ -59,6 +59,7 @@ def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
     res = [None] * n_batches
     done = [0.0] * n_batches              # when a batch's records were in the caller's buffers
     phase = [(0.0, 0.0, 0.0, 0.0)] * n_batches
+    sub = [(0.0, 0.0, 0.0)] * n_batches
     # warm-up: every slot's engine allocates its buffers, every output buffer set is allocated and touched by one transfer
     for e in engs:
         e.upload(pb, po, pr)
@@ -82,9 +83,12 @@ def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
                     pos = list(state["pos"])
                 tc = time.time()
                 e.set_stream_pos(pos)
+                tc1 = time.time()
                 e.run()
+                tc2 = time.time()
                 end = e.stream_end()
                 td = time.time()
+                sub[k] = (tc1 - tc, tc2 - tc1, td - tc2)
                 with cv:
                     state["pos"], state["turn"] = end, k + 1
                     cv.notify_all()
@@ -124,7 +128,62 @@ def pipelined_abi(aln, index, params, pin_in, n_batches=8, slots=3):
     for o in outs:
         o.close()
     hb.close()
+    phase = [p + q for p, q in zip(phase, sub)]
     return dt, sums, serial, ts, done, phase
+
+
+def pipeline_probe(aln, index, params, pin_in, reps=12):
+    """What a run costs beside another job slot's transfers (PSVR_BENCH_PIPE_PROBE=1): engine A's run() timed alone, beside a thread that
+    uploads to engine B in a loop, beside one that downloads B's records in a loop, and beside both."""
+    import threading
+    pb, po, pr = pin_in
+    a, b, c2 = aln.Engine(index, params), aln.Engine(index, params), aln.Engine(index, params)
+    hb = aln.HostBuffers()
+    for e in (a, b, c2):
+        e.upload(pb, po, pr)
+        e.run()
+    b.download_compact(hb)
+    out = {}
+    for name, jobs in (("alone", ()), ("beside_uploads", ("up",)), ("beside_downloads", ("down",)), ("beside_both", ("up", "down"))):
+        stop = threading.Event()
+
+        def loop_up():
+            while not stop.is_set():
+                c2.upload(pb, po, pr)
+
+        def loop_down():
+            while not stop.is_set():
+                b.download_compact(hb)
+        th = [threading.Thread(target=loop_up if j == "up" else loop_down) for j in jobs]
+        for t in th:
+            t.start()
+        time.sleep(0.05)
+        t0 = time.time()
+        for _ in range(reps):
+            a.run()
+        out[name] = round((time.time() - t0) / reps * 1e3, 2)
+        stop.set()
+        for t in th:
+            t.join()
+    # the first run after an upload against a repeat of it (same batch, same position): wall, and the kernels that differ most
+    fr = {}
+    for tag in ("first", "repeat"):
+        if tag == "first":
+            a.upload(pb, po, pr)
+        t0 = time.time()
+        a.run()
+        fr[tag + "_ms"] = round((time.time() - t0) * 1e3, 2)
+    a.upload(pb, po, pr)
+    a.run(timing=True)
+    k1 = {k: v["ms"] for k, v in a.stats()["kernels"].items()}
+    a.run(timing=True)
+    k2 = {k: v["ms"] for k, v in a.stats()["kernels"].items()}
+    fr["kernels_first_minus_repeat_ms"] = {k: round(k1[k] - k2.get(k, 0.0), 3) for k in sorted(k1, key=lambda k: -(k1[k] - k2.get(k, 0.0)))[:6]}
+    out["first_run_after_upload"] = fr
+    for e in (a, b, c2):
+        e.close()
+    hb.close()
+    return out
 
 
 def main():
@@ -457,11 +516,13 @@ def main():
             pcie["pipelined"] = {"reads_per_s": round(2 * args.pairs * nb / pdt, 1), "ms_per_batch": round(pdt / nb * 1e3, 2), "batches": nb, "slots": slots,
                                  "sustained_reads_per_s": round(2 * args.pairs / steady, 1), "sustained_ms_per_batch": round(steady * 1e3, 2),
                                  "equal_to_serial": psums == ssums, "serial_ms_per_batch_incl_checksum": round(sdt / nb * 1e3, 2),
-                                 "phase_ms_mean": dict(zip(("upload", "wait_turn", "run", "download"), [round(1e3 * sum(p[i] for p in phase[2:]) / max(len(phase) - 2, 1), 2) for i in range(4)])),
+                                 "phase_ms_mean": dict(zip(("upload", "wait_turn", "run", "download", "run:set_stream_pos", "run:run", "run:stream_end"), [round(1e3 * sum(p[i] for p in phase[2:]) / max(len(phase) - 2, 1), 2) for i in range(7)])),
                                  "note": "%d batches of the bench batch back to back (the draw streams continue from batch to batch), %d engines on their own HIP queues driven by %d host threads: "
                                          "upload(N+1) | run(N) | download_compact(N-1); page-locked buffers allocated and touched before the clock starts; the records of every batch == the serial path's "
                                          "(crc32).  reads_per_s: all batches over the whole wall, the first upload and the last download included; sustained_*: the interval between hand-overs once "
                                          "the pipeline is full" % (nb, slots, slots)}
+            if os.environ.get("PSVR_BENCH_PIPE_PROBE"):
+                pcie["pipelined"]["run_ms_probe"] = pipeline_probe(aln, index, aln.default_params((150, 200, 400, 600)), (pb, po, pr))
         except Exception as ex:          # noqa: BLE001
             pcie["pipelined"] = {"error": repr(ex)[:300]}
     pin_in.close()

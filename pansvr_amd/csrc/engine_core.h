@@ -25,7 +25,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <chrono>
@@ -68,6 +70,45 @@ struct RandStream {           // lazily extended table of one generator + device
 	void ensure(long long n) { while ((long long)host.size() < n) host.push_back(gen.next()); }
 };
 
+// The process-wide rand() stream (the reference never seeds it: seed 1), generated once for every engine of the process in blocks that never
+// move.  Each engine used to keep a table of its own and extend it when its position left the device window: a pipeline's job slots -- or
+// the devices of one command -- each generated the same millions of draws again, 17 ms at a time in the middle of a run (the overlapped
+// rate through the ABI lost a third to it, the CLI's engine stage ~2 ms per batch).
+struct SharedRand {
+	static constexpr int kLog = 22;                      // 4 M draws per block
+	static constexpr long long kMask = (1ll << kLog) - 1;
+	std::mutex mu;
+	HostRand3 gen;
+	int32_t *blk[1 << 12] = {};                          // 16 G draws
+	std::atomic<long long> n{0};
+	SharedRand() { gen.seed(1); }
+	~SharedRand() { for (int32_t *b : blk) delete[] b; }
+	void ensure(long long want)
+	{
+		if (want <= n.load(std::memory_order_acquire)) return;
+		std::lock_guard<std::mutex> lk(mu);
+		long long k = n.load(std::memory_order_relaxed);
+		want = (want + 0xfffff) & ~0xfffffll;            // a million at a time
+		for (; k < want; ++k) {
+			int32_t *&b = blk[k >> kLog];
+			if (!b) b = new int32_t[(size_t)1 << kLog];
+			b[k & kMask] = gen.next();
+		}
+		n.store(k, std::memory_order_release);
+	}
+	int32_t at(long long k) const { return blk[k >> kLog][k & kMask]; }          // k below what the caller has ensure()d
+	// the draws [from, from + cnt) handed to `put(dst offset, source, entries)` block by block
+	template <class F> void pieces(long long from, long long cnt, F &&put) const
+	{
+		for (long long o = 0; o < cnt;) {
+			const long long k = from + o, room = (kMask + 1) - (k & kMask), m = cnt - o < room ? cnt - o : room;
+			put(o, blk[k >> kLog] + (k & kMask), m);
+			o += m;
+		}
+	}
+};
+inline SharedRand &shared_grand() { static SharedRand s; return s; }
+
 struct DpIO {                 // what the DP stage needs beyond Ctx
 	long long begin, end;     // descriptor range of this round
 	int32_t *qlen, *tlen;
@@ -89,7 +130,8 @@ template <class BE> struct EngineCore {
 	Ctx c;
 	long long P = 0, R = 0;                 // pairs / reads of the uploaded batch
 	long long total_bases = 0;
-	RandStream grand, hrand[2];
+	SharedRand &grand = shared_grand();             // rand(): one stream per process, as in the reference
+	RandStream hrand[2];                            // random_r: one per handler
 	long long grand_pos = 0, hrand_pos[2] = {0, 0};     // draws consumed by earlier batches
 	long long grand_dev_n = 0, hrand_dev_n = 0;
 	// the device tables hold a WINDOW of the host streams: entries [base, base + n).  A run, a rebase or a new batch whose needs lie inside the
@@ -169,16 +211,17 @@ template <class BE> struct EngineCore {
 		for (int l = 0; l < 4; ++l) { for (int m = 0; m < 4; ++m) c.mat[k++] = (int8_t)(l == m ? par.match : -par.mismatch); c.mat[k++] = 0; }
 		for (int m = 0; m < 5; ++m) c.mat[k++] = 0;
 		// rr.cpp:62-67 at -t 1: the two handlers seed their random_r state with rand() draws #0 and #1
-		grand.gen.seed(1);
 		grand.ensure(2);
-		hrand[0].gen.seed((unsigned)grand.host[0]);
-		hrand[1].gen.seed((unsigned)grand.host[1]);
+		hrand[0].gen.seed((unsigned)grand.at(0));
+		hrand[1].gen.seed((unsigned)grand.at(1));
 		grand_pos = 2;
 	}
 
 	bool upload_rand(long long need_g, long long need_h)
 	{
-		const long long margin = 1 << 20;                                   // entries beyond what this run needs: room for the position to move
+		// entries beyond what this run needs: room for the position to move before the window is uploaded again (a batch of 1 M pairs needs a
+		// window of 4.7 M and draws ~0.4 M times: forty batches; small inputs stay small)
+		const long long margin_h = 1 << 20, margin = std::max<long long>(margin_h, 4 * need_g);
 		if (!(d_grand && grand_pos >= grand_dev_base && grand_pos + need_g <= grand_dev_base + grand_dev_n)) {
 			const long long n = need_g + need_g / 2 + 4096 + margin;
 			grand.ensure(grand_pos + n);
@@ -188,13 +231,13 @@ template <class BE> struct EngineCore {
 				if (!d_grand) return false;
 				grand_dev_cap = n;
 			}
-			be.h2d(d_grand, grand.host.data() + grand_pos, n * 4);
+			grand.pieces(grand_pos, n, [&](long long o, const int32_t *src, long long m) { be.h2d(d_grand + o, src, (size_t)m * 4); });
 			grand_dev_base = grand_pos, grand_dev_n = n;
 		}
 		bool hok = d_hrand[0] && d_hrand[1];
 		for (int k = 0; k < 2 && hok; ++k) hok = hrand_pos[k] >= hrand_dev_base[k] && hrand_pos[k] + need_h <= hrand_dev_base[k] + hrand_dev_n;
 		if (!hok) {
-			const long long n = need_h + need_h / 2 + 4096 + margin;
+			const long long n = need_h + need_h / 2 + 4096 + margin_h;
 			for (int k = 0; k < 2; ++k) {
 				hrand[k].ensure(hrand_pos[k] + n);
 				if (n > hrand_dev_cap || !d_hrand[k]) {
@@ -747,9 +790,9 @@ template <class BE> struct EngineCore {
 						const HwRow *rows = &hw_rows[(size_t)sp_row0[si]];
 						grand.ensure(t + 64);
 						int code = 0, sh2 = 0;
-						for (int j = 0; j < sp.n1; ++j) code |= (grand.host[t + j] & 3) << sh2, sh2 += 2;
+						for (int j = 0; j < sp.n1; ++j) code |= (grand.at(t + j) & 3) << sh2, sh2 += 2;
 						const int32_t c1 = rows[code].c1;                           // mate 0 does not depend on mate 1's residues
-						for (int j = 0; j < sp.n2; ++j) code |= (grand.host[t + c1 + j] & 3) << sh2, sh2 += 2;
+						for (int j = 0; j < sp.n2; ++j) code |= (grand.at(t + c1 + j) & 3) << sh2, sh2 += 2;
 						const HwRow vr = rows[code];
 						D = vr.d_ok >> 1;
 						// The two reads of that variant slot drew nothing but the forced residues: their records ARE this pair's at any offset
