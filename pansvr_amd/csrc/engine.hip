@@ -782,18 +782,25 @@ __global__ void k_special_class(Ctx c, const SpecialPair *sp, long long n, uint8
 	cls[i] = (uint8_t)k;
 	if (k) mask[sp[i].pair] = 0;
 }
-// one wavefront per special pair of class 1 that is still predictable (not count-sensitive): adopt_auto in aln_device.h
+// the special pairs of class 1 that are still predictable (not count-sensitive): adopt_auto in aln_device.h
+#ifndef PSVR_ADOPT_LANES
+#define PSVR_ADOPT_LANES 4
+#endif
+static const int kAdoptLanes = PSVR_ADOPT_LANES;
 __global__ __launch_bounds__(kBlock) void k_adopt_auto(Ctx c, const SpecialPair *sp, long long n, const uint8_t *cls, const uint8_t *mask, const long long *noff,
                                                        int32_t *adopted, long long *adopted_at, unsigned long long *count, const int32_t *host_pairs, const int32_t *host_slots, long long n_host)
 {
-	const long long i = blockIdx.x * (long long)(kBlock / 64) + (threadIdx.x >> 6);
+	// kAdoptLanes lanes per adoption (what lanes share is the copy of 24 header words; the rest is one lane's chain of loads and stores): a
+	// wavefront per adoption kept 20 k wavefronts alive for one lane's chain each, 78 us; sixteen adoptions per wavefront are one round, 
+	const long long i = blockIdx.x * (long long)(kBlock / kAdoptLanes) + (threadIdx.x / kAdoptLanes);
+	const int part = (int)(threadIdx.x % kAdoptLanes);
 	if (i >= n) {                                                     // behind the special pairs: the adoptions the host's walk decided (pair, slot)
-		if (i - n < n_host) adopt_variant(c, host_pairs[i - n], host_slots[i - n], noff, threadIdx.x & 63, 64);
+		if (i - n < n_host) adopt_variant(c, host_pairs[i - n], host_slots[i - n], noff, part, kAdoptLanes);
 		return;
 	}
 	if (!cls[i] || mask[sp[i].pair]) return;
-	const int did = adopt_auto(c, sp[i], noff, adopted + i, adopted_at + i, threadIdx.x & 63, 64);
-	if (count && did && (threadIdx.x & 63) == 0) atomicAdd(count, 1ull);   // (statistics only: 17 k wavefronts on one counter are 0.2 ms, tools/atomic_rate_bench.hip)
+	const int did = adopt_auto(c, sp[i], noff, adopted + i, adopted_at + i, part, kAdoptLanes);
+	if (count && did && part == 0) atomicAdd(count, 1ull);           // (statistics only: 17 k wavefronts on one counter are 0.2 ms, tools/atomic_rate_bench.hip)
 }
 // ---- result hand-over -------------------------------------------------------------------------
 // the fixed-size ABI records (psvr_engine_download): one thread per read
@@ -1533,7 +1540,7 @@ struct GpuBE {
 			note(tmp_idx.ensure(n_host * 4)), note(tmp_val.ensure(n_host * 4));
 			h2d(tmp_idx.p, host_pairs, n_host * 4), h2d(tmp_val.p, host_slots, n_host * 4);
 		}
-		hipLaunchKernelGGL(k_adopt_auto, dim3(grid_for(n + n_host, kBlock / 64)), dim3(kBlock), 0, stream, c, sp, n, cls, mask, noff, adopted, adopted_at, count,
+		hipLaunchKernelGGL(k_adopt_auto, dim3(grid_for(n + n_host, kBlock / kAdoptLanes)), dim3(kBlock), 0, stream, c, sp, n, cls, mask, noff, adopted, adopted_at, count,
 		                   (const int32_t *)tmp_idx.p, (const int32_t *)tmp_val.p, n_host);
 		note(hipGetLastError());
 	}
