@@ -210,3 +210,37 @@ def test_index_built_in_hbm_from_the_anchor_fasta_aligns_like_the_reference_buil
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     with gzip.open(os.path.join(ac.golden_dir("fx2"), "reads150.sam.gz"), "rb") as f:
         assert open(os.path.join(tmp, "o.sam"), "rb").read() == f.read()
+
+
+def test_job_slots_of_one_process_continue_each_other():
+    """Three engines of one process take turns, batch after batch, each starting in the draw streams where the one before stopped -- the
+    pattern of a caller that overlaps upload / run / download over job slots (bench.py's pipelined leg, the reference's kt_pipeline).  The
+    engines share the process-wide rand() stream (engine_core.h SharedRand) and take their batches as windows of ONE array (offsets that
+    do not start at 0: what the device's pass over an uploaded batch, k_scan_batch, must cope with, unaligned read starts included).
+    Their records, batch by batch, are the reference's for the whole input: the golden run is one stream over all pairs."""
+    from pansvr_amd import aln
+    bases, base_off, ori, stat = _inputs("fx2", "reads150", 900)      # fx2: N bases, unmapped / full-score originals, tied chains
+    P = (len(base_off) - 1) // 2
+    index = _index()
+    engs = [aln.Engine(index, aln.default_params(stat)) for _ in range(3)]
+    cuts = [0, 97, 98, 350, 351, 600, 899, 900]                        # ragged batches, one of a single pair
+    lens = np.diff(base_off)
+    got, pos = [], None
+    for k in range(len(cuts) - 1):
+        lo, hi = cuts[k], cuts[k + 1]
+        e = engs[k % 3]
+        e.upload(bases, base_off[2 * lo:2 * hi + 1], ori[2 * lo:2 * hi])
+        if pos is not None:
+            e.set_stream_pos(pos)
+        e.run()
+        pos = e.stream_end()
+        r, p, c = e.download()
+        recs = ac.engine_records(r, p, c, ori[2 * lo:2 * hi], lens[2 * lo:2 * hi], 0, hi - lo)
+        for x in recs:
+            x["i"] += lo
+        got += recs
+    want = [ac.strip_trace(l) for l in ac.golden_lines("fx2", "reads150")[:P]]
+    assert got == want
+    for e in engs:
+        e.close()
+    index.close()
