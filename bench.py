@@ -640,8 +640,9 @@ def main():
             cli = os.path.join(ROOT, "pansvr_amd", "bin", "panSVR")
             nt = min(48, ncore)                      # the reference's own thread limit (read_realignment.hpp:121)
             e2e = {"pairs": n_e2e, "threads": nt, "input": "FASTQ of the bench batch in RAM-backed storage (%.2f GB)" % (os.path.getsize(fq) / 1e9)}
-            # SAM text; BAM at zlib's default level (what htslib's "wb" -- the reference's output -- uses); BAM at level 1 (--compress-level 1)
-            for key, mode, ext in (("sam", ["-S"], "sam"), ("bam", [], "bam"), ("bam_level1", ["--compress-level", "1"], "bam")):
+            # SAM text; BAM at zlib's default level (what htslib's "wb" -- the reference's output -- uses); BAM at level 1 (--compress-level 1); BAM with the BGZF blocks
+            # compressed on the GPU (--bgzf-device)
+            for key, mode, ext in (("sam", ["-S"], "sam"), ("bam", [], "bam"), ("bam_level1", ["--compress-level", "1"], "bam"), ("bam_device", ["--bgzf-device"], "bam")):
                 r = subprocess.run([cli, "aln", "-t", str(nt)] + mode + ["-o", os.path.join(tmp, "o." + ext), "-p", os.path.join(tmp, "p." + ext)] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 if r.returncode != 0:
                     e2e[key] = {"error": r.stderr.decode()[-300:]}

@@ -292,6 +292,15 @@ int psvr_engine_rebase(psvr_engine_t *eng, const int64_t pos[3], void *stream);
 /* work counters of the last run (probes, hits, dp problems, cells, speculative re-runs ...) as JSON */
 int psvr_engine_stats(const psvr_engine_t *eng, char *buf, size_t buflen);
 
+/* ---- BGZF members on the device (the BAM output's compression) --------------------------------------------------------------
+ * Replaces, for the drop-in command's BAM output, htslib's bgzf_compress (htslib bgzf.c: zlib deflate of 0xff00-byte blocks on the host,
+ * reached from the reference's sam_write1 calls, read_realignment.cpp:166-176 -> bam_file.c).  `in` (host memory, n_bytes) is cut into
+ * blocks of 16 KB (BGZF allows any size up to 64 KB; htslib uses 0xff00); every block becomes one BGZF member (gzip header with the BC field, raw DEFLATE, CRC32, ISIZE), the members are
+ * written next to each other into `out` (host memory, out_cap bytes; psvr_bgzf_bound(n_bytes) always suffices) and *out_bytes is their
+ * total size.  The EOF marker block is the caller's.  Any BGZF / gzip reader decodes the result; the bytes differ from zlib's. */
+int64_t psvr_bgzf_bound(int64_t n_bytes);
+int psvr_bgzf_compress(int device, const void *in, int64_t n_bytes, void *out, int64_t out_cap, int64_t *out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 #include <atomic>
@@ -20,6 +21,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#ifdef PSVR_BGZF_ON_DEVICE                            /* (the CLI, which links the engine library: psvr_bgzf_compress) */
+#include "../../include/psvr_engine.h"
+#endif
 
 namespace psvr {
 
@@ -42,6 +46,8 @@ class BgzfWriter {
 	bool ok_ = true;
 	int threads_ = 1;
 	int level_ = Z_DEFAULT_COMPRESSION;           // htslib's "wb" is zlib's default level too
+	int device_ = -1;                             // >= 0: BGZF members come from psvr_bgzf_compress on that device
+	std::vector<uint8_t> dev_out_;
 	// one member: gzip header with the BC extra field, raw deflate, CRC32, ISIZE (SAMv1 4.1); returns the member size
 	static size_t compress_block(const uint8_t *p, size_t n, uint8_t *out, int level = Z_DEFAULT_COMPRESSION)
 	{
@@ -69,6 +75,19 @@ private:
 	void flush_blocks(const uint8_t *p, size_t n)
 	{
 		const size_t nb = (n + kBlock - 1) / kBlock;
+#ifdef PSVR_BGZF_ON_DEVICE
+		static const size_t dev_min = getenv("PSVR_BGZF_DEVICE_MIN_BLOCKS") ? (size_t)atoll(getenv("PSVR_BGZF_DEVICE_MIN_BLOCKS")) : 64;   // (tests: small files through the device too)
+		if (device_ >= 0 && nb >= dev_min) {
+			dev_out_.resize((size_t)psvr_bgzf_bound((int64_t)n));
+			int64_t got = 0;
+			if (psvr_bgzf_compress(device_, p, (int64_t)n, dev_out_.data(), (int64_t)dev_out_.size(), &got) == 0) {
+				if (fwrite(dev_out_.data(), 1, (size_t)got, f_) != (size_t)got) ok_ = false;
+				return;
+			}
+			fprintf(stderr, "[panSVR-amd] BGZF on the device failed (%s): compressing on the host\n", psvr_last_error());
+			device_ = -1;
+		}
+#endif
 		std::vector<uint8_t> out(nb * kOut);
 		std::vector<size_t> len(nb, 0);
 		std::atomic<size_t> next(0);
@@ -89,11 +108,15 @@ private:
 	}
 public:
 	bool open(const char *fn, int threads = 1, int level = Z_DEFAULT_COMPRESSION) { f_ = fopen(fn, "wb"); threads_ = threads; level_ = level; return f_ != nullptr; }
+	// compress on HIP device `d` (psvr_bgzf_compress: a lane per block; the members decode like any other, their bytes are not zlib's)
+	void set_device(int d) { device_ = d; }
 	void write(const void *p, size_t n)
 	{
 		const uint8_t *b = (const uint8_t *)p;
 		buf_.insert(buf_.end(), b, b + n);
-		const size_t batch = kBlock * (size_t)(threads_ < 1 ? 1 : threads_) * 8;   // enough whole blocks to keep every thread busy
+		// enough whole blocks to keep every thread busy; on the device a call lasts as long as ONE block takes a lane (tens of ms) however
+		// many blocks it holds, so the batches are large
+		const size_t batch = device_ >= 0 ? kBlock * (size_t)3072 : kBlock * (size_t)(threads_ < 1 ? 1 : threads_) * 8;
 		if (buf_.size() < batch) return;
 		const size_t whole = buf_.size() / kBlock * kBlock;
 		flush_blocks(buf_.data(), whole);
@@ -124,6 +147,17 @@ inline int nt16_code(char ch)
 inline char nt16_char(char ch) { return "=ACMGRSVTWYHKDBN"[nt16_code(ch)]; }
 
 struct BamRef { std::string name; uint32_t len; };
+
+inline int bam_reg2bin(int64_t beg, int64_t end)             // SAMv1 section 5.3
+{
+	--end;
+	if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+	if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+	if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+	if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+	if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+	return 0;
+}
 
 // one alignment record in SAM terms (what the CLI's emit_record prints)
 struct SamFields {
@@ -266,6 +300,7 @@ public:
 		return true;
 	}
 	void write_raw(const void *p, size_t n) { z_.write(p, n); }
+	void set_device(int d) { z_.set_device(d); }
 	bool close() { return z_.close(); }
 };
 

@@ -10,6 +10,7 @@
 // every batch is cut into contiguous blocks -- pair i of n goes to device floor(i * D / n), kt_for's contract of independent
 // items (clib/kthread.c:43-86) with the order kept -- and because the reference draws from ONE rand()/random_r sequence in input
 // order, block d is moved to start where block d-1 ended (psvr_engine_rebase) before the ordered gather into step 2.
+#define PSVR_BGZF_ON_DEVICE 1
 #include <getopt.h>
 #include <signal.h>
 #include <stdio.h>
@@ -52,6 +53,7 @@ struct Opt {
 	                                       // reference-sized batches do not fill a four-stage pipeline, forty pieces do
 	bool sig_all = false, sig_discard = false;   // BAM input: fc_signal's -D / -U
 	int bam_level = -1;                          // zlib level of the BGZF blocks (-1 = zlib's default, what htslib's "wb" uses)
+	bool bgzf_device = false;                    // the main file's BGZF blocks compressed on the first device (psvr_bgzf_compress)
 };
 
 static int usage()
@@ -86,6 +88,8 @@ static int usage()
 	        "        --batch-bases       INT  bases per batch (the reference stops a batch at 100 MB of bases) [100000000]\n"
 	        "        --sub-batch         INT  pairs per pipeline piece of a batch, 0 = whole batches (results do not depend on it) [65536]\n"
 	        "        --compress-level    INT  zlib level of the BAM output's BGZF blocks, 0-9 (1 is ~3x faster than the default) [-1 = default, like htslib]\n"
+	        "        --bgzf-device            compress the BAM output's BGZF blocks on the GPU (a lane per block; ~10 %% larger than zlib level 1,\n"
+	        "                                 the host's deflate is what bounds the BAM route otherwise)\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
 	        "        --trace                  add per-strand seed/chain hashes to --records\n\n");
 	return 1;
@@ -180,7 +184,7 @@ int main(int argc, char **argv)
 	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
 	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
 	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
-	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006}, {"sub-batch", 1, 0, 1007},
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006}, {"sub-batch", 1, 0, 1007}, {"bgzf-device", 0, 0, 1008},
 	                             {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {"sort-by-name", 0, 0, 'N'}, {0, 0, 0, 0}};
 	int c;
 	bool sig_by_name = false;
@@ -208,6 +212,7 @@ int main(int argc, char **argv)
 		case 1004: if (!parse_devices(optarg, &o.devices)) { fprintf(stderr, "bad --devices list '%s'\n", optarg); return 1; } break;
 		case 1005: o.batch_bases = atoll(optarg); break;
 		case 1007: o.sub_pairs = atoll(optarg); break;
+		case 1008: o.bgzf_device = true; break;
 		case 1006: o.bam_level = atoi(optarg); if (o.bam_level < -1 || o.bam_level > 9) { fprintf(stderr, "--compress-level wants -1 .. 9\n"); return 1; } break;
 		case 'D': o.sig_all = true; break;
 		case 'U': o.sig_discard = true; break;
@@ -278,6 +283,7 @@ int main(int argc, char **argv)
 	else if (!fq.open(fq_path.c_str())) { fprintf(stderr, "%s\n", fq.error().c_str()); abort(); }
 	OutFile fo, fo_ori;
 	if (!fo.open(o.out, !o.sam, H, o.thread_n, o.bam_level) || !fo_ori.open(o.out_ori, !o.sam, H, o.thread_n, o.bam_level)) { fprintf(stderr, "fail to open output file\n"); abort(); }
+	if (o.bgzf_device && !o.sam) fo.bam.set_device(o.devices[0]), fo_ori.bam.set_device(o.devices[0]);
 	FILE *frec = o.records.empty() ? nullptr : fopen(o.records.c_str(), "w");
 	fprintf(stderr, "Processing file: [%s].\n", o.reads.c_str());
 

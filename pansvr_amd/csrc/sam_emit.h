@@ -113,12 +113,37 @@ struct RawOut {
 		put(b + n, (size_t)(24 - n));
 	}
 	void tag_int(const char *tag5, long long x) { ch('\t'), put(tag5, 5), num(x); }
+	// ---- BAM (little-endian binary)
+	void u8(unsigned x) { *p++ = (uint8_t)x; }
+	void u16(unsigned x) { p[0] = (uint8_t)x, p[1] = (uint8_t)(x >> 8), p += 2; }
+	void u32(uint32_t x) { p[0] = (uint8_t)x, p[1] = (uint8_t)(x >> 8), p[2] = (uint8_t)(x >> 16), p[3] = (uint8_t)(x >> 24), p += 4; }
+	void bam_int(const char *tag2, long long x)        // an integer tag in the smallest type, as sam_parse1 chooses (BamWriter::put_int_tag)
+	{
+		put(tag2, 2);
+		if (x < 0) {
+			if (x >= -128) u8('c'), u8((unsigned)(int8_t)x);
+			else if (x >= -32768) u8('s'), u16((unsigned)(uint16_t)(int16_t)x);
+			else u8('i'), u32((uint32_t)(int32_t)x);
+		} else {
+			if (x <= 255) u8('C'), u8((unsigned)x);
+			else if (x <= 65535) u8('S'), u16((unsigned)x);
+			else u8('I'), u32((uint32_t)x);
+		}
+	}
+	void bam_z(const char *tag2) { put(tag2, 2), u8('Z'); }   // the value and its NUL follow
 };
 // SEQ / QUAL of a record: forward = the read through htslib's 4-bit code (nt16_char), reverse = getReverseStr_char /
 // getReverseStr_qual_char (the even-length quirk: the middle pair is swapped back) -- byte tables instead of a switch per base
 struct SeqTables {
 	uint8_t rc[256], n16[256];
-	SeqTables() { for (int c = 0; c < 256; ++c) rc[c] = (uint8_t)sam_rc_char((char)c), n16[c] = (uint8_t)nt16_char((char)c); }
+	uint8_t c16[256], rc16[256];                     // the 4-bit BAM code of a base / of its reverse-strand character
+	SeqTables()
+	{
+		for (int c = 0; c < 256; ++c) {
+			rc[c] = (uint8_t)sam_rc_char((char)c), n16[c] = (uint8_t)nt16_char((char)c);
+			c16[c] = (uint8_t)nt16_code((char)c), rc16[c] = (uint8_t)nt16_code(sam_rc_char((char)c));
+		}
+	}
 };
 inline const SeqTables &seq_tables() { static const SeqTables t; return t; }
 inline void put_seq_qual(RawOut &o, const char *t, const char *qt, int n, bool reverse)
@@ -142,6 +167,7 @@ public:
 	const HeaderInfo *H = nullptr;
 	const SvNames *sv = nullptr;
 	bool as_bam = false, not_ori = false;
+	bool bam_via_text = false;                       // tests: every BAM record through the SAM-line strings and BamWriter::encode (the direct encoder must give the same bytes)
 	int min_filter_score = 520;
 	EmitStats *stats = nullptr;
 
@@ -298,7 +324,7 @@ public:
 			} else {
 				const psvr_cand_t &cd = V.cands[rr.cand_off + rr.primary];
 				chr_id = cd.chr_id, direction = cd.direction, mapq = cd.mapq, ref_bg = cd.ref_bg, align_score = cd.align_score, chain_score = cd.chain_score;
-				if (as_bam) cigar_text(cd, V.cig, cg); else pcd = &cd;        // (the SAM path prints the operations straight into the record)
+				if (!as_bam) pcd = &cd;                                       // (both paths print / encode the operations straight into the record)
 			}
 			if ((uint32_t)chr_id == 0xffffffffu) continue;           // primary_result->chrID == MAX_uint32_t
 			const int flag = (uint8_t)((k == 0 ? 0x40 : 0) + (direction == 0 ? 0x10 : 0) + (rr.has_mate ? 0 : 0x8));
@@ -362,6 +388,108 @@ public:
 				o.ch('\n');
 				o.close();
 				continue;
+			}
+			{
+				// BAM record straight into the output buffer: the fields of the SAM line above in BAM's binary layout (SAMv1 4.2), i.e. what
+				// BamWriter::encode makes of that line -- which stays the path for the records this one declines (a tab inside a string
+				// tag's value, a CIGAR operator beyond 'X': the text path decides what becomes of those).  Building six strings per record
+				// and parsing them back was 0.45 s per 1 M pairs of the command's BAM route.
+				const char *qt, *nt, *ct; int qn, nn, cn;
+				B.qual(r, qt, qn), B.name(r, nt, nn), B.comment(r, ct, cn);
+				const int pos = (int)ref_bg;
+				const char *svs = sv->print_string(rr.prim_sv_id);
+				const char *mvs = rr.has_mate ? sv->print_string(rr.mate_sv_id) : nullptr;
+				const psvr_cand_t *sc = rr.secondary >= 0 ? &V.cands[rr.cand_off + rr.secondary] : nullptr;
+				const char *vid = sc ? sv->vcf_id(sc->sv_id) : nullptr;
+				const psvr_cand_t *cd = is_ori ? nullptr : &V.cands[rr.cand_off + rr.primary];
+				bool plain = !bam_via_text && chr_id >= 0 && chr_id < (int)H->names.size() && pos - 1 >= 0 && nn > 0 && nn <= 254 && qn == read_l && !memchr(ct, '\t', (size_t)cn) &&
+				             !(svs && strchr(svs, '\t')) && !(mvs && strchr(mvs, '\t')) && !(vid && strchr(vid, '\t')) && (!cd || cd->n_cigar <= 0xffff);
+				if (plain && cd) for (uint32_t j = 0; j < cd->n_cigar; ++j) if ((V.cig[cd->cigar_off + j] & 0xf) > 8) { plain = false; break; }
+				if (plain) {
+					const SeqTables &T = seq_tables();
+					RawOut o(dst, (size_t)nn + (size_t)cn + 2 * (size_t)read_l + (cd ? (size_t)cd->n_cigar * 4 : 8) + (svs ? strlen(svs) : 0) + (mvs ? strlen(mvs) : 0) + (vid ? strlen(vid) : 0) + 512);
+					uint8_t *const rec0 = o.p;
+					o.u32(0);                                                   // block_size, patched below
+					o.u32((uint32_t)chr_id), o.u32((uint32_t)(pos - 1));
+					o.u8((unsigned)nn + 1), o.u8((unsigned)mapq);
+					uint8_t *const bin_at = o.p;
+					o.u16(0);                                                   // bin, patched when the reference length is known
+					const uint32_t ncig = cd ? cd->n_cigar : (ori.read_bg > 0 ? 2u : 1u);
+					o.u16(ncig), o.u16((unsigned)flag), o.u32((uint32_t)read_l);
+					int mtid = -1;
+					long pnext = 0;
+					if (rr.has_mate) {
+						const int mp = (int)rr.mate_ref_bg, mc = rr.mate_chr_id;
+						if (mc >= 0 && mc < (int)H->names.size() && !(mp - 1 < 0)) mtid = mc;
+						pnext = mp;
+					}
+					o.u32((uint32_t)mtid), o.u32((uint32_t)(int32_t)(pnext - 1)), o.u32((uint32_t)isize);
+					o.put(nt, (size_t)nn), o.u8(0);
+					int64_t rlen = 0;
+					auto cig_op = [&](long long len, unsigned op) {            // (lengths are printed as int16 and parsed back: negative ones keep their sign bits)
+						o.u32((uint32_t)len << 4 | op);
+						if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (uint32_t)len & 0xfffffff;
+					};
+					if (cd) for (uint32_t j = 0; j < cd->n_cigar; ++j) { const uint32_t w = V.cig[cd->cigar_off + j]; cig_op((int)(int16_t)(w >> 4), w & 0xf); }
+					else {
+						if (ori.read_bg > 0) cig_op((int)(int16_t)(uint16_t)ori.read_bg, 4);
+						cig_op((int)(int16_t)(uint16_t)(read_l - (int)ori.read_bg), 0);
+					}
+					{
+						const int64_t p0 = pos - 1;
+						const int bin = bam_reg2bin(p0, p0 + (rlen > 0 ? rlen : 1));
+						bin_at[0] = (uint8_t)bin, bin_at[1] = (uint8_t)(bin >> 8);
+					}
+					// SEQ: two 4-bit codes per byte; QUAL: phred values (the reverse strand through getReverseStr_char / getReverseStr_qual_char)
+					const bool rev = direction == 0;
+					for (int i = 0; i < read_l; i += 2) {
+						const unsigned hi = rev ? T.rc16[(uint8_t)t[read_l - 1 - i]] : T.c16[(uint8_t)t[i]];
+						const unsigned lo = i + 1 < read_l ? (rev ? T.rc16[(uint8_t)t[read_l - 2 - i]] : T.c16[(uint8_t)t[i + 1]]) : 0u;
+						o.u8(hi << 4 | lo);
+					}
+					{
+						uint8_t *ql = o.p;
+						if (rev) {
+							for (int i = 0; i < read_l; ++i) ql[i] = (uint8_t)(qt[read_l - 1 - i] - 33);
+							if (!(read_l & 1) && read_l >= 2) ql[read_l / 2 - 1] = (uint8_t)(qt[read_l / 2 - 1] - 33), ql[read_l / 2] = (uint8_t)(qt[read_l / 2] - 33);
+						} else for (int i = 0; i < read_l; ++i) ql[i] = (uint8_t)(qt[i] - 33);
+						o.p += read_l;
+					}
+					o.bam_int("AS", (int)align_score), o.bam_int("OS", (int)ori.align_score);
+					o.bam_z("OA"), o.num(ori.chr_id), o.ch(','), o.num((int)(ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg)), o.ch(','), o.num((int)ori.read_bg), o.ch(',');
+					o.num((int)ori.mapq), o.put(rr.unmapped ? ",U;" : ",M;", 3), o.u8(0);
+					if (!is_ori) o.bam_int("CS", (int)chain_score);
+					if (svs) o.bam_z("SV"), o.put(svs, strlen(svs)), o.u8(0);
+					if (mvs) o.bam_z("MV"), o.put(mvs, strlen(mvs)), o.u8(0);
+					if (sc) {
+						o.bam_z("XA"), o.num(sc->chr_id), o.ch(','), o.num((int)sc->ref_bg), o.ch(','), o.num((int)sc->read_bg), o.ch(','), o.num((int)sc->align_score);
+						o.put(sc->direction == 1 ? ",F," : ",R,", 3);
+						if (vid) o.put(vid, strlen(vid)); else o.ch('*');
+						o.ch(';'), o.u8(0);
+					}
+					{   // RC:Z = the comment as parse_ori_mapping_rst leaves it (see rewrite_comment), up to a NUL
+						o.bam_z("RC");
+						uint8_t *at = o.p;
+						memcpy(at, ct, (size_t)cn);
+						int32_t cut[10];
+						parse_ori_span(ct, cn, cut);
+						size_t len = (size_t)cn;
+						for (int q = 0; q < 10; ++q) {
+							if (cut[q] < 0) continue;
+							if (cut[q] < cn - 1) at[(size_t)cut[q]] = ',';
+							else if ((size_t)cut[q] < len) len = (size_t)cut[q];
+						}
+						if (const void *z = memchr(at, 0, len)) len = (size_t)((const uint8_t *)z - at);
+						o.p += len;
+						o.u8(0);
+					}
+					const uint32_t bs = (uint32_t)(o.p - rec0) - 4;
+					rec0[0] = (uint8_t)bs, rec0[1] = (uint8_t)(bs >> 8), rec0[2] = (uint8_t)(bs >> 16), rec0[3] = (uint8_t)(bs >> 24);
+					o.close();
+					continue;
+				}
+				if (!cd) {}                                                   // (is_ori: cg holds the text already)
+				else cigar_text(*cd, V.cig, cg);
 			}
 			seq.assign(t, (size_t)n);
 			B.qual(r, t, n), qual.assign(t, (size_t)n);

@@ -223,7 +223,8 @@ int main(int argc, char **argv)
 	bool trace = false, quiet = false, not_ori = false, sig_n = false, sig_d = false, sig_u = false;
 	long long batch = 1 << 20;
 	int threads = 1;
-	const char *sam_fn = nullptr, *ori_fn = nullptr;
+	const char *sam_fn = nullptr, *ori_fn = nullptr, *bam_fn = nullptr;
+	bool bam_text = false;
 	long long pos[3] = {-1, -1, -1}, from[3] = {-1, -1, -1};
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
@@ -236,6 +237,8 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--sam") && i + 1 < argc) sam_fn = argv[++i];
 		else if (!strcmp(argv[i], "--ori-sam") && i + 1 < argc) ori_fn = argv[++i];
+		else if (!strcmp(argv[i], "--bam-records") && i + 1 < argc) bam_fn = argv[++i];      // the main file's records as BAM bytes (uncompressed, no header): direct encoder
+		else if (!strcmp(argv[i], "--bam-via-text")) bam_text = true;                          // ... through the SAM-line strings and BamWriter::encode instead
 		else if (!strcmp(argv[i], "--stream-pos") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &pos[0], &pos[1], &pos[2]);       // start of this shard in the three draw streams
 		else if (!strcmp(argv[i], "--rebase-from") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &from[0], &from[1], &from[2]);  // run there first, then rebase to --stream-pos
 	}
@@ -276,7 +279,8 @@ int main(int argc, char **argv)
 	HostSvNames svn;
 	svn.h = &hi;
 	SamEmitter em;
-	FILE *fsam = nullptr, *fori = nullptr;
+	FILE *fsam = nullptr, *fori = nullptr, *fbam = nullptr;
+	if (bam_fn && !(fbam = fopen(bam_fn, "wb"))) { fprintf(stderr, "cannot open %s\n", bam_fn); return 2; }
 	if (sam_fn && ori_fn) {
 		if (!H.load(argv[3])) { fprintf(stderr, "cannot read %s\n", argv[3]); return 2; }
 		fsam = fopen(sam_fn, "w"), fori = fopen(ori_fn, "w");
@@ -312,6 +316,13 @@ int main(int argc, char **argv)
 			Bytes a, b;
 			for (long long p = 0; p < fb.n_pairs(); ++p) em.main_pair(fb, V, p, a), em.ori_pair(fb, V, p, b);
 			fwrite(a.data(), 1, a.size(), fsam), fwrite(b.data(), 1, b.size(), fori);
+			if (fbam) {
+				SamEmitter eb = em;
+				eb.as_bam = true, eb.bam_via_text = bam_text;
+				Bytes m;
+				for (long long p = 0; p < fb.n_pairs(); ++p) eb.main_pair(fb, V, p, m);
+				fwrite(m.data(), 1, m.size(), fbam);
+			}
 		}
 		core.commit();
 		fprintf(stderr, "[emu] stream_end %lld %lld %lld\n", core.grand_pos, core.hrand_pos[0], core.hrand_pos[1]);
@@ -321,6 +332,7 @@ int main(int argc, char **argv)
 		        core.stats.pairs_run, core.stats.pair_only, core.stats.shadow_runs, core.stats.sensitive, core.stats.window_miss, core.stats.dp_problems, core.stats.cands);
 	}
 	if (fsam) fclose(fsam), fclose(fori);
+	if (fbam) fclose(fbam);
 	feed.abort();
 	if (sig_thread.joinable()) sig_thread.join();
 	if (sig_rc) { fprintf(stderr, "the signal step failed\n"); return 4; }

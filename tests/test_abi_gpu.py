@@ -244,3 +244,40 @@ def test_job_slots_of_one_process_continue_each_other():
     for e in engs:
         e.close()
     index.close()
+
+
+def test_bgzf_members_from_the_device_decode_to_their_input():
+    """psvr_bgzf_compress: every block (16 KB; PSVR_BGZF_BLOCK) of the input becomes one BGZF member on the device (a lane per block); the members,
+    decoded one by one with zlib -- header fields, BSIZE, CRC32 and ISIZE checked by hand --, give back the input.  Input: BAM-like
+    records, incompressible bytes (stored blocks), long runs, a last block of 1 byte."""
+    import struct
+    import zlib
+    from pansvr_amd._lib import check, lib
+    rng = np.random.RandomState(5)
+    parts = [bytes(rng.randint(0, 256, size=200000, dtype=np.uint8)), b"\0" * 300000,
+             b"".join(b"read%07d\tAS:i:%d\tXA:Z:chr%d,%d;\n" % (i, rng.randint(300), rng.randint(24), rng.randint(1 << 30)) for i in range(60000)),
+             bytes(rng.randint(0, 4, size=400000, dtype=np.uint8) + 65), b"x"]
+    data = b"".join(parts)
+    blk = int(os.environ.get("PSVR_BGZF_BLOCK", "16384"))
+    data += b"y" * ((-len(data)) % blk + 1)                         # the last block holds a single byte
+    L = lib()
+    L.psvr_bgzf_bound.restype = C.c_int64
+    L.psvr_bgzf_bound.argtypes = [C.c_int64]
+    cap = L.psvr_bgzf_bound(len(data))
+    out = C.create_string_buffer(cap)
+    got = C.c_int64(0)
+    check(L.psvr_bgzf_compress(0, data, C.c_int64(len(data)), out, C.c_int64(cap), C.byref(got)))
+    raw, pos, back, stored = out.raw[:got.value], 0, [], 0
+    while pos < len(raw):
+        assert raw[pos:pos + 4] == b"\x1f\x8b\x08\x04" and raw[pos + 10:pos + 16] == b"\x06\x00BC\x02\x00"
+        bsize = struct.unpack("<H", raw[pos + 16:pos + 18])[0] + 1
+        body = raw[pos + 18:pos + bsize - 8]
+        crc, isize = struct.unpack("<II", raw[pos + bsize - 8:pos + bsize])
+        d = zlib.decompressobj(-15)
+        block = d.decompress(body) + d.flush()
+        assert d.eof and not d.unused_data and len(block) == isize and zlib.crc32(block) == crc
+        stored += (body[0] & 6) == 0
+        back.append(block)
+        pos += bsize
+    assert b"".join(back) == data and all(len(b) == blk for b in back[:-1]) and len(back[-1]) == 1
+    assert stored >= 3 and got.value < 0.75 * len(data)              # the random bytes are stored, the rest is compressed

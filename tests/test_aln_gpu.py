@@ -71,6 +71,14 @@ def test_gpu_cli_bam_output_equals_sam_text():
         r = subprocess.run([CLI, "aln"] + mode + ["-o", os.path.join(tmp, "out." + ext), "-p", os.path.join(tmp, "ori." + ext)] + base,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
+    # ... and with the BGZF blocks compressed on the device (--bgzf-device; the threshold that leaves small files to the host lowered)
+    r = subprocess.run([CLI, "aln", "--bgzf-device", "-o", os.path.join(tmp, "outd.bam"), "-p", os.path.join(tmp, "orid.bam")] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, PSVR_BGZF_DEVICE_MIN_BLOCKS="1"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert "BGZF on the device failed" not in r.stderr.decode()
+    assert bam_reader.check_bgzf(os.path.join(tmp, "outd.bam")) >= 1
+    assert bam_reader.read_bam(os.path.join(tmp, "outd.bam")) == bam_reader.read_bam(os.path.join(tmp, "out.bam"))
+    assert bam_reader.read_bam(os.path.join(tmp, "orid.bam")) == bam_reader.read_bam(os.path.join(tmp, "ori.bam"))
     header = open(os.path.join(w, "header.sam")).read()
     for stem in ("out", "ori"):
         assert bam_reader.check_bgzf(os.path.join(tmp, stem + ".bam")) >= 1

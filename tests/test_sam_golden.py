@@ -60,3 +60,23 @@ def test_formatter_not_ori_option_matches_the_reference(emu, name, rname):
         assert got == want, "%s differs from the reference's -Q file" % got_fn
     # the option really drops records: the -Q main file is a proper subset of the default one
     assert golden_text(name, rname, ".notori.sam.gz").count(b"\n") < golden_text(name, rname, ".sam.gz").count(b"\n")
+
+
+@pytest.mark.parametrize("name,rname", [("fx2", "reads150"), ("fx3", "ragged"), ("fx3", "lower"), ("fx1", "reads150")])
+def test_direct_bam_encoder_writes_the_bytes_of_the_text_path(emu, name, rname):
+    """The main file's BAM records come straight from the engine's results (sam_emit.h, the direct encoder); BamWriter::encode on the
+    SAM line's fields -- the path that was checked against the reference's SAM text through an independent BAM reader -- must give the
+    same bytes, record for record (fx2: N bases, unmapped and full-score originals, secondary candidates; fx3: ragged lengths incl. even
+    ones on the reverse strand, lower-case bases)."""
+    w = ac.workdir(name)
+    if not os.path.exists(os.path.join(w, rname + ".fq")):
+        pytest.skip("no such read set")
+    tmp = tempfile.mkdtemp(prefix="psvr_bamenc_")
+    outs = []
+    for tag, extra in (("direct", []), ("text", ["--bam-via-text"])):
+        fn = os.path.join(tmp, tag + ".bamrec")
+        r = subprocess.run([emu, ac.index_dir(name), os.path.join(w, rname + ".fq"), os.path.join(w, "header.sam"), "--no-records", "--sam", os.path.join(tmp, tag + ".sam"),
+                            "--ori-sam", os.path.join(tmp, tag + ".ori.sam"), "--bam-records", fn] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        outs.append(open(fn, "rb").read())
+    assert len(outs[0]) > 10000 and outs[0] == outs[1]
