@@ -47,7 +47,8 @@ class BgzfWriter {
 	int threads_ = 1;
 	int level_ = Z_DEFAULT_COMPRESSION;           // htslib's "wb" is zlib's default level too
 	int device_ = -1;                             // >= 0: BGZF members come from psvr_bgzf_compress on that device
-	std::vector<uint8_t> dev_out_;
+	uint8_t *pin_in_ = nullptr, *pin_out_ = nullptr;   // page-locked: the records of a batch, its members
+	size_t pin_n_ = 0, pin_out_cap_ = 0;
 	// one member: gzip header with the BC extra field, raw deflate, CRC32, ISIZE (SAMv1 4.1); returns the member size
 	static size_t compress_block(const uint8_t *p, size_t n, uint8_t *out, int level = Z_DEFAULT_COMPRESSION)
 	{
@@ -78,10 +79,11 @@ private:
 #ifdef PSVR_BGZF_ON_DEVICE
 		static const size_t dev_min = getenv("PSVR_BGZF_DEVICE_MIN_BLOCKS") ? (size_t)atoll(getenv("PSVR_BGZF_DEVICE_MIN_BLOCKS")) : 64;   // (tests: small files through the device too)
 		if (device_ >= 0 && nb >= dev_min) {
-			dev_out_.resize((size_t)psvr_bgzf_bound((int64_t)n));
+			const size_t need = (size_t)psvr_bgzf_bound((int64_t)n);
+			if (need > pin_out_cap_) { if (pin_out_) psvr_host_free(pin_out_); pin_out_ = (uint8_t *)psvr_host_alloc(need), pin_out_cap_ = pin_out_ ? need : 0; }
 			int64_t got = 0;
-			if (psvr_bgzf_compress(device_, p, (int64_t)n, dev_out_.data(), (int64_t)dev_out_.size(), &got) == 0) {
-				if (fwrite(dev_out_.data(), 1, (size_t)got, f_) != (size_t)got) ok_ = false;
+			if (pin_out_ && psvr_bgzf_compress(device_, p, (int64_t)n, pin_out_, (int64_t)pin_out_cap_, &got) == 0) {
+				if (fwrite(pin_out_, 1, (size_t)got, f_) != (size_t)got) ok_ = false;
 				return;
 			}
 			fprintf(stderr, "[panSVR-amd] BGZF on the device failed (%s): compressing on the host\n", psvr_last_error());
@@ -113,6 +115,23 @@ public:
 	void write(const void *p, size_t n)
 	{
 		const uint8_t *b = (const uint8_t *)p;
+#ifdef PSVR_BGZF_ON_DEVICE
+		if (device_ >= 0) {
+			// the records gather in page-locked memory (the transfer starts from where they lie: out of pageable memory the runtime copies
+			// them once more), whole batches go to the device, what is left at close() to the host's zlib
+			const size_t cap = kBlock * (size_t)3072;
+			if (!pin_in_ && !(pin_in_ = (uint8_t *)psvr_host_alloc(cap))) { device_ = -1; }
+			else {
+				if (!buf_.empty()) { std::vector<uint8_t> first; first.swap(buf_); write(first.data(), first.size()); }   // (what was written before set_device: the BAM header)
+				while (n) {
+					const size_t m = cap - pin_n_ < n ? cap - pin_n_ : n;
+					memcpy(pin_in_ + pin_n_, b, m), pin_n_ += m, b += m, n -= m;
+					if (pin_n_ == cap) flush_blocks(pin_in_, pin_n_), pin_n_ = 0;
+				}
+				return;
+			}
+		}
+#endif
 		buf_.insert(buf_.end(), b, b + n);
 		// enough whole blocks to keep every thread busy; on the device a call lasts as long as ONE block takes a lane (tens of ms) however
 		// many blocks it holds, so the batches are large
@@ -125,6 +144,11 @@ public:
 	bool close()
 	{
 		if (!f_) return false;
+#ifdef PSVR_BGZF_ON_DEVICE
+		if (pin_n_) flush_blocks(pin_in_, pin_n_), pin_n_ = 0;
+		if (pin_in_) psvr_host_free(pin_in_), pin_in_ = nullptr;
+		if (pin_out_) psvr_host_free(pin_out_), pin_out_ = nullptr, pin_out_cap_ = 0;
+#endif
 		if (!buf_.empty()) flush_blocks(buf_.data(), buf_.size());
 		static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if (fwrite(eof, 1, 28, f_) != 28) ok_ = false;

@@ -14,12 +14,14 @@
 namespace psvr {
 
 static const int kBgzfHashBits = 9;                          // 512 x uint16 per block: with its other tables 2240 bytes of LDS per lane, 140 KB per wavefront
+static const uint32_t kBgzfLaneLds = 2240 + 4;               // (an odd number of words: the lanes' tables start in different banks)
+static_assert(kBgzfLaneLds >= 2240, "lane tables");
 
 __global__ __launch_bounds__(64) void k_bgzf_deflate(const uint8_t *in, long long n_bytes, long long n_blocks, uint32_t blk, uint32_t slot, uint8_t *slots, uint8_t *work, uint32_t work_stride, int32_t *len)
 {
 	extern __shared__ __align__(16) uint8_t bgzf_lds[];
 	uint32_t *crc_tab = (uint32_t *)bgzf_lds;                                // [256]
-	uint8_t *fast = bgzf_lds + 1024 + (size_t)threadIdx.x * df_fast_bytes(kBgzfHashBits);   // this lane's tables (deflate_device.h)
+	uint8_t *fast = bgzf_lds + 1024 + (size_t)threadIdx.x * kBgzfLaneLds;   // this lane's tables (deflate_device.h)
 	for (int i = threadIdx.x; i < 256; i += 64) {
 		uint32_t c = (uint32_t)i;
 		for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
@@ -98,7 +100,7 @@ extern "C" int psvr_bgzf_compress(int device, const void *in, int64_t n_bytes, v
 		if (c.stream) (void)hipStreamDestroy(c.stream), c.stream = nullptr;
 		c.device = device;
 		PSVR_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-		PSVR_HIP(hipFuncSetAttribute((const void *)k_bgzf_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 + 64 * (int)df_fast_bytes(kBgzfHashBits)));
+		PSVR_HIP(hipFuncSetAttribute((const void *)k_bgzf_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 + 64 * (int)kBgzfLaneLds));
 	}
 	const uint32_t blk = bgzf_block_bytes(), slot = blk + 64;             // (a member never exceeds its input by more than the stored block's 5 + 26 bytes)
 	const long long nb = (n_bytes + blk - 1) / blk;
@@ -110,7 +112,7 @@ extern "C" int psvr_bgzf_compress(int device, const void *in, int64_t n_bytes, v
 	PSVR_HIP(c.off.ensure((size_t)nb * 8));
 	PSVR_HIP(c.packed.ensure((size_t)psvr_bgzf_bound(n_bytes)));
 	PSVR_HIP(hipMemcpyAsync(c.in.p, in, (size_t)n_bytes, hipMemcpyHostToDevice, c.stream));
-	hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)((nb + 63) / 64)), dim3(64), (size_t)1024 + (size_t)64 * df_fast_bytes(kBgzfHashBits), c.stream, c.in.as<uint8_t>(), (long long)n_bytes, nb, blk, slot,
+	hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)((nb + 63) / 64)), dim3(64), (size_t)1024 + (size_t)64 * kBgzfLaneLds, c.stream, c.in.as<uint8_t>(), (long long)n_bytes, nb, blk, slot,
 	                   c.slots.as<uint8_t>(), c.work.as<uint8_t>(), wstride, c.len.as<int32_t>());
 	PSVR_HIP(hipGetLastError());
 	std::vector<int32_t> len((size_t)nb);

@@ -24,21 +24,25 @@ namespace psvr {
 static const uint32_t kDfMaxIn = 0xff00;           // bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
 static const int kDfLit = 286, kDfDist = 30;
 
-struct DfBits {                                     // LSB-first bit writer into [p, end)
+struct DfBits {                                     // LSB-first bit writer into [p, end): four bytes at a time, one test per put
 	uint8_t *p, *end;
 	uint64_t acc;
 	int n;
 	bool over;
-	PSVR_DF void put(uint32_t v, int bits)
+	PSVR_DF void put(uint32_t v, int bits)          // bits <= 16
 	{
 		acc |= (uint64_t)v << n;
 		n += bits;
-		while (n >= 8) {
-			if (p < end) *p++ = (uint8_t)acc; else over = true;
-			acc >>= 8, n -= 8;
+		if (n >= 32) {
+			if (p + 4 <= end) { const uint32_t w = (uint32_t)acc; __builtin_memcpy(p, &w, 4); p += 4; } else over = true;
+			acc >>= 32, n -= 32;
 		}
 	}
-	PSVR_DF void flush() { if (n > 0) { if (p < end) *p++ = (uint8_t)acc; else over = true; } acc = 0, n = 0; }
+	PSVR_DF void flush()
+	{
+		while (n > 0) { if (p < end) *p++ = (uint8_t)acc; else over = true; acc >>= 8, n -= 8; }
+		acc = 0, n = 0;
+	}
 };
 
 // A block's small tables live in `fast` memory of the caller's (LDS on the device, 64 lanes' worth per workgroup): a lane waits for every
@@ -53,26 +57,38 @@ PSVR_DF uint32_t df_fast_freq_at(int hbits) { const uint32_t h = 2u << hbits; re
 PSVR_DF uint32_t df_fast_bytes(int hbits) { return df_fast_freq_at(hbits) + 640u + 320u; }
 
 // length 3..258 -> symbol 257..285 and its extra bits; distance 1..32768 -> symbol 0..29 and its extra bits (RFC 1951 3.2.5)
+PSVR_DF uint32_t df_ctz64(uint64_t x)               // trailing zero bits, x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t)(__ffsll((unsigned long long)x) - 1);
+#else
+	return (uint32_t)__builtin_ctzll(x);
+#endif
+}
+PSVR_DF uint32_t df_log2(uint32_t x)                  // floor(log2 x), x > 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return 31u - (uint32_t)__clz((int)x);
+#else
+	return 31u - (uint32_t)__builtin_clz(x);
+#endif
+}
+// (no loops, no branches on the value: the lanes of a wavefront each compress a block of their own, and every branch one of them takes
+// is executed by all)
 PSVR_DF void df_len_code(uint32_t len, uint32_t &sym, uint32_t &ebits, uint32_t &eval)
 {
-	if (len == 258) { sym = 285, ebits = 0, eval = 0; return; }
-	const uint32_t l = len - 3;                     // 0..254
-	if (l < 8) { sym = 257 + l, ebits = 0, eval = 0; return; }
-	uint32_t e = 0;
-	while ((l >> (e + 2)) > 1) ++e;                 // 4 << e <= l < 8 << e: four codes per extra-bit count, (l >> e) & 3 picks one
-	ebits = e;
-	sym = 257 + 4 * (e + 1) + ((l >> e) & 3);
-	eval = l & ((1u << e) - 1);
+	const uint32_t l = len - 3;                     // 0..255
+	const uint32_t e = l < 8 ? 0u : df_log2(l) - 2u;            // 4 << e <= l < 8 << e: four codes per extra-bit count, (l >> e) & 3 picks one
+	const uint32_t s = l < 8 ? 257u + l : 257u + 4u * (e + 1u) + ((l >> e) & 3u);
+	const bool top = len == 258;                    // its own code, no extra bits
+	sym = top ? 285u : s, ebits = top ? 0u : e, eval = top ? 0u : l & ((1u << e) - 1u);
 }
 PSVR_DF void df_dist_code(uint32_t dist, uint32_t &sym, uint32_t &ebits, uint32_t &eval)
 {
 	const uint32_t d = dist - 1;                    // 0..32767
-	if (d < 4) { sym = d, ebits = 0, eval = 0; return; }
-	uint32_t e = 0;
-	while ((d >> (e + 1)) > 1) ++e;                 // 2 << e <= d < 4 << e
-	ebits = e;
-	sym = 2 * (e + 1) + ((d >> e) & 1);
-	eval = d & ((1u << e) - 1);
+	const uint32_t e = d < 4 ? 0u : df_log2(d) - 1u;            // 2 << e <= d < 4 << e
+	sym = d < 4 ? d : 2u * (e + 1u) + ((d >> e) & 1u);
+	ebits = e, eval = d & ((1u << e) - 1u);
 }
 
 // code lengths (at most `maxbits`) for the n symbols with the frequencies f[0..n); len[] gets 0 for unused symbols.  At least two
@@ -170,43 +186,45 @@ PSVR_DF uint32_t deflate_block(const uint8_t *in, uint32_t n, uint8_t *out, uint
 		return (uint32_t)(win >> (8 * (p - wpos)));
 	};
 	auto hash_of = [&](uint32_t tri) { return ((tri & 0xffffffu) * 0x9E3779B1u >> (32 - hbits)) & hmask; };   // the three bytes at a position, little endian
-	auto tri_at = [&](uint32_t i) { return (uint32_t)in[i] | ((uint32_t)in[i + 1] << 8) | ((uint32_t)in[i + 2] << 16); };
-	auto bump = [](uint16_t &c) { if (c != 0xffff) ++c; };                    // (a block holds at most 65280 symbols)
 	uint32_t nt = 0;
 	for (uint32_t i = 0; i < n;) {
-		uint32_t best = 0, dist = 0;
-		if (i + 3 <= n) {
-			const bool wide = i + 4 <= n;
-			const uint32_t cur = wide ? cur32(i) : tri_at(i);
+		uint32_t best = 0, dist = 0, lit = 0;
+		if (i + 4 <= n) {
+			const uint32_t cur = cur32(i);
+			lit = cur & 0xffu;
 			const uint32_t h = hash_of(cur);
 			const uint32_t c = head[h];
 			head[h] = (uint16_t)(i + 1);
 			if (c && i + 1 - c <= 32768u) {
 				const uint32_t cp = c - 1, lim = n - i < 258u ? n - i : 258u;
-				const uint32_t cand = wide ? ld32(cp) : tri_at(cp);            // (cp < i: cp + 4 <= n whenever i + 4 <= n)
-				if (((cand ^ cur) & 0xffffffu) == 0) {
+				if (((ld32(cp) ^ cur) & 0xffffffu) == 0) {                       // (cp < i: cp + 4 <= n)
 					uint32_t k = 3;
-					while (k + 4 <= lim && ld32(cp + k) == ld32(i + k)) k += 4;
-					while (k < lim && in[cp + k] == in[i + k]) ++k;
+					while (k + 8 <= lim) {                                        // eight bytes a step
+						uint64_t a, b;
+						__builtin_memcpy(&a, in + cp + k, 8), __builtin_memcpy(&b, in + i + k, 8);
+						const uint64_t x = a ^ b;
+						if (x) { k += (uint32_t)(df_ctz64(x) >> 3); break; }
+						k += 8;
+					}
+					if (k + 8 > lim) while (k < lim && in[cp + k] == in[i + k]) ++k;
 					best = k, dist = i - cp;
 				}
 			}
-		}
-		if (best) {
-			uint32_t s, eb, ev;
-			df_len_code(best, s, eb, ev), bump(lf[s]);
-			df_dist_code(dist, s, eb, ev), bump(df[s]);
-			tok[nt++] = 0x80000000u | ((best - 3) << 16) | (dist - 1);
-			// the positions inside a match enter the table too (short matches: all of them; long ones: the first sixteen, like zlib's fast levels)
-			const uint32_t ins = best < 16u ? best : 16u;
-			for (uint32_t k = 1; k < ins; ++k) if (i + k + 3 <= n) head[hash_of(i + k + 4 <= n ? cur32(i + k) : tri_at(i + k))] = (uint16_t)(i + k + 1);
-			i += best;
-		} else {
-			const uint32_t lit = i + 4 <= n ? (cur32(i) & 0xffu) : in[i];
-			bump(lf[lit]);
-			tok[nt++] = lit;
-			++i;
-		}
+		} else lit = in[i];                                                   // (the last three bytes of a block go out as literals)
+		// (positions inside a match are not entered into the table: 1.6 % of the ratio on BAM records for a loop every lane would wait for)
+		tok[nt++] = best ? 0x80000000u | ((best - 3) << 16) | (dist - 1) : lit;
+		i += best ? best : 1u;
+	}
+	// frequencies: a pass of its own over the tokens, the same few instructions for a literal and a match
+	for (uint32_t t = 0; t < nt; ++t) {
+		const uint32_t x = tok[t];
+		const bool m = (x & 0x80000000u) != 0;
+		uint32_t s, d, eb, ev;
+		df_len_code(m ? ((x >> 16) & 0xff) + 3 : 3u, s, eb, ev);
+		df_dist_code(m ? (x & 0xffff) + 1 : 1u, d, eb, ev);
+		uint16_t &c1 = lf[m ? s : x];
+		if (c1 != 0xffff) ++c1;                                               // (a block holds at most 65280 symbols)
+		if (m && df[d] != 0xffff) ++df[d];
 	}
 	lf[256] = 1;                                                               // end of block
 	uint8_t *ll = fast + df_fast_freq_at(hbits) + 640, *dl = ll + kDfLit;
