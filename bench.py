@@ -561,7 +561,7 @@ def main():
                                  "ksw2_extd2_sse / htslib sam_parse1, compiled from the reference tree): `value` = the reference's kt_for over align_read_pair (incl. output_BAM) at -t %d, "
                                  "value_1_thread the same at -t 1; port_value = oracle/aln_oracle on %d pairs" % (n_cpu, nt, n_port)}
         # which term of the algorithmic bytes each timed kernel owns
-        groups = {"k_prep": ["k_prep"], "k_seed": ["k_seed"], "k_chain": ["k_chain", "k_chain_select", "k_chain_small"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
+        groups = {"k_prep": ["k_prep", "k_prep_pair", "k_prep_mate1"], "k_seed": ["k_seed"], "k_chain": ["k_chain", "k_chain_select", "k_chain_small"], "k_walk+k_dp_fetch": ["k_walk", "k_dp_fetch"],
                   "k_assemble+k_finalize_pair": ["k_assemble", "k_finalize_pair"], "extd2_*": [k for k in kern if k.startswith("extd2_")]}
         group_of = {k: g for g, names in groups.items() for k in names}
         launches = max(1, kern[dom]["launches"])
