@@ -1731,7 +1731,7 @@ struct GpuBE {
 		// beside its second launch, a thread per alignment chasing records and direction bytes through memory with the SIMDs idle (beside
 		// the sweep they took 1.1 ms for 0.3 ms of work and cost it 0.09 ms; the phase as a whole is the same 1.93 ms either way).
 		const bool fan = !timing && n_other + (team.T.n_classes ? 1 : 0) > 1 && side_streams();
-		int used = 0;
+		int used = 0, flip = 0;
 		bool side2_forked = false;
 		B.idx = plan_idx.as<int32_t>();
 		if (team.T.n_classes) {
@@ -1757,13 +1757,22 @@ struct GpuBE {
 					}
 					++used;
 				} else {
-					// beside the team kernel's finish launch: the two largest classes each on a side stream of their own, every other launch one
-					// after the other on a third -- together they are shorter than one of the large ones.  Dealt round-robin over four side streams
-					// the short ones waited behind the long ones for a hardware queue and ran after the finish launch, 0.12 ms of the step
-					// (profiles/r04f_step_timeline.txt)
-					const int k = used < 2 ? used : 2;
-					if (used <= 2) PSVR_HIP(hipStreamWaitEvent(side[k], ev_fork, 0));
-					s2 = side[k], ++used;
+					// beside the team kernel's finish launch: TWO side streams (a third one's launches waited for a hardware queue until one of
+					// the others was through, profiles/r04p_step_timeline.txt), and every launch cut in two halves, one per stream -- whole
+					// launches dealt out left one stream with the two large classes' 0.28 ms each and the small ones behind them
+					if (used == 0) { PSVR_HIP(hipStreamWaitEvent(side[0], ev_fork, 0)); PSVR_HIP(hipStreamWaitEvent(side[1], ev_fork, 0)); used = 2; }
+					const long long unit = 64;
+					long long half = (L.count / 2 + unit - 1) / unit * unit;
+					if (half > L.count) half = L.count;
+					t0(dp_kind_name(L.kind, 0));
+					B.idx = plan_idx.as<int32_t>() + L.first;
+					if (half > 0) dp_launch_kind(L.kind, 0, (unsigned)half, L.lds, side[flip], B, dpP);
+					B.idx = plan_idx.as<int32_t>() + L.first + half;
+					if (L.count - half > 0) dp_launch_kind(L.kind, 0, (unsigned)(L.count - half), L.lds, side[flip ^ 1], B, dpP);
+					flip ^= 1;
+					t1();
+					PSVR_HIP(hipGetLastError());
+					continue;
 				}
 			}
 			B.idx = plan_idx.as<int32_t>() + L.first;
@@ -1773,7 +1782,7 @@ struct GpuBE {
 			PSVR_HIP(hipGetLastError());
 		}
 		if (!team.T.n_classes && used > 2) used = side2_forked ? 3 : 2;   // (the side streams that were used)
-		if (team.T.n_classes && used > 3) used = 3;
+
 		for (int k = 0; k < kSide && k < used; ++k) PSVR_HIP(hipEventRecord(ev_join[k], side[k]));
 		B.idx = plan_idx.as<int32_t>();
 		if (team.T.n_classes && fan) { team.launch_finish(stream, B, dpP, dp_lean); PSVR_HIP(hipGetLastError()); }
