@@ -21,6 +21,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include "worker_pool.h"
 #ifdef PSVR_BGZF_ON_DEVICE                            /* (the CLI, which links the engine library: psvr_bgzf_compress) */
 #include "../../include/psvr_engine.h"
 #endif
@@ -41,6 +42,7 @@ typedef std::vector<uint8_t, NoInitAlloc<uint8_t>> Bytes;
 class BgzfWriter {
 	FILE *f_ = nullptr;
 	std::vector<uint8_t> buf_;
+	std::vector<uint8_t> out_;                    // compressed blocks of a flush
 	static const size_t kBlock = 0xff00;      // uncompressed bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
 	static const size_t kOut = 0x10000 + 64;
 	bool ok_ = true;
@@ -90,7 +92,8 @@ private:
 			device_ = -1;
 		}
 #endif
-		std::vector<uint8_t> out(nb * kOut);
+		if (out_.size() < nb * kOut) out_.resize(nb * kOut);      // (kept across calls: a fresh vector was 0.8 GB of zeroing per 1 M pairs)
+		std::vector<uint8_t> &out = out_;
 		std::vector<size_t> len(nb, 0);
 		std::atomic<size_t> next(0);
 		auto work = [&]() {
@@ -100,10 +103,7 @@ private:
 			}
 		};
 		const int nt = threads_ < 1 ? 1 : (size_t)threads_ > nb ? (int)nb : threads_;
-		std::vector<std::thread> th;
-		for (int t = 1; t < nt; ++t) th.emplace_back(work);
-		work();
-		for (std::thread &t : th) t.join();
+		thread_pool().run(nt, [&](int) { work(); });
 		for (size_t b = 0; b < nb; ++b) {
 			if (!len[b] || fwrite(out.data() + b * kOut, 1, len[b], f_) != len[b]) ok_ = false;
 		}
@@ -169,6 +169,8 @@ inline int nt16_code(char ch)
 	return q ? (int)(q - nt16) : 15;
 }
 inline char nt16_char(char ch) { return "=ACMGRSVTWYHKDBN"[nt16_code(ch)]; }
+struct Nt16Table { uint8_t code[256]; Nt16Table() { for (int c = 0; c < 256; ++c) code[c] = (uint8_t)nt16_code((char)c); } };
+inline const uint8_t *nt16_table() { static const Nt16Table t; return t.code; }        // (nt16_code per base is a strchr per base)
 
 struct BamRef { std::string name; uint32_t len; };
 
@@ -305,12 +307,17 @@ public:
 		rec_.insert(rec_.end(), s.qname.begin(), s.qname.end());
 		rec_.push_back(0);
 		for (uint32_t c : cig) put32(rec_, c);
-		for (uint32_t i = 0; i < l_seq; i += 2) {
-			const int hi = nt16_code(s.seq[i]), lo = i + 1 < l_seq ? nt16_code(s.seq[i + 1]) : 0;
-			rec_.push_back((uint8_t)(hi << 4 | lo));
+		if (l_seq) {
+			const uint8_t *T = nt16_table();
+			const size_t at = rec_.size(), nb = (l_seq + 1) / 2;
+			rec_.resize(at + nb + l_seq);
+			uint8_t *q = &rec_[at];
+			const uint8_t *sq = (const uint8_t *)s.seq.data();
+			for (uint32_t i = 0; i + 1 < l_seq; i += 2) *q++ = (uint8_t)(T[sq[i]] << 4 | T[sq[i + 1]]);
+			if (l_seq & 1) *q++ = (uint8_t)(T[sq[l_seq - 1]] << 4);
+			if (s.qual.empty() || s.qual == "*" || s.qual.size() != l_seq) memset(q, 0xff, l_seq);
+			else for (uint32_t i = 0; i < l_seq; ++i) q[i] = (uint8_t)(s.qual[i] - 33);
 		}
-		if (s.qual.empty() || s.qual == "*" || s.qual.size() != l_seq) rec_.insert(rec_.end(), l_seq, 0xff);
-		else for (char ch : s.qual) rec_.push_back((uint8_t)(ch - 33));
 		if (!put_tags(rec_, s.tags)) { rec_.resize(base); return false; }
 		const uint32_t bs = (uint32_t)(rec_.size() - base) - 4;
 		for (int i = 0; i < 4; ++i) rec_[base + i] = (uint8_t)(bs >> (8 * i));

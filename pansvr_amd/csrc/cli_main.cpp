@@ -389,10 +389,7 @@ int main(int argc, char **argv)
 					}
 				}
 			};
-			std::vector<std::thread> th;
-			for (int t = 1; t < o.thread_n && t < nchunk; ++t) th.emplace_back(work);
-			work();
-			for (std::thread &t : th) t.join();
+			thread_pool().run((int)(o.thread_n < nchunk ? o.thread_n : nchunk), [&](int) { work(); });
 			t_format += walltime() - tw;
 			set_state(J, 3);
 		}

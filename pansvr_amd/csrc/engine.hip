@@ -196,6 +196,9 @@ __device__ __forceinline__ void block_list_append2(int32_t *list, unsigned int *
 	if (e1 >= 0) list[at] = e1;
 }
 
+#ifndef PSVR_PREP_BITS
+#define PSVR_PREP_BITS 11            // log2 of the bits of a lane's STR-screen set, reads of up to 160 bases
+#endif
 template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work, long long n, int bits_log2)
 {
@@ -226,6 +229,9 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		const bool unm = o_unm != 0 || o_chr > 24u;
 		const bool act = !(L > 32 * W || L < kLenKmer) && !(!unm && o_score == (uint32_t)(L * c.par.match));
 		c.read_l[read] = L, c.unmapped[read] = unm, c.has_mem[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
+#if defined(PSVR_DIAG_PREP) && PSVR_DIAG_PREP == 3     /* timing experiment: the Strand records are not reset (results are wrong) */
+		if (L < 0)
+#endif
 		{
 			uint4 *st = (uint4 *)(c.strand + read * 2);                       // two Strand records: counts and offsets 0, both hashes the FNV basis
 			const uint32_t hl = (uint32_t)1469598103934665603ULL, hh = (uint32_t)(1469598103934665603ULL >> 32);
@@ -316,6 +322,9 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		for (int w = 0; w < W + 2; ++w) if (w < c.wmax) w0[w] = w < W ? F[w < W ? w : 0] : 0;
 		// ---- reverse strand: base j is 3 - base (L-1-j).  Shift the forward string right until it ends at the array's end,
 		// reverse the 2-bit groups of the whole array, complement, clear what lies behind base L-1.
+#if defined(PSVR_DIAG_PREP) && PSVR_DIAG_PREP == 2     /* timing experiment: no reverse strand (results are wrong) */
+		if (L < 0)
+#endif
 		{
 			uint64_t G[W];
 #pragma unroll
@@ -349,7 +358,12 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		// 16 such events prove the read is not STR.  The few reads left (is_str = 2) get the exact count in k_str_detect.
 		const int kn = L - kLenKmer + 1;
 		int verdict = 2;
+#if defined(PSVR_DIAG_PREP) && PSVR_DIAG_PREP == 1     /* timing experiment: no STR screen (results are wrong) */
+		if (kn >= 15) verdict = 0;
+		if (false) {
+#else
 		if (kn >= 15) {
+#endif
 			uint32_t klo = 0, khi = 0;
 			int taken = 0;
 #pragma unroll
@@ -1425,7 +1439,7 @@ struct GpuBE {
 				note(hipMemsetAsync(redo.p, 0, 4, stream));
 				hipLaunchKernelGGL(k_prep_mate1, dim3(grid_for(n)), dim3(kBlock), 0, stream, c, w, n, redo.as<int32_t>() + 4, (unsigned int *)redo.p);
 				launch_prep_wave(c, (const int32_t *)(redo.as<int32_t>() + 4), 0, 1, (const unsigned int *)redo.p, 64);
-			} else if (c.lmax <= 160) hipLaunchKernelGGL((k_prep_pair<5, 256>), dim3(grid_for(n, 256)), dim3(256), (size_t)4 * 64 * 256, stream, c, w, n, 11);
+			} else if (c.lmax <= 160) hipLaunchKernelGGL((k_prep_pair<5, 256>), dim3(grid_for(n, 256)), dim3(256), (size_t)4 * 64 * (1 << (PSVR_PREP_BITS - 3)), stream, c, w, n, PSVR_PREP_BITS);
 			else hipLaunchKernelGGL((k_prep_pair<9, 128>), dim3(grid_for(n, 128)), dim3(128), (size_t)2 * 64 * 512, stream, c, w, n, 12);
 			t1();
 			note(hipGetLastError());
@@ -1757,22 +1771,14 @@ struct GpuBE {
 					}
 					++used;
 				} else {
-					// beside the team kernel's finish launch: TWO side streams (a third one's launches waited for a hardware queue until one of
-					// the others was through, profiles/r04p_step_timeline.txt), and every launch cut in two halves, one per stream -- whole
-					// launches dealt out left one stream with the two large classes' 0.28 ms each and the small ones behind them
+					// beside the team kernel's finish launch: two side streams, the launches dealt to them in turn (largest classes first).  The finish
+					// launch's wavefronts hold 128 KB of a CU's LDS (4 KB each for the traceback window) and these kernels want up to 40 KB a
+					// block: while it runs they get a block in now and then, whatever the stream -- the two largest run beside it, the short ones
+					// behind them two at a time.  (A third side stream's launches waited for a hardware queue and ran one after the other
+					// behind everything, profiles/r04p_step_timeline.txt; every launch cut in two halves, one per stream: the large classes'
+					// halves ran beside each other as slowly as the whole had, and the short ones queued behind them, +0.07 ms.)
 					if (used == 0) { PSVR_HIP(hipStreamWaitEvent(side[0], ev_fork, 0)); PSVR_HIP(hipStreamWaitEvent(side[1], ev_fork, 0)); used = 2; }
-					const long long unit = 64;
-					long long half = (L.count / 2 + unit - 1) / unit * unit;
-					if (half > L.count) half = L.count;
-					t0(dp_kind_name(L.kind, 0));
-					B.idx = plan_idx.as<int32_t>() + L.first;
-					if (half > 0) dp_launch_kind(L.kind, 0, (unsigned)half, L.lds, side[flip], B, dpP);
-					B.idx = plan_idx.as<int32_t>() + L.first + half;
-					if (L.count - half > 0) dp_launch_kind(L.kind, 0, (unsigned)(L.count - half), L.lds, side[flip ^ 1], B, dpP);
-					flip ^= 1;
-					t1();
-					PSVR_HIP(hipGetLastError());
-					continue;
+					s2 = side[flip], flip ^= 1;
 				}
 			}
 			B.idx = plan_idx.as<int32_t>() + L.first;

@@ -97,6 +97,7 @@ struct SharedRand {
 		n.store(k, std::memory_order_release);
 	}
 	int32_t at(long long k) const { return blk[k >> kLog][k & kMask]; }          // k below what the caller has ensure()d
+	void prefetch(long long k) const { if (k >= 0 && k < n.load(std::memory_order_relaxed)) __builtin_prefetch(blk[k >> kLog] + (k & kMask)); }
 	// the draws [from, from + cnt) handed to `put(dst offset, source, entries)` block by block
 	template <class F> void pieces(long long from, long long cnt, F &&put) const
 	{
@@ -777,6 +778,9 @@ template <class BE> struct EngineCore {
 				for (size_t i = 0; i < listed.size(); ++i) {
 					const int32_t s = listed[i];
 					const long long t = grand_pos + pre[i] + acc;
+					// (the draws a pair further down will look at: its offset moves by a few entries at most until the walk is there -- each
+					// pair's look-up is otherwise a miss to memory, the list being spread over the whole batch's draws)
+					if (i + 8 < listed.size()) grand.prefetch(grand_pos + pre[i + 8] + acc);
 					int32_t D = cur_tot[i];
 					const int32_t sidx = l_si[i];
 					if (sidx >= 0 && is_special[(size_t)sidx] == 2) {

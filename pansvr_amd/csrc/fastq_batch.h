@@ -22,8 +22,10 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #include "../../include/psvr_engine.h"
+#include "worker_pool.h"
 
 namespace psvr {
 
@@ -32,10 +34,8 @@ template <class F> inline void parallel_ranges(long long n, int threads, F &&fn)
 	const int nt = threads < 1 ? 1 : threads;
 	if (n <= 0) return;
 	const long long per = (n + nt - 1) / nt;
-	std::vector<std::thread> th;
-	for (int t = 1; t < nt; ++t) if (t * per < n) th.emplace_back([&fn, t, per, n]() { fn(t * per, (t + 1) * per < n ? (t + 1) * per : n); });
-	fn(0, per < n ? per : n);
-	for (std::thread &t : th) t.join();
+	const int use = (int)((n + per - 1) / per);
+	thread_pool().run(use, [&](int t) { fn(t * per, (t + 1) * per < n ? (t + 1) * per : n); });
 }
 
 // page-locked when the engine library can provide it (psvr_host_alloc), pageable otherwise; kept by its owner across batches
@@ -104,6 +104,21 @@ inline psvr_ori_t parse_ori_span(const char *cm, int L, int32_t cut[10])
 	o.direction = (nt > 9 && te[9] - ts[9] >= 1 && ts[9][0] == 'F') ? 1 : 0;
 	o.unmapped = (nt > 9 && te[9] - ts[9] >= 2 && ts[9][1] == 'Y') ? 1 : 0;
 	return o;
+}
+// the separators alone (what the writer of a record needs of parse_ori_span)
+inline void ori_cuts(const char *cm, int L, int32_t cut[10])
+{
+	const char *p = cm, *e = cm + L;
+	int nt = 0;
+	for (; nt < 10; ++nt) {
+		while (p < e && *p == '_') ++p;
+		if (p >= e) break;
+		const char *q = (const char *)memchr(p, '_', (size_t)(e - p));
+		p = q ? q : e;
+		cut[nt] = p < e ? (int32_t)(p - cm) : -1;
+		if (p < e) ++p;
+	}
+	for (int k = nt; k < 10; ++k) cut[k] = -1;
 }
 // the comment as the reference leaves it after parse_ori_mapping_rst: every separator strtok_r cut becomes ',' except one at
 // the very last position, which stays a NUL and ends the C string there
@@ -277,10 +292,7 @@ class FastqReader {
 			const char *p = base + a, *e = base + b;
 			while (p < e && (p = (const char *)memchr(p, '\n', (size_t)(e - p)))) { ++p; v.push_back((uint64_t)(p - base)); }
 		};
-		std::vector<std::thread> th;
-		for (int t = 1; t < nt; ++t) if ((size_t)t * per < span) th.emplace_back(scan, t);
-		scan(0);
-		for (std::thread &t : th) t.join();
+		thread_pool().run(per ? (int)((span + per - 1) / per) : 0, scan);
 		for (auto &v : part) ls.insert(ls.end(), v.begin(), v.end());
 	}
 

@@ -816,8 +816,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PSVR_TEAM_WA
 // dependent loads (a record per anti-diagonal, a direction byte per CIGAR step); inside the sweep kernel, one lane per team at three
 // wavefronts per SIMD, they took 0.39 of 2.21 ms on the DP micro-benchmark (profiles/r03e).  Thread t of block b serves team t % PB of the sweep's
 // block (b * 64 + t) / PB and finds that wavefront's scratch the way it did.
+#ifndef PSVR_FINISH_WAVES
+#define PSVR_FINISH_WAVES 8          // most wavefronts of the finish launch per SIMD (experiments)
+#endif
 template <int LANES, int CPL, int LEAN>
-__global__ __launch_bounds__(64) void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, PSVR_FINISH_WAVES))) void extd2_team_finish_kernel(DpBatch B, DpParams P, TeamPlan T)
 {
 	constexpr int SW = CPL * LANES, PB = 64 / LANES, kWinRows = 8;
 	__shared__ uint32_t win[kWinRows * (CPL / 4) * 64];              // the traceback's window of direction bytes: [row][dword][thread]

@@ -9,6 +9,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <atomic>
 #include <string>
 #include <vector>
@@ -103,14 +106,20 @@ struct RawOut {
 	void put(const char *s, size_t n) { memcpy(p, s, n), p += n; }
 	void put(const std::string &s) { put(s.data(), s.size()); }
 	void ch(char c) { *p++ = (uint8_t)c; }
-	void num(long long x)
+	void num(long long x)                              // %lld
 	{
+		static const char d2[] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+		unsigned long long u = (unsigned long long)x;
+		if (x < 0) *p++ = '-', u = 0ull - u;
+		// (flags, qualities, scores, insert sizes: mostly one to three digits)
+		if (u < 10) { *p++ = (uint8_t)('0' + u); return; }
+		if (u < 100) { p[0] = (uint8_t)d2[2 * u], p[1] = (uint8_t)d2[2 * u + 1], p += 2; return; }
+		if (u < 1000) { const unsigned h = (unsigned)u / 100, r = (unsigned)u - 100 * h; p[0] = (uint8_t)('0' + h), p[1] = (uint8_t)d2[2 * r], p[2] = (uint8_t)d2[2 * r + 1], p += 3; return; }
 		char b[24];
 		int n = 24;
-		unsigned long long u = x < 0 ? 0ull - (unsigned long long)x : (unsigned long long)x;
-		do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
-		if (x < 0) b[--n] = '-';
-		put(b + n, (size_t)(24 - n));
+		while (u >= 100) { const unsigned r = (unsigned)(u % 100); u /= 100; b[--n] = d2[2 * r + 1], b[--n] = d2[2 * r]; }
+		if (u >= 10) b[--n] = d2[2 * u + 1], b[--n] = d2[2 * u]; else b[--n] = (char)('0' + u);
+		for (; n < 24; ++n) *p++ = (uint8_t)b[n];
 	}
 	void tag_int(const char *tag5, long long x) { ch('\t'), put(tag5, 5), num(x); }
 	// ---- BAM (little-endian binary)
@@ -146,16 +155,57 @@ struct SeqTables {
 	}
 };
 inline const SeqTables &seq_tables() { static const SeqTables t; return t; }
+#if defined(__SSE2__)
+// sixteen bytes at a time where every one of them is A, C, G, T or N (what the table maps to itself / to its complement); a block with
+// anything else goes through the tables
+struct Seq16 {
+	__m128i a, c, g, t, n;
+	Seq16() : a(_mm_set1_epi8('A')), c(_mm_set1_epi8('C')), g(_mm_set1_epi8('G')), t(_mm_set1_epi8('T')), n(_mm_set1_epi8('N')) {}
+	static __m128i reversed(__m128i v)
+	{
+		v = _mm_shuffle_epi32(v, _MM_SHUFFLE(0, 1, 2, 3));
+		v = _mm_shufflelo_epi16(v, _MM_SHUFFLE(2, 3, 0, 1)), v = _mm_shufflehi_epi16(v, _MM_SHUFFLE(2, 3, 0, 1));
+		return _mm_or_si128(_mm_slli_epi16(v, 8), _mm_srli_epi16(v, 8));
+	}
+	// all sixteen plain?  *comp = their complements
+	bool plain(__m128i v, __m128i *comp) const
+	{
+		const __m128i ia = _mm_cmpeq_epi8(v, a), ic = _mm_cmpeq_epi8(v, c), ig = _mm_cmpeq_epi8(v, g), it = _mm_cmpeq_epi8(v, t), in = _mm_cmpeq_epi8(v, n);
+		if (_mm_movemask_epi8(_mm_or_si128(_mm_or_si128(_mm_or_si128(ia, ic), _mm_or_si128(ig, it)), in)) != 0xffff) return false;
+		if (comp) *comp = _mm_or_si128(_mm_or_si128(_mm_or_si128(_mm_and_si128(ia, t), _mm_and_si128(ic, g)), _mm_or_si128(_mm_and_si128(ig, c), _mm_and_si128(it, a))), _mm_and_si128(in, n));
+		return true;
+	}
+};
+#endif
 inline void put_seq_qual(RawOut &o, const char *t, const char *qt, int n, bool reverse)
 {
 	const SeqTables &T = seq_tables();
 	uint8_t *sq = o.p, *ql = sq + n + 1;
+	int i = 0;
 	if (reverse) {
-		for (int i = 0; i < n; ++i) sq[i] = T.rc[(uint8_t)t[n - 1 - i]];      // A C G T N only: already what the 4-bit code gives back
-		for (int i = 0; i < n; ++i) ql[i] = (uint8_t)qt[n - 1 - i];
+#if defined(__SSE2__)
+		const Seq16 K;
+		for (; i + 16 <= n; i += 16) {
+			const __m128i v = _mm_loadu_si128((const __m128i *)(t + n - 16 - i));
+			__m128i comp;
+			if (K.plain(v, &comp)) _mm_storeu_si128((__m128i *)(sq + i), Seq16::reversed(comp));
+			else for (int j = i; j < i + 16; ++j) sq[j] = T.rc[(uint8_t)t[n - 1 - j]];
+			_mm_storeu_si128((__m128i *)(ql + i), Seq16::reversed(_mm_loadu_si128((const __m128i *)(qt + n - 16 - i))));
+		}
+#endif
+		for (int j = i; j < n; ++j) sq[j] = T.rc[(uint8_t)t[n - 1 - j]];      // A C G T N only: already what the 4-bit code gives back
+		for (int j = i; j < n; ++j) ql[j] = (uint8_t)qt[n - 1 - j];
 		if (!(n & 1) && n >= 2) ql[n / 2 - 1] = (uint8_t)qt[n / 2 - 1], ql[n / 2] = (uint8_t)qt[n / 2];   // loop bound len/2 + 1: the middle pair is swapped back
 	} else {
-		for (int i = 0; i < n; ++i) sq[i] = T.n16[(uint8_t)t[i]];
+#if defined(__SSE2__)
+		const Seq16 K;
+		for (; i + 16 <= n; i += 16) {
+			const __m128i v = _mm_loadu_si128((const __m128i *)(t + i));
+			if (K.plain(v, nullptr)) _mm_storeu_si128((__m128i *)(sq + i), v);
+			else for (int j = i; j < i + 16; ++j) sq[j] = T.n16[(uint8_t)t[j]];
+		}
+#endif
+		for (; i < n; ++i) sq[i] = T.n16[(uint8_t)t[i]];
 		memcpy(ql, qt, (size_t)n);
 	}
 	sq[n] = '\t';
@@ -199,6 +249,12 @@ private:
 	static bool acceptable(const std::string &qname, const std::string &cigar, const std::string &seq, const std::string &qual)
 	{
 		if (qname.empty() || qname.size() > 254) return false;                    // "query name too long"
+		if (!acceptable_cigar(cigar)) return false;
+		if (seq != "*" && qual != "*" && seq.size() != qual.size()) return false;  // "SEQ and QUAL are of different length"
+		return true;
+	}
+	static bool acceptable_cigar(const std::string &cigar)
+	{
 		if (!cigar.empty() && cigar != "*") {
 			bool digit = false;
 			for (char ch : cigar) {
@@ -209,7 +265,6 @@ private:
 			}
 			if (digit) return false;
 		}
-		if (seq != "*" && qual != "*" && seq.size() != qual.size()) return false;  // "SEQ and QUAL are of different length"
 		return true;
 	}
 	// one record after the sam_parse1 -> sam_format1 round trip
@@ -274,6 +329,57 @@ private:
 		for (int i = 0; i < tl - 5; i++) if (tags[(size_t)i] == '_' && tags[(size_t)i + 3] == ':' && tags[(size_t)i + 5] == ':') tags[(size_t)i] = '\t';
 		if (tl > 0) tags.resize((size_t)tl - 1);
 		r->tags = tags;
+		return true;
+	}
+	// the same from the comment's span without the C library's scanners (two sscanf and three strstr per read were most of what the
+	// second file's records cost).  Numbers that are plain runs of one to nine digits (a '-' in front where %d takes one) are read here;
+	// anything else -- white space, a '+', more digits -- is left to the function above, so both give the same record.
+	static bool parse_ori_record(const char *ct, int cn, OriRecord *r)
+	{
+		const char *c = ct, *e = ct + strnlen(ct, (size_t)cn);
+		auto slow = [&]() { return parse_ori_record(std::string(ct, (size_t)cn), r); };
+		auto find = [&](const char *from, const char *lit, size_t n) { return from <= e ? (const char *)memmem(from, (size_t)(e - from), lit, n) : nullptr; };
+		// 0: not a plain number (caller falls back); 1: read
+		auto number = [&](const char *&p, bool sign, long long *v) {
+			const char *q = p;
+			bool neg = false;
+			if (sign && q < e && *q == '-') neg = true, ++q;
+			const char *d0 = q;
+			long long x = 0;
+			while (q < e && *q >= '0' && *q <= '9' && q - d0 < 10) x = x * 10 + (*q - '0'), ++q;
+			if (q == d0 || q - d0 > 9) return 0;
+			*v = neg ? -x : x, p = q;
+			return 1;
+		};
+		const char *f = find(c, "FLAG_", 5);
+		if (!f) return false;
+		const char *p = f + 5;
+		long long fl, q, a, b, d;
+		if (!number(p, false, &fl) || p >= e || *p != '_') return slow();
+		++p;
+		if (!number(p, false, &q)) return slow();
+		r->flag = (int)fl, r->mapq = (int)q;
+		const char *cg = find(f + 5, "CIGAR_", 6);
+		if (!cg) return false;
+		cg += 6;
+		const char *ce = cg <= e ? (const char *)memchr(cg, '_', (size_t)(e - cg)) : nullptr;
+		if (!ce) return false;
+		r->cigar.assign(cg, (size_t)(ce - cg));
+		if (e - ce < 6) return false;
+		p = ce + 1 + 5;                                          // skips "MATE_"
+		if (!number(p, true, &a) || p >= e || *p != '_') return slow();
+		++p;
+		if (!number(p, true, &b) || p >= e || *p != '_') return slow();
+		++p;
+		if (!number(p, true, &d)) return slow();
+		r->mate_chr = (int)a, r->mate_pos = (int)b + 1, r->isize = (int)d;
+		const char *tg = find(ce + 1 + 5, "TAG_", 4);
+		if (!tg) return false;
+		r->tags.assign(tg + 4, (size_t)(e - (tg + 4)));
+		std::string &tags = r->tags;
+		const int tl = (int)tags.size();
+		for (int i = 0; i < tl - 5; i++) if (tags[(size_t)i] == '_' && tags[(size_t)i + 3] == ':' && tags[(size_t)i + 5] == ':') tags[(size_t)i] = '\t';
+		if (tl > 0) tags.resize((size_t)tl - 1);
 		return true;
 	}
 	// bam_has_clip_or_unmapped_ori (rr.cpp:721-733) on the CIGAR text
@@ -375,7 +481,7 @@ public:
 					uint8_t *at = o.p;
 					memcpy(at, ct, (size_t)cn);
 					int32_t cut[10];
-					parse_ori_span(ct, cn, cut);
+					ori_cuts(ct, cn, cut);
 					size_t len = (size_t)cn;
 					for (int q = 0; q < 10; ++q) {
 						if (cut[q] < 0) continue;
@@ -442,17 +548,44 @@ public:
 					}
 					// SEQ: two 4-bit codes per byte; QUAL: phred values (the reverse strand through getReverseStr_char / getReverseStr_qual_char)
 					const bool rev = direction == 0;
-					for (int i = 0; i < read_l; i += 2) {
+					int i = 0;
+#if defined(__SSE2__)
+					{
+						// sixteen plain bases (A C G T N) -> eight bytes of 4-bit codes; a block with anything else through the tables
+						const Seq16 K;
+						const __m128i k1 = _mm_set1_epi8(1), k2 = _mm_set1_epi8(2), k4 = _mm_set1_epi8(4), k8 = _mm_set1_epi8(8), k15 = _mm_set1_epi8(15), lo8 = _mm_set1_epi16(0x00ff);
+						for (; i + 16 <= read_l; i += 16) {
+							__m128i v = _mm_loadu_si128((const __m128i *)(rev ? t + read_l - 16 - i : t + i));
+							if (rev) v = Seq16::reversed(v);
+							const __m128i ia = _mm_cmpeq_epi8(v, K.a), ic = _mm_cmpeq_epi8(v, K.c), ig = _mm_cmpeq_epi8(v, K.g), it = _mm_cmpeq_epi8(v, K.t), in = _mm_cmpeq_epi8(v, K.n);
+							if (_mm_movemask_epi8(_mm_or_si128(_mm_or_si128(_mm_or_si128(ia, ic), _mm_or_si128(ig, it)), in)) != 0xffff) break;
+							const __m128i code = rev ? _mm_or_si128(_mm_or_si128(_mm_or_si128(_mm_and_si128(ia, k8), _mm_and_si128(ic, k4)), _mm_or_si128(_mm_and_si128(ig, k2), _mm_and_si128(it, k1))), _mm_and_si128(in, k15))
+							                         : _mm_or_si128(_mm_or_si128(_mm_or_si128(_mm_and_si128(ia, k1), _mm_and_si128(ic, k2)), _mm_or_si128(_mm_and_si128(ig, k4), _mm_and_si128(it, k8))), _mm_and_si128(in, k15));
+							const __m128i w = _mm_or_si128(_mm_slli_epi16(_mm_and_si128(code, lo8), 4), _mm_srli_epi16(code, 8));
+							_mm_storel_epi64((__m128i *)o.p, _mm_packus_epi16(w, w));
+							o.p += 8;
+						}
+					}
+#endif
+					for (; i < read_l; i += 2) {
 						const unsigned hi = rev ? T.rc16[(uint8_t)t[read_l - 1 - i]] : T.c16[(uint8_t)t[i]];
 						const unsigned lo = i + 1 < read_l ? (rev ? T.rc16[(uint8_t)t[read_l - 2 - i]] : T.c16[(uint8_t)t[i + 1]]) : 0u;
 						o.u8(hi << 4 | lo);
 					}
 					{
 						uint8_t *ql = o.p;
+						int j = 0;
+#if defined(__SSE2__)
+						const __m128i k33 = _mm_set1_epi8(33);
+						for (; j + 16 <= read_l; j += 16) {
+							const __m128i v = _mm_loadu_si128((const __m128i *)(rev ? qt + read_l - 16 - j : qt + j));
+							_mm_storeu_si128((__m128i *)(ql + j), _mm_sub_epi8(rev ? Seq16::reversed(v) : v, k33));
+						}
+#endif
 						if (rev) {
-							for (int i = 0; i < read_l; ++i) ql[i] = (uint8_t)(qt[read_l - 1 - i] - 33);
+							for (; j < read_l; ++j) ql[j] = (uint8_t)(qt[read_l - 1 - j] - 33);
 							if (!(read_l & 1) && read_l >= 2) ql[read_l / 2 - 1] = (uint8_t)(qt[read_l / 2 - 1] - 33), ql[read_l / 2] = (uint8_t)(qt[read_l / 2] - 33);
-						} else for (int i = 0; i < read_l; ++i) ql[i] = (uint8_t)(qt[i] - 33);
+						} else for (; j < read_l; ++j) ql[j] = (uint8_t)(qt[j] - 33);
 						o.p += read_l;
 					}
 					o.bam_int("AS", (int)align_score), o.bam_int("OS", (int)ori.align_score);
@@ -472,7 +605,7 @@ public:
 						uint8_t *at = o.p;
 						memcpy(at, ct, (size_t)cn);
 						int32_t cut[10];
-						parse_ori_span(ct, cn, cut);
+						ori_cuts(ct, cn, cut);
 						size_t len = (size_t)cn;
 						for (int q = 0; q < 10; ++q) {
 							if (cut[q] < 0) continue;
@@ -524,9 +657,7 @@ public:
 		const psvr_pair_result_t &pr = V.pairs[p - V.pair0];
 		if (!(pr.max_score <= min_filter_score && B.ori[2 * p].chr_id != -1 && B.ori[2 * p + 1].chr_id != -1)) return;
 		OriRecord orr[2];
-		std::string cm[2];
-		for (int k = 0; k < 2; ++k) { const char *t; int n; B.comment(2 * p + k, t, n); cm[k].assign(t, (size_t)n); }
-		if (!parse_ori_record(cm[0], &orr[0]) || !parse_ori_record(cm[1], &orr[1])) return;
+		for (int k = 0; k < 2; ++k) { const char *t; int n; B.comment(2 * p + k, t, n); if (!parse_ori_record(t, n, &orr[k])) return; }
 		bool proper = pr.proper != 0;
 		for (int k = 0; proper && k < 2; ++k) {
 			const int mx = k == 0 ? pr.max1 : pr.max2;
@@ -552,7 +683,7 @@ public:
 				const uint32_t rb = (ori.ref_bg >= 0x7fffffffu ? 1u : ori.ref_bg) + 1;
 				const int pos = (int)rb, chr_id = ori.chr_id;
 				if (chr_id < 0 || chr_id >= (int)H->names.size() || pos - 1 < 0) continue;
-				if (!acceptable(std::string(nt, (size_t)nn), orr[k].cigar, std::string("x"), std::string("x")) || qn != n) { drop("@ori_bam_sam_parse1 ERROR"); continue; }
+				if (nn <= 0 || nn > 254 || !acceptable_cigar(orr[k].cigar) || qn != n) { drop("@ori_bam_sam_parse1 ERROR"); continue; }
 				const int mp = orr[k].mate_pos, mc = orr[k].mate_chr;
 				const bool mate_named = mc >= 0 && mc < (int)H->names.size();
 				RawOut o(dst, (size_t)nn + 2 * (size_t)n + orr[k].cigar.size() + orr[k].tags.size() + H->names[(size_t)chr_id].size() + (mate_named ? H->names[(size_t)mc].size() : 0) + 256);

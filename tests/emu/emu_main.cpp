@@ -10,6 +10,7 @@
 // results, so the SAM text can be compared with the reference's own files without a GPU.
 //
 // Usage: emu_aln <fixture_index_dir> <reads.fq> <header.sam> [--trace] [--batch N] [--sam FILE --ori-sam FILE] [--threads N]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -225,6 +226,7 @@ int main(int argc, char **argv)
 	int threads = 1;
 	const char *sam_fn = nullptr, *ori_fn = nullptr, *bam_fn = nullptr;
 	bool bam_text = false;
+	int format_reps = 0;
 	long long pos[3] = {-1, -1, -1}, from[3] = {-1, -1, -1};
 	for (int i = 4; i < argc; ++i) {
 		if (!strcmp(argv[i], "--trace")) trace = true;
@@ -238,6 +240,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--sam") && i + 1 < argc) sam_fn = argv[++i];
 		else if (!strcmp(argv[i], "--ori-sam") && i + 1 < argc) ori_fn = argv[++i];
 		else if (!strcmp(argv[i], "--bam-records") && i + 1 < argc) bam_fn = argv[++i];      // the main file's records as BAM bytes (uncompressed, no header): direct encoder
+		else if (!strcmp(argv[i], "--format-reps") && i + 1 < argc) format_reps = atoi(argv[++i]);   // host stages timed on one thread: the batch formatted this many times (stderr)
 		else if (!strcmp(argv[i], "--bam-via-text")) bam_text = true;                          // ... through the SAM-line strings and BamWriter::encode instead
 		else if (!strcmp(argv[i], "--stream-pos") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &pos[0], &pos[1], &pos[2]);       // start of this shard in the three draw streams
 		else if (!strcmp(argv[i], "--rebase-from") && i + 1 < argc) sscanf(argv[++i], "%lld,%lld,%lld", &from[0], &from[1], &from[2]);  // run there first, then rebase to --stream-pos
@@ -314,6 +317,23 @@ int main(int argc, char **argv)
 			ResultView V;
 			V.hdr = core.c.rh, V.pairs = core.c.pres, V.cands = core.c.cand, V.cig = core.c.cig.base;
 			Bytes a, b;
+			if (format_reps > 0) {
+				auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+				for (int mode = 0; mode < 2; ++mode) {
+					SamEmitter e2 = em;
+					e2.as_bam = mode == 1;
+					size_t bytes = 0;
+					const double t0 = now();
+					for (int rep = 0; rep < format_reps; ++rep) {
+						a.clear(), b.clear();
+						for (long long p = 0; p < fb.n_pairs(); ++p) e2.main_pair(fb, V, p, a), e2.ori_pair(fb, V, p, b);
+						bytes = a.size() + b.size();
+					}
+					const double dt = (now() - t0) / format_reps;
+					fprintf(stderr, "[emu] format (%s): %.1f ns per read, %.2f GB/s of output, %zu bytes\n", mode ? "BAM records" : "SAM text", dt * 1e9 / (2.0 * fb.n_pairs()), bytes / dt / 1e9, bytes);
+				}
+				a.clear(), b.clear();
+			}
 			for (long long p = 0; p < fb.n_pairs(); ++p) em.main_pair(fb, V, p, a), em.ori_pair(fb, V, p, b);
 			fwrite(a.data(), 1, a.size(), fsam), fwrite(b.data(), 1, b.size(), fori);
 			if (fbam) {

@@ -7,7 +7,7 @@ mkdir -p $R/gpu_exp $R/build/exp
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   objs=""
-  for s in engine ksw_host ksw_kernels; do
+  for s in engine ksw_host ksw_kernels bgzf; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $defs -c $R/pansvr_amd/csrc/$s.hip -o $R/build/exp/${s}_$name.o &
     objs="$objs $R/build/exp/${s}_$name.o"
   done
