@@ -643,14 +643,17 @@ def main():
             # SAM text; BAM at zlib's default level (what htslib's "wb" -- the reference's output -- uses); BAM at level 1 (--compress-level 1); BAM with the BGZF blocks
             # compressed on the GPU (--bgzf-device)
             for key, mode, ext in (("sam", ["-S"], "sam"), ("bam", [], "bam"), ("bam_level1", ["--compress-level", "1"], "bam"), ("bam_device", ["--bgzf-device"], "bam")):
+                for fn in ("o." + ext, "p." + ext):      # (a 0.9 GB file opened for writing again is first emptied: 0.1 s of the next run's wall)
+                    if os.path.exists(os.path.join(tmp, fn)):
+                        os.remove(os.path.join(tmp, fn))
                 r = subprocess.run([cli, "aln", "-t", str(nt)] + mode + ["-o", os.path.join(tmp, "o." + ext), "-p", os.path.join(tmp, "p." + ext)] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 if r.returncode != 0:
                     e2e[key] = {"error": r.stderr.decode()[-300:]}
                     continue
                 j = json.loads([l for l in r.stderr.decode().split("\n") if "e2e_json" in l][-1].split("e2e_json ", 1)[1])
                 e2e[key] = {"reads_per_s": round(2 * n_e2e / j["wall_s"], 1), "wall_s": j["wall_s"], "index_load_s": j["index_s"], "read_parse_s": j["read_parse_s"], "engine_s": j["engine_s"],
-                            "format_s": j["format_s"], "write_s": j["write_s"], "batches": j["batches"], "d2h_bytes": j["d2h_bytes"], "out_bytes": os.path.getsize(os.path.join(tmp, "o." + ext))}
-            e2e["note"] = "wall_s = first FASTQ byte to both files closed (four overlapped stages: read+parse | engine | format | write); index_load_s (files -> HBM) is outside it"
+                            "format_s": j["format_s"], "write_s": j["write_s"], "teardown_s": j.get("teardown_s"), "batches": j["batches"], "d2h_bytes": j["d2h_bytes"], "out_bytes": os.path.getsize(os.path.join(tmp, "o." + ext))}
+            e2e["note"] = "wall_s = first FASTQ byte to both files closed (four overlapped stages: read+parse | engine | format | write); index_load_s (files -> HBM) before it and teardown_s (HBM given back) after it are outside it"
     # ---- configs[4] beside it (not `value`): 250 bp reads against edge-2000 anchors, the shape whose DP problems are several hundred
     # anti-diagonals wide, so the wavefront-per-alignment kernels get a timing and a roofline of their own
     cfg5 = None

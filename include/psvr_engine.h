@@ -43,6 +43,10 @@ int psvr_device_count(void);
  * them once with these.  NULL on failure (psvr_last_error says why). */
 void *psvr_host_alloc(size_t bytes);
 void psvr_host_free(void *p);
+/* Optional: sets up the device's queues on a thread of its own and returns at once.  The first streams of a process cost 3 - 14 ms each
+ * and an engine uses four; a caller that has something else to do first (the command: loading the index, src/jlra_aln.cpp:29-57 in the
+ * reference's order of work) calls this before it and finds them ready when it creates its engines.  Nothing depends on it. */
+int psvr_device_warmup(int device, int n_streams);
 
 /* ------------------------------------------------------------------------------------------
  * Seam B2: batched banded DP.  Field-for-field ksw_extz_t (src/kswlib/ksw2.h:26-35); the

@@ -242,6 +242,7 @@ int main(int argc, char **argv)
 	fprintf(stderr, "Begin loading index @%s\n", o.index_dir.c_str());
 	const double t_idx0 = walltime();
 	const int D = (int)o.devices.size();
+	for (int d = 0; d < D; ++d) (void)psvr_device_warmup(o.devices[(size_t)d], 4);     // the engines' queues are set up while the index loads
 	// one index per DISTINCT device: the first comes from the files, the others from it, device to device
 	std::vector<psvr_index_t *> idx((size_t)D, nullptr);
 	double t_idx_first = 0, t_idx_clone = 0;
@@ -311,6 +312,12 @@ int main(int argc, char **argv)
 		bool last = false;          // end-of-input marker travelling through the stages
 		long long batch_pairs_done = 0;   // > 0 on the last piece of a reference-sized batch: that batch's pairs (the progress line)
 	};
+	// PSVR_CLI_TIMING: when each stage had each piece (ms from the first FASTQ byte), printed at the end
+	static const bool cli_tl = getenv("PSVR_CLI_TIMING") != nullptr;
+	struct Span { double a = 0, b = 0; };
+	std::vector<Span> tl[4];
+	if (cli_tl) for (auto &v : tl) v.resize(1 << 16);
+	auto mark = [&](int stage, long long piece, double a, double b) { if (cli_tl && piece < (1 << 16)) tl[stage][(size_t)piece].a = a, tl[stage][(size_t)piece].b = b; };
 	const int kSlots = 5;
 	Job jobs[kSlots];
 	for (Job &J : jobs) J.blk = std::vector<Block>((size_t)D);
@@ -324,7 +331,8 @@ int main(int argc, char **argv)
 	size_t hbm_first = 0, hbm_last = 0;
 	EmitStats emit_stats;
 	std::thread reader([&]() {
-		long long loaded = 0, pair_base = 0;
+		long long loaded = 0, pair_base = 0, n_read_pieces = 0;
+		const long long kFirstPiece = 8192;
 		// the reference's batch: N_NEEDED pairs or MAX_read_size bases, whichever comes first (rr.cpp:24,109,126); it is read in pieces
 		// that end where it ends (a piece stops at what is left of both limits), so the batches are the reference's
 		long long in_batch_pairs = 0, in_batch_bases = 0;
@@ -333,10 +341,14 @@ int main(int argc, char **argv)
 			wait_state(J, 0);
 			long long want = o.batch_pairs - in_batch_pairs;
 			if (o.sub_pairs > 0 && o.sub_pairs < want) want = o.sub_pairs;
+			// the first pieces are short ones: the later stages have something to do after a millisecond of reading instead of ten, and the
+			// engine's first batch -- mostly set-up that does not depend on its size -- is through sooner
+			if (o.sub_pairs > 0 && n_read_pieces < 3 && (kFirstPiece << n_read_pieces) < want) want = kFirstPiece << n_read_pieces;
 			if (o.max_use_read - loaded < want) want = o.max_use_read - loaded;
 			double tw = walltime();
 			const bool ok = want > 0 && fq.read(J.fb, want, o.batch_bases - in_batch_bases, o.thread_n);
 			t_read += walltime() - tw;
+			mark(0, n_read_pieces++, tw, walltime());
 			if (!ok) { J.last = true; J.batch_pairs_done = in_batch_pairs; set_state(J, 1); return; }
 			if (loaded == 0) fq.stat_params(&par);          // STAT_ of the very first read (rr.cpp:134-148), before the first batch is aligned
 			loaded += J.fb.n_pairs();
@@ -352,6 +364,7 @@ int main(int argc, char **argv)
 	SamEmitter em;
 	em.H = &H, em.sv = &svn, em.as_bam = !o.sam, em.not_ori = o.not_ori, em.stats = &emit_stats;
 	std::thread formatter([&]() {
+		long long n_fmt_pieces = 0;
 		for (int slot = 0;; slot = (slot + 1) % kSlots) {
 			Job &J = jobs[slot];
 			wait_state(J, 2);
@@ -391,10 +404,12 @@ int main(int argc, char **argv)
 			};
 			thread_pool().run((int)(o.thread_n < nchunk ? o.thread_n : nchunk), [&](int) { work(); });
 			t_format += walltime() - tw;
+			mark(2, n_fmt_pieces++, tw, walltime());
 			set_state(J, 3);
 		}
 	});
 	std::thread writer([&]() {
+		long long n_wr_pieces = 0;
 		for (int slot = 0;; slot = (slot + 1) % kSlots) {
 			Job &J = jobs[slot];
 			wait_state(J, 3);
@@ -402,6 +417,7 @@ int main(int argc, char **argv)
 			const double tw = walltime();
 			for (size_t ci = 0; ci < J.mb.size(); ++ci) fo.write_raw(J.mb[ci]), fo_ori.write_raw(J.ob[ci]);
 			t_write += walltime() - tw;
+			mark(3, n_wr_pieces++, tw, walltime());
 			set_state(J, 0);
 		}
 	});
@@ -500,6 +516,7 @@ int main(int argc, char **argv)
 		}
 		++n_batches, total_pairs += P;
 		t_engine += walltime() - tw;
+		mark(1, n_batches - 1, tw, walltime());
 		set_state(J, 2);
 	}
 	reader.join(), formatter.join(), writer.join();
@@ -510,20 +527,30 @@ int main(int argc, char **argv)
 	}
 	if (!fo.close() || !fo_ori.close()) { fprintf(stderr, "fail to write output file\n"); abort(); }
 	if (frec) fclose(frec);
+	const double wall = walltime() - wall0;              // first FASTQ byte to the files closed; giving the HBM back is reported beside it, like the index load
 	for (int d = 0; d < D; ++d) if (eng[(size_t)d]) psvr_engine_destroy(eng[(size_t)d]);
 	for (int d = 0; d < D; ++d) {
 		bool dup = false;
 		for (int q = 0; q < d; ++q) if (idx[(size_t)q] == idx[(size_t)d]) dup = true;
 		if (!dup) psvr_index_destroy(idx[(size_t)d]);
 	}
-	const double wall = walltime() - wall0;
+	const double t_teardown = walltime() - wall0 - wall;
+	if (cli_tl) {
+		static const char *nm[4] = {"read", "engine", "format", "write"};
+		for (long long i = 0; i <= n_batches && i < (1 << 16); ++i) {
+			fprintf(stderr, "[panSVR-amd] piece %lld:", i);
+			for (int st = 0; st < 4; ++st) fprintf(stderr, "  %s %.1f-%.1f", nm[st], (tl[st][(size_t)i].a - wall0) * 1e3, (tl[st][(size_t)i].b - wall0) * 1e3);
+			fprintf(stderr, "\n");
+		}
+		fprintf(stderr, "[panSVR-amd] files closed at %.1f ms, engine and index released %.1f ms later\n", wall * 1e3, t_teardown * 1e3);
+	}
 	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
 	if (emit_stats.dropped) fprintf(stderr, "[panSVR-amd] %lld records were refused by the record rules of sam_parse1 and not written (see the ERROR lines above)\n", (long long)emit_stats.dropped);
 	fprintf(stderr, "[panSVR-amd] wall: read+parse %.3f s, engine (upload+run+download) %.3f s, format %.3f s, write%s %.3f s\n", t_read, t_engine, t_format, o.sam ? "" : "+compress", t_write);
 	fprintf(stderr,
 	        "[panSVR-amd] e2e_json {\"pairs\":%lld,\"batches\":%lld,\"pieces\":%lld,\"devices\":%d,\"threads\":%d,\"wall_s\":%.4f,\"index_s\":%.4f,\"index_first_s\":%.4f,\"index_clone_s\":%.4f,\"read_parse_s\":%.4f,"
-	        "\"engine_s\":%.4f,\"exchange_s\":%.4f,\"rebase_iterations\":%lld,\"format_s\":%.4f,\"write_s\":%.4f,\"d2h_bytes\":%lld,\"hbm_used_first\":%zu,\"hbm_used_last\":%zu,\"dropped\":%lld}\n",
+	        "\"engine_s\":%.4f,\"exchange_s\":%.4f,\"rebase_iterations\":%lld,\"format_s\":%.4f,\"write_s\":%.4f,\"d2h_bytes\":%lld,\"hbm_used_first\":%zu,\"hbm_used_last\":%zu,\"dropped\":%lld,\"teardown_s\":%.4f}\n",
 	        total_pairs, n_ref_batches, n_batches, D, o.thread_n, wall, t_index, t_idx_first, t_idx_clone, t_read, t_engine, t_exchange, rebase_iters, t_format, t_write, d2h_bytes, hbm_first, hbm_last,
-	        (long long)emit_stats.dropped);
+	        (long long)emit_stats.dropped, t_teardown);
 	return 0;
 }

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "common.h"
 #include "engine_core.h"
@@ -1144,6 +1146,34 @@ __global__ __launch_bounds__(256) void k_dp_fetch(Ctx c, long long begin, long l
 	}
 }
 
+// Streams kept per device for the engines of this process.  The first streams of a process each set up a hardware queue (3 - 14 ms a
+// stream, and the first copy on one another 8 ms): 25 - 40 ms of an engine's first batch.  psvr_device_warmup() does that on a thread of
+// its own while the caller is busy with something else (the command: loading the index); an engine takes its streams from here and
+// gives them back when it is destroyed, so the next engine of the process finds them too.
+struct StreamPool {
+	std::mutex mu;
+	std::vector<hipStream_t> idle[64];
+	hipStream_t get(int dev)
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if (dev >= 0 && dev < 64 && !idle[dev].empty()) { hipStream_t s = idle[dev].back(); idle[dev].pop_back(); return s; }
+		}
+		hipStream_t s = nullptr;
+		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+		return s;
+	}
+	void put(int dev, hipStream_t s)
+	{
+		if (!s) return;
+		(void)hipStreamSynchronize(s);
+		if (dev < 0 || dev >= 64) { (void)hipStreamDestroy(s); return; }
+		std::lock_guard<std::mutex> lk(mu);
+		idle[dev].push_back(s);
+	}
+};
+static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }        // (never destroyed: no HIP calls from a static destructor)
+
 struct GpuBE {
 	static constexpr unsigned int kArenaShards = kArenaMaxShards;   // storage arenas: one counter (cache line) per workgroup residue
 	hipStream_t stream = nullptr;
@@ -1153,7 +1183,8 @@ struct GpuBE {
 	DpParams dpP;
 	bool dp_ready = false, dp_lean = false;
 	static constexpr long long kTeamMinProblems = 32768;       // below this a round's DP problems go to the wavefront-per-alignment kernels
-	static constexpr int kSide = 4;                            // side streams: the DP kernels of a round are independent of each other
+	static constexpr int kSide = 3;                            // side streams: the DP kernels of a round are independent of each other
+	int device = -1;                                           // (for the stream pool)
 	hipStream_t side[kSide] = {};
 	hipEvent_t ev_fork = nullptr, ev_join[kSide] = {};
 	bool side_ok = false;
@@ -1163,7 +1194,7 @@ struct GpuBE {
 		if (ev_fork) return false;                                // tried before and failed: stay on the one stream
 		if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
 		for (int i = 0; i < kSide; ++i)
-			if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
+			if (!(side[i] = stream_pool().get(device)) || hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess) return false;
 		return side_ok = true;
 	}
 	// engine_core.h runs the pairing-only repeats on the first side stream: `stream` is switched, so the st_* launches follow
@@ -1333,7 +1364,7 @@ struct GpuBE {
 		if (up_ring) (void)hipHostFree(up_ring);
 		if (ev_early) (void)hipEventDestroy(ev_early);
 		for (int i = 0; i < kSide; ++i) {
-			if (side[i]) (void)hipStreamSynchronize(side[i]), (void)hipStreamDestroy(side[i]);
+			stream_pool().put(device, side[i]);
 			if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
 		}
 		if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -2172,6 +2203,34 @@ extern "C" int psvr_seed_mem_batch(const psvr_index_t *ix, int64_t n, const uint
 // ------------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------------
+extern "C" int psvr_device_warmup(int device, int n_streams)
+{
+	if (device < 0 || device >= 64 || n_streams < 1) return set_error(PSVR_ERR_ARG, "psvr_device_warmup: bad argument");
+	if (n_streams > 16) n_streams = 16;
+	std::thread([device, n_streams]() {
+		if (hipSetDevice(device) != hipSuccess) return;
+		std::vector<hipStream_t> got;
+		void *h = nullptr, *d = nullptr;
+		const bool buf = hipHostMalloc(&h, 4096, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, 4096) == hipSuccess;
+		if (buf) memset(h, 0, 4096);
+		for (int i = 0; i < n_streams; ++i) {
+			hipStream_t s = nullptr;
+			if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+			// a copy each way and a fill: the queue, the copy engines' paths and the fill kernel are set up by their first use
+			if (buf) (void)hipMemcpyAsync(d, h, 4096, hipMemcpyHostToDevice, s), (void)hipMemsetAsync(d, 0, 4096, s), (void)hipMemcpyAsync(h, d, 4096, hipMemcpyDeviceToHost, s);
+			(void)hipStreamSynchronize(s);
+			got.push_back(s);
+		}
+		if (h) (void)hipHostFree(h);
+		if (d) (void)hipFree(d);
+		(void)hipGetLastError();
+		StreamPool &P = stream_pool();
+		std::lock_guard<std::mutex> lk(P.mu);
+		for (hipStream_t s : got) P.idle[device].push_back(s);
+	}).detach();
+	return PSVR_OK;
+}
+
 struct psvr_engine {
 	const psvr_index *ix;
 	GpuBE be;
@@ -2194,8 +2253,8 @@ extern "C" int psvr_engine_create(const psvr_index_t *ix, const psvr_aln_params_
 	if (!ix || !par || !out) return set_error(PSVR_ERR_ARG, "psvr_engine_create: null argument");
 	PSVR_HIP(hipSetDevice(ix->device));
 	psvr_engine *e = new psvr_engine(ix);
-	if (hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking) != hipSuccess) e->own = nullptr;     // (the default queue then)
-	e->be.stream = e->own;
+	e->own = stream_pool().get(ix->device);                  // (nullptr: the default queue then)
+	e->be.stream = e->own, e->be.device = ix->device;
 	e->core.init(ix->dev, *par);
 	*out = e;
 	return PSVR_OK;
@@ -2206,8 +2265,10 @@ extern "C" void psvr_engine_destroy(psvr_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->ix->device);
 	e->core.free_all();
-	if (e->own) (void)hipStreamSynchronize(e->own), (void)hipStreamDestroy(e->own);
-	delete e;
+	const int dev = e->ix->device;
+	hipStream_t own = e->own;
+	delete e;                                                // (its backend gives the side streams back)
+	stream_pool().put(dev, own);
 }
 
 static int engine_status(psvr_engine *e, int rc)
