@@ -512,7 +512,7 @@ int main(int argc, char **argv)
 		fail_check();
 		{   // steady footprint: HBM in use on the first device after the first and after the latest batch
 			char sb[8192];
-			if (!psvr_engine_stats(eng[0], sb, sizeof sb)) { const char *q = strstr(sb, "\"hbm_used_bytes\":"); if (q) { hbm_last = strtoull(q + 17, nullptr, 10); if (!n_batches) hbm_first = hbm_last; } }
+			if (!psvr_engine_stats(eng[0], sb, sizeof sb)) { const char *q = strstr(sb, "\"hbm_used_bytes\":"); if (q) { hbm_last = strtoull(q + 17, nullptr, 10); if (n_batches <= 3) hbm_first = hbm_last; } }      // (first: after the first piece of full size -- the three before it are short ones)
 		}
 		++n_batches, total_pairs += P;
 		t_engine += walltime() - tw;

@@ -213,6 +213,7 @@ inline void put_seq_qual(RawOut &o, const char *t, const char *qt, int n, bool r
 }
 
 class SamEmitter {
+	friend struct EmitCheck;                         // tests/tools/emit_check.cpp: the fast scanners against the C library's
 public:
 	const HeaderInfo *H = nullptr;
 	const SvNames *sv = nullptr;

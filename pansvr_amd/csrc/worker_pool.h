@@ -20,6 +20,7 @@ class WorkerPool {
 	unsigned long long gen_ = 0;
 	int want_ = 0, left_ = 0;
 	bool stop_ = false;
+	bool busy_ = false;                               // (only the owning thread looks at it)
 	void loop(int id)
 	{
 		unsigned long long seen = 0;
@@ -48,6 +49,8 @@ public:
 	template <class F> void run(int n, F &&fn)
 	{
 		if (n <= 1) { if (n == 1) fn(0); return; }
+		if (busy_) { for (int t = 0; t < n; ++t) fn(t); return; }      // called from inside its own fn(0): one after the other, here
+		struct Busy { bool &b; explicit Busy(bool &x) : b(x) { b = true; } ~Busy() { b = false; } } mark(busy_);
 		while ((int)th_.size() < n - 1) { const int id = (int)th_.size() + 1; th_.emplace_back([this, id] { loop(id); }); }
 		{
 			std::lock_guard<std::mutex> lk(mu_);
