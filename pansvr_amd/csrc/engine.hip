@@ -217,30 +217,49 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 	int draws0 = 0;
 	unsigned n_act = 0;
 	int32_t listed[2] = {-1, -1};                                         // reads for the exact STR count, appended by the workgroup at the end
+	// The four Strand records of a pair are 192 contiguous bytes that every read gets reset to one pattern.  A wavefront whose 64 lanes have
+	// 64 consecutive pairs (the first round: no work list) writes its 12 KB of them as twelve coalesced stores instead of twelve stores of
+	// a 16-byte piece per lane 192 bytes apart (64 lines each: the kernel is bound by such requests)
+	bool strands_done = false;
+#if !defined(PSVR_PREP_STRAND_FILL) || PSVR_PREP_STRAND_FILL
+	if (work == nullptr && wi - lane + 63 < n) {
+		const uint32_t hl = (uint32_t)1469598103934665603ULL, hh = (uint32_t)(1469598103934665603ULL >> 32);
+		uint4 *st = (uint4 *)(c.strand + (wi - lane) * 4);
+#pragma unroll
+		for (int k = 0; k < 12; ++k) {
+			const int j = k * 64 + lane;
+			st[j] = j % 3 == 2 ? make_uint4(hl, hh, hl, hh) : make_uint4(0, 0, 0, 0);
+		}
+		strands_done = true;
+	}
+#endif
+#if !defined(PSVR_PREP_WORDS_STAGE) || PSVR_PREP_WORDS_STAGE
+	const bool coalesced = work == nullptr && wi - lane + 63 < n && 64 * 16 * c.wmax <= nb * 64 * 4;
+#else
+	const bool coalesced = false;
+#endif
 #pragma unroll 1
 	for (int mate = 0; mate < 2; ++mate) {
 		const long long read = slot * 2 + mate, sr = sp * 2 + mate, item = slot * 3 + mate;
-		// every lane of the wavefront, with or without a read, clears its share of the wavefront's bit sets
-		for (int k = lane; k < nb * 16; k += 64) ((uint4 *)bits)[k] = make_uint4(0, 0, 0, 0);
-		__builtin_amdgcn_wave_barrier();
-		if (!have) continue;
+		uint64_t F[W], Rv[W];                                              // the packed words of both strands (when `produce`)
+		int L = 0;
+		// ---- the lane's own part: false = no packed words from this lane (no read, an inactive one, or one prep_read() has redone)
+		const bool produce = [&]() -> bool {
+		if (!have) return false;
 		const uint32_t *ow = (const uint32_t *)(c.ori + sr);                // psvr_ori_t as words: chr_id, ref_bg, read_bg, align_score, {mapq, direction, unmapped, -}
 		const uint32_t o_chr = ow[0], o_score = ow[3], o_unm = (ow[4] >> 16) & 0xffu;
 		const long long bo0 = c.base_off[sr], bo1 = c.base_off[sr + 1];
-		const int L = (int)(bo1 - bo0);
+		L = (int)(bo1 - bo0);
 		const bool unm = o_unm != 0 || o_chr > 24u;
 		const bool act = !(L > 32 * W || L < kLenKmer) && !(!unm && o_score == (uint32_t)(L * c.par.match));
 		c.read_l[read] = L, c.unmapped[read] = unm, c.has_mem[read] = 0, c.hcnt[read] = 0, c.n_ccand[read] = 0, c.active[read] = act;
-#if defined(PSVR_DIAG_PREP) && PSVR_DIAG_PREP == 3     /* timing experiment: the Strand records are not reset (results are wrong) */
-		if (L < 0)
-#endif
-		{
+		if (!strands_done) {
 			uint4 *st = (uint4 *)(c.strand + read * 2);                       // two Strand records: counts and offsets 0, both hashes the FNV basis
 			const uint32_t hl = (uint32_t)1469598103934665603ULL, hh = (uint32_t)(1469598103934665603ULL >> 32);
 			st[0] = make_uint4(0, 0, 0, 0), st[1] = make_uint4(0, 0, 0, 0), st[2] = make_uint4(hl, hh, hl, hh);
 			st[3] = make_uint4(0, 0, 0, 0), st[4] = make_uint4(0, 0, 0, 0), st[5] = make_uint4(hl, hh, hl, hh);
 		}
-		if (!act) { c.is_str[read] = 0, c.rcnt[item] = 0; continue; }
+		if (!act) { c.is_str[read] = 0, c.rcnt[item] = 0; return false; }
 		++n_act;
 		const long long ro = p_off + (mate ? draws0 : 0);
 		int draws = 0, err = 0;
@@ -250,7 +269,6 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		const uintptr_t a = (uintptr_t)(c.bases + bo0);
 		const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
 		const uint32_t sh = (uint32_t)(a & 3);
-		uint64_t F[W];
 		uint32_t other[W];
 		uint32_t prev = q[0];
 #pragma unroll
@@ -315,18 +333,12 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 			c.is_str[read] = 2;
 			listed[mate] = (int32_t)read;
 			--n_act;
-			continue;
+			return false;
 		}
 		c.has_n4[read] = 0;
 		c.rcnt[item] = (mate && draws) ? kPrepMark | draws | (draws0 << 10) : draws;
-		uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
-#pragma unroll
-		for (int w = 0; w < W + 2; ++w) if (w < c.wmax) w0[w] = w < W ? F[w < W ? w : 0] : 0;
 		// ---- reverse strand: base j is 3 - base (L-1-j).  Shift the forward string right until it ends at the array's end,
 		// reverse the 2-bit groups of the whole array, complement, clear what lies behind base L-1.
-#if defined(PSVR_DIAG_PREP) && PSVR_DIAG_PREP == 2     /* timing experiment: no reverse strand (results are wrong) */
-		if (L < 0)
-#endif
 		{
 			uint64_t G[W];
 #pragma unroll
@@ -344,17 +356,42 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 				for (int w = W - 1; w >= 0; --w) G[w] = (G[w] >> r) | (w ? G[w ? w - 1 : 0] << (64 - r) : 0);
 			}
 #pragma unroll
-			for (int w = 0; w < W + 2; ++w) {
-				if (w >= c.wmax) continue;
-				uint64_t v = 0;
-				if (w < W) {
-					const int keep = L - 32 * w;                                    // bases of this word that exist
-					v = ~rev_groups2(G[w < W ? W - 1 - w : 0]);
-					v = keep <= 0 ? 0 : keep >= 32 ? v : v & (~0ull << (64 - 2 * keep));
-				}
-				w1[w] = v;
+			for (int w = 0; w < W; ++w) {
+				const int keep = L - 32 * w;                                    // bases of this word that exist
+				uint64_t v = ~rev_groups2(G[W - 1 - w]);
+				v = keep <= 0 ? 0 : keep >= 32 ? v : v & (~0ull << (64 - 2 * keep));
+				Rv[w] = v;
 			}
 		}
+		return true;
+		}();
+		// ---- the words go out.  A wavefront with 64 consecutive pairs (see the Strand records above) stages them in its LDS -- the bit sets'
+		// space, not yet in use -- and writes the 16-byte pieces of its reads side by side: wmax stores a mate that touch 16 lines each
+		// instead of 4 wmax stores of eight bytes per lane 32 wmax bytes apart (64 lines each)
+		if (coalesced) {
+			const int wm = c.wmax;
+			uint64_t *stg = (uint64_t *)bits + (size_t)lane * 2 * wm;
+			if (produce) {
+#pragma unroll
+				for (int w = 0; w < W + 2; ++w) if (w < wm) stg[w] = w < W ? F[w < W ? w : 0] : 0, stg[wm + w] = w < W ? Rv[w < W ? w : 0] : 0;
+			}
+			const unsigned long long pm = __ballot(produce);
+			__builtin_amdgcn_wave_barrier();
+			char *g0 = (char *)c.rb + ((wi - lane) * 2 + mate) * (long long)(16 * wm);
+			for (int q = lane; q < 64 * wm; q += 64) {
+				const int pl = q / wm, r = q - pl * wm;
+				if ((pm >> pl) & 1) *(uint4 *)(g0 + (long long)pl * (32 * wm) + r * 16) = ((const uint4 *)bits)[q];
+			}
+			__builtin_amdgcn_wave_barrier();
+		} else if (produce) {
+			uint64_t *w0 = c.rb + (read * 2) * (long long)c.wmax, *w1 = w0 + c.wmax;
+#pragma unroll
+			for (int w = 0; w < W + 2; ++w) if (w < c.wmax) w0[w] = w < W ? F[w < W ? w : 0] : 0, w1[w] = w < W ? Rv[w < W ? w : 0] : 0;
+		}
+		// every lane of the wavefront, with or without a read, clears its share of the wavefront's bit sets
+		for (int k = lane; k < nb * 16; k += 64) ((uint4 *)bits)[k] = make_uint4(0, 0, 0, 0);
+		__builtin_amdgcn_wave_barrier();
+		if (!produce) continue;
 		// ---- STR screen (rr.cpp:549-598 decides STR when fewer than kn - 15 of the kn 20-mers are distinct, i.e. at least 16 repeats):
 		// every 20-mer sets a hashed bit of the lane's set; one that finds its bit taken is a repeat or a collision, so fewer than
 		// 16 such events prove the read is not STR.  The few reads left (is_str = 2) get the exact count in k_str_detect.
