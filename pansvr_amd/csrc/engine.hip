@@ -233,6 +233,19 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		strands_done = true;
 	}
 #endif
+	// what both mates' turns start from, asked for once: the pair's three base offsets and the words of its two psvr_ori_t records (chr_id,
+	// ref_bg, read_bg, align_score, {mapq, direction, unmapped, -}) -- mate 1's turn then starts with its bases' loads instead of a round trip
+	// for their address -- and mate 1's first dword of bases, on its way while mate 0 is worked on
+	long long bo_0 = 0, bo_1 = 0, bo_2 = 0;
+	uint32_t oc0 = 0, os0 = 0, ou0 = 0, oc1 = 0, os1 = 0, ou1 = 0, first1 = 0;
+	if (have) {
+		const long long *bo = c.base_off + sp * 2;
+		bo_0 = bo[0], bo_1 = bo[1], bo_2 = bo[2];
+		const uint32_t *ow = (const uint32_t *)(c.ori + sp * 2);
+		static_assert(sizeof(psvr_ori_t) == 20, "psvr_ori_t as five words");
+		oc0 = ow[0], os0 = ow[3], ou0 = ow[4], oc1 = ow[5], os1 = ow[8], ou1 = ow[9];
+		first1 = *(const uint32_t *)((uintptr_t)(c.bases + bo_1) & ~(uintptr_t)3);
+	}
 #if !defined(PSVR_PREP_WORDS_STAGE) || PSVR_PREP_WORDS_STAGE
 	const bool coalesced = work == nullptr && wi - lane + 63 < n && 64 * 16 * c.wmax <= nb * 64 * 4;
 #else
@@ -246,9 +259,8 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		// ---- the lane's own part: false = no packed words from this lane (no read, an inactive one, or one prep_read() has redone)
 		const bool produce = [&]() -> bool {
 		if (!have) return false;
-		const uint32_t *ow = (const uint32_t *)(c.ori + sr);                // psvr_ori_t as words: chr_id, ref_bg, read_bg, align_score, {mapq, direction, unmapped, -}
-		const uint32_t o_chr = ow[0], o_score = ow[3], o_unm = (ow[4] >> 16) & 0xffu;
-		const long long bo0 = c.base_off[sr], bo1 = c.base_off[sr + 1];
+		const uint32_t o_chr = mate ? oc1 : oc0, o_score = mate ? os1 : os0, o_unm = ((mate ? ou1 : ou0) >> 16) & 0xffu;
+		const long long bo0 = mate ? bo_1 : bo_0, bo1 = mate ? bo_2 : bo_1;
 		L = (int)(bo1 - bo0);
 		const bool unm = o_unm != 0 || o_chr > 24u;
 		const bool act = !(L > 32 * W || L < kLenKmer) && !(!unm && o_score == (uint32_t)(L * c.par.match));
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 		const uint32_t *q = (const uint32_t *)(a & ~(uintptr_t)3);
 		const uint32_t sh = (uint32_t)(a & 3);
 		uint32_t other[W];
-		uint32_t prev = q[0];
+		uint32_t prev = mate ? first1 : q[0];
 #pragma unroll
 		for (int w = 0; w < W; ++w) {
 			uint64_t word = 0;
