@@ -1,5 +1,6 @@
 set -e
-# L1/L2 traffic counters per kernel for one bench step (separate --pmc passes); summary with tools/pmc_table.py-style grouping below
+# L1/L2 traffic counters per kernel for one bench step (separate --pmc passes, ~2.5 min each: every kernel of the index build is counted too; the same
+# command line as tools/gpu_round_profile.sh -- with a warm-up step or the parity sample a pass does not fit 300 s); a per-kernel table at the end
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-memc}
 mkdir -p $O
@@ -7,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p$i -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --no-e2e --no-cfg5 --one-pass > $O/p$i.log 2>&1 || { echo "set $i failed"; tail -n 5 $O/p$i.log; }
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-pairs 0 --check-pairs 0 --no-e2e --no-cfg5 --one-pass > $O/p$i.log 2>&1 || { echo "set $i failed"; tail -n 5 $O/p$i.log; }
 done
 python3 - $O <<'PY'
 import csv,glob,sys,collections
