@@ -641,8 +641,8 @@ def main():
             nt = min(48, ncore)                      # the reference's own thread limit (read_realignment.hpp:121)
             e2e = {"pairs": n_e2e, "threads": nt, "input": "FASTQ of the bench batch in RAM-backed storage (%.2f GB)" % (os.path.getsize(fq) / 1e9)}
             # SAM text; BAM at zlib's default level (what htslib's "wb" -- the reference's output -- uses); BAM at level 1 (--compress-level 1); BAM with the BGZF blocks
-            # compressed on the GPU (--bgzf-device)
-            for key, mode, ext in (("sam", ["-S"], "sam"), ("bam", [], "bam"), ("bam_level1", ["--compress-level", "1"], "bam"), ("bam_device", ["--bgzf-device"], "bam")):
+            # from the built-in encoder on the host threads (--bgzf-fast); ... compressed on the GPU (--bgzf-device)
+            for key, mode, ext in (("sam", ["-S"], "sam"), ("bam", [], "bam"), ("bam_level1", ["--compress-level", "1"], "bam"), ("bam_fast", ["--bgzf-fast"], "bam"), ("bam_device", ["--bgzf-device"], "bam")):
                 for fn in ("o." + ext, "p." + ext):      # (a 0.9 GB file opened for writing again is first emptied: 0.1 s of the next run's wall)
                     if os.path.exists(os.path.join(tmp, fn)):
                         os.remove(os.path.join(tmp, fn))

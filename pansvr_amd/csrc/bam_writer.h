@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 #include "worker_pool.h"
+#include "deflate_device.h"
 #ifdef PSVR_BGZF_ON_DEVICE                            /* (the CLI, which links the engine library: psvr_bgzf_compress) */
 #include "../../include/psvr_engine.h"
 #endif
@@ -71,7 +72,29 @@ class BgzfWriter {
 		for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
 		return clen + 26;
 	}
+	// the same member from this repository's own encoder (deflate_device.h, the one the device route runs a lane per member, here a host
+	// thread per member): greedy LZ77 + one dynamic-Huffman block.  1.6 x zlib level 1's speed per thread for members 8 - 10 % larger.
+	static size_t compress_block_fast(const uint8_t *p, size_t n, uint8_t *out)
+	{
+		static const int hbits = 13;
+		static thread_local std::vector<uint8_t> fast;
+		static thread_local std::vector<uint32_t> tok;
+		if (fast.empty()) fast.resize(df_fast_bytes(hbits) + 16), tok.resize(kDfMaxIn + 16);
+		if (n > kDfMaxIn) return 0;
+		uint32_t *tk = (uint32_t *)(((uintptr_t)tok.data() + 15) & ~(uintptr_t)15);
+		const size_t clen = deflate_block(p, (uint32_t)n, out + 18, (uint32_t)(0x10000 - 26), fast.data(), hbits, tk);
+		if (!clen) return 0;
+		const size_t bsize = clen + 18 + 8 - 1;
+		static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+		memcpy(out, hdr, 16);
+		out[16] = (uint8_t)(bsize & 0xff), out[17] = (uint8_t)(bsize >> 8);
+		const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+		uint8_t *t = out + 18 + clen;
+		for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i)), t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+		return clen + 26;
+	}
 public:
+	static const int kLevelFast = -2;             // `level`: zlib's levels, Z_DEFAULT_COMPRESSION (-1), or this: compress_block_fast
 	static size_t compress_block_public(const uint8_t *p, size_t n, uint8_t *out) { return compress_block(p, n, out); }   // out: 0x10000 + 64 bytes
 private:
 	// blocks are independent: compress them on `threads_` threads, write in order
@@ -99,7 +122,7 @@ private:
 		auto work = [&]() {
 			for (size_t b = next++; b < nb; b = next++) {
 				const size_t o = b * kBlock, m = n - o < kBlock ? n - o : kBlock;
-				len[b] = compress_block(p + o, m, out.data() + b * kOut, level_);
+				len[b] = level_ == kLevelFast ? compress_block_fast(p + o, m, out.data() + b * kOut) : compress_block(p + o, m, out.data() + b * kOut, level_);
 			}
 		};
 		const int nt = threads_ < 1 ? 1 : (size_t)threads_ > nb ? (int)nb : threads_;

@@ -88,6 +88,7 @@ static int usage()
 	        "        --batch-bases       INT  bases per batch (the reference stops a batch at 100 MB of bases) [100000000]\n"
 	        "        --sub-batch         INT  pairs per pipeline piece of a batch, 0 = whole batches (results do not depend on it) [65536]\n"
 	        "        --compress-level    INT  zlib level of the BAM output's BGZF blocks, 0-9 (1 is ~3x faster than the default) [-1 = default, like htslib]\n"
+	        "        --bgzf-fast              BGZF blocks from the built-in encoder on the -t threads (1.6x the speed of level 1, blocks ~10% larger)\n"
 	        "        --bgzf-device            compress the BAM output's BGZF blocks on the GPU (a lane per block; ~10 %% larger than zlib level 1,\n"
 	        "                                 the host's deflate is what bounds the BAM route otherwise)\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"
@@ -184,7 +185,7 @@ int main(int argc, char **argv)
 	static struct option lo[] = {{"thread", 1, 0, 't'}, {"gap-open1", 1, 0, 'O'}, {"gap-open2", 1, 0, 'P'}, {"gap-extension1", 1, 0, 'E'}, {"gap-extension2", 1, 0, 'F'},
 	                             {"match-score", 1, 0, 'M'}, {"mis-score", 1, 0, 'm'}, {"zdrop", 1, 0, 'z'}, {"band-width", 1, 0, 'w'}, {"output", 1, 0, 'o'},
 	                             {"output_signal_ori", 1, 0, 'p'}, {"not-ori", 0, 0, 'Q'}, {"SAM", 0, 0, 'S'}, {"max_use_read", 1, 0, 'R'}, {"device", 1, 0, 1000},
-	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006}, {"sub-batch", 1, 0, 1007}, {"bgzf-device", 0, 0, 1008},
+	                             {"records", 1, 0, 1001}, {"trace", 0, 0, 1002}, {"batch", 1, 0, 1003}, {"devices", 1, 0, 1004}, {"batch-bases", 1, 0, 1005}, {"compress-level", 1, 0, 1006}, {"sub-batch", 1, 0, 1007}, {"bgzf-device", 0, 0, 1008}, {"bgzf-fast", 0, 0, 1009},
 	                             {"not-use-filter", 0, 0, 'D'}, {"discard-full-match", 0, 0, 'U'}, {"sort-by-name", 0, 0, 'N'}, {0, 0, 0, 0}};
 	int c;
 	bool sig_by_name = false;
@@ -213,6 +214,7 @@ int main(int argc, char **argv)
 		case 1005: o.batch_bases = atoll(optarg); break;
 		case 1007: o.sub_pairs = atoll(optarg); break;
 		case 1008: o.bgzf_device = true; break;
+		case 1009: o.bam_level = psvr::BgzfWriter::kLevelFast; break;
 		case 1006: o.bam_level = atoi(optarg); if (o.bam_level < -1 || o.bam_level > 9) { fprintf(stderr, "--compress-level wants -1 .. 9\n"); return 1; } break;
 		case 'D': o.sig_all = true; break;
 		case 'U': o.sig_discard = true; break;

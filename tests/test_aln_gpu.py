@@ -79,6 +79,12 @@ def test_gpu_cli_bam_output_equals_sam_text():
     assert bam_reader.check_bgzf(os.path.join(tmp, "outd.bam")) >= 1
     assert bam_reader.read_bam(os.path.join(tmp, "outd.bam")) == bam_reader.read_bam(os.path.join(tmp, "out.bam"))
     assert bam_reader.read_bam(os.path.join(tmp, "orid.bam")) == bam_reader.read_bam(os.path.join(tmp, "ori.bam"))
+    # ... and from the built-in encoder on the host threads (--bgzf-fast)
+    r = subprocess.run([CLI, "aln", "--bgzf-fast", "-t", "4", "-o", os.path.join(tmp, "outf.bam"), "-p", os.path.join(tmp, "orif.bam")] + base, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert bam_reader.check_bgzf(os.path.join(tmp, "outf.bam")) >= 1
+    assert bam_reader.read_bam(os.path.join(tmp, "outf.bam")) == bam_reader.read_bam(os.path.join(tmp, "out.bam"))
+    assert bam_reader.read_bam(os.path.join(tmp, "orif.bam")) == bam_reader.read_bam(os.path.join(tmp, "ori.bam"))
     header = open(os.path.join(w, "header.sam")).read()
     for stem in ("out", "ori"):
         assert bam_reader.check_bgzf(os.path.join(tmp, stem + ".bam")) >= 1

@@ -14,7 +14,8 @@ int main(int argc, char **argv)
 {
 	psvr::BamWriter w;
 	std::vector<psvr::BamRef> refs = {{"chr1", 1000000}, {"chr2", 2000000}};
-	if (!w.open(argv[1], "@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:1000000\n@SQ\tSN:chr2\tLN:2000000\n", refs)) return 2;
+	const int level = argc > 2 ? atoi(argv[2]) : Z_DEFAULT_COMPRESSION;        // -2: the built-in encoder (--bgzf-fast)
+	if (!w.open(argv[1], "@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:1000000\n@SQ\tSN:chr2\tLN:2000000\n", refs, 3, level)) return 2;
 	for (int i = 0; i < 3000; ++i) {
 		psvr::SamFields f;
 		f.qname = "r" + std::to_string(i), f.flag = i % 2 ? 0x50 : 0x83, f.tid = i % 2, f.pos1 = 100 + i * 337, f.mapq = i % 61;
@@ -29,11 +30,15 @@ int main(int argc, char **argv)
 '''
 
 
-def test_bam_writer_round_trip():
+import pytest
+
+
+@pytest.mark.parametrize("level", [-1, 1, -2])
+def test_bam_writer_round_trip(level):
     d = tempfile.mkdtemp(prefix="psvr_bamw_")
     open(os.path.join(d, "t.cpp"), "w").write(DRIVER)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ac.ROOT, "pansvr_amd", "csrc"), "-o", os.path.join(d, "t"), os.path.join(d, "t.cpp"), "-lz"])
-    subprocess.check_call([os.path.join(d, "t"), os.path.join(d, "x.bam")])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ac.ROOT, "pansvr_amd", "csrc"), "-o", os.path.join(d, "t"), os.path.join(d, "t.cpp"), "-lz", "-lpthread"])
+    subprocess.check_call([os.path.join(d, "t"), os.path.join(d, "x.bam"), str(level)])
     assert bam_reader.check_bgzf(os.path.join(d, "x.bam")) > 2          # several 0xff00-byte blocks + EOF
     text, refs, recs = bam_reader.read_bam(os.path.join(d, "x.bam"))
     assert text.startswith("@HD") and refs == [("chr1", 1000000), ("chr2", 2000000)] and len(recs) == 3000

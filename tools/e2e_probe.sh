@@ -44,6 +44,10 @@ fi
 [ "$2" = "sam-only" ] && { rm -rf $D; exit 0; }
 run "BAM t=48" -t 48 -o $D/o.bam -p $D/p.bam
 run "BAM level1 t=48" -t 48 --compress-level 1 -o $D/o.bam -p $D/p.bam
+ls -l $D/o.bam | awk '{print "  o.bam bytes", $5}' | tee -a $O/probe.txt
+run "BAM fast t=48" -t 48 --bgzf-fast -o $D/o.bam -p $D/p.bam
+ls -l $D/o.bam | awk '{print "  o.bam bytes", $5}' | tee -a $O/probe.txt
+run "BAM fast t=16" -t 16 --bgzf-fast -o $D/o.bam -p $D/p.bam
 run "BAM device t=48" -t 48 --bgzf-device -o $D/o.bam -p $D/p.bam
 run "BAM device t=16" -t 16 --bgzf-device -o $D/o.bam -p $D/p.bam
 rm -rf $D
