@@ -88,7 +88,7 @@ static int usage()
 	        "        --batch-bases       INT  bases per batch (the reference stops a batch at 100 MB of bases) [100000000]\n"
 	        "        --sub-batch         INT  pairs per pipeline piece of a batch, 0 = whole batches (results do not depend on it) [65536]\n"
 	        "        --compress-level    INT  zlib level of the BAM output's BGZF blocks, 0-9 (1 is ~3x faster than the default) [-1 = default, like htslib]\n"
-	        "        --bgzf-fast              BGZF blocks from the built-in encoder on the -t threads (1.6x the speed of level 1, blocks ~10% larger)\n"
+	        "        --bgzf-fast              BGZF blocks from the built-in encoder on the -t threads (1.6x the speed of level 1, blocks ~10%% larger)\n"
 	        "        --bgzf-device            compress the BAM output's BGZF blocks on the GPU (a lane per block; ~10 %% larger than zlib level 1,\n"
 	        "                                 the host's deflate is what bounds the BAM route otherwise)\n"
 	        "        --records           STR  dump per-pair decision records (JSON lines) for parity checks\n"

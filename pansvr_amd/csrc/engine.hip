@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep_pair(Ctx c, const int32_t *work,
 #endif
 #pragma unroll 1
 	for (int mate = 0; mate < 2; ++mate) {
-		const long long read = slot * 2 + mate, sr = sp * 2 + mate, item = slot * 3 + mate;
+		const long long read = slot * 2 + mate, item = slot * 3 + mate;
 		uint64_t F[W], Rv[W];                                              // the packed words of both strands (when `produce`)
 		int L = 0;
 		// ---- the lane's own part: false = no packed words from this lane (no read, an inactive one, or one prep_read() has redone)
