@@ -621,7 +621,7 @@ def main():
                 if ms <= 0:
                     continue
                 gbs = own_bytes[g] * 2 * args.pairs / (ms * 1e-3) / 1e9
-                tr = traffic_of([k for k in names if k in kern])
+                tr = traffic_of(names)       # (every kernel of the group the counters saw: the engine times the preparation kernels under one name, the counters name three)
                 row = {"kernels": g, "own_alg_bytes_per_read": round(own_bytes[g], 1), "ms_per_step": round(ms, 4), "achieved_GBps": round(gbs, 2), "frac_of_hbm_peak": round(gbs / 8000.0, 6),
                        "traffic": tr, "traffic_over_algorithmic": round(tr / (own_bytes[g] * 2 * args.pairs), 2) if tr and own_bytes[g] > 0 else None}
                 if g == "extd2_*":
